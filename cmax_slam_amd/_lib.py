@@ -1,0 +1,96 @@
+"""ctypes loader for libcmaxhip.so (the C ABI declared in include/cmax_hip.h).
+
+There is no fallback of any kind: if the HIP extension is missing or fails to load, importing the
+evaluators raises.  Nothing in this package touches oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcmaxhip.so")
+
+OK, ERR_INVALID_ARG, ERR_EVENT_RANGE, ERR_HIP, ERR_SPLINE_RANGE, ERR_STATE, ERR_TIME_ORDER = range(7)
+VARIANCE, MEAN_SQUARE, GRADIENT_MAGNITUDE = 0, 1, 2
+GRAD_PLANES, GRAD_ADJOINT = 0, 1
+OPT_GRAD_MODE, OPT_SPLAT_MODE = 1, 2
+PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
+T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COUNT = 0, 1, 2, 3, 4, 5
+T_NAMES = ("splat", "image", "pose", "gather", "zero")
+
+c_dp = C.POINTER(C.c_double)
+c_fp = C.POINTER(C.c_float)
+c_u16p = C.POINTER(C.c_uint16)
+c_i64p = C.POINTER(C.c_int64)
+ctx_p = C.c_void_p
+
+# every symbol include/cmax_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "cmx_version": (C.c_char_p, []),
+    "cmx_device_count": (C.c_int, []),
+    "cmx_last_error": (C.c_char_p, [ctx_p]),
+    "cmx_status_string": (C.c_char_p, [C.c_int]),
+    "cmx_destroy": (None, [ctx_p]),
+    "cmx_set_option": (C.c_int, [ctx_p, C.c_int, C.c_int]),
+    "cmx_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
+    "cmx_frontend_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, c_dp]),
+    "cmx_frontend_set_packet": (C.c_int, [ctx_p, C.c_int64, c_u16p, c_u16p, c_i64p, C.c_int64, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, C.c_int, C.c_double, C.c_int]),
+    "cmx_frontend_eval": (C.c_int, [ctx_p, c_dp, c_dp, c_dp]),
+    "cmx_frontend_get_iwe": (C.c_int, [ctx_p, c_dp, C.c_int, c_fp, c_fp]),
+    "cmx_backend_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_int]),
+    "cmx_backend_set_window": (C.c_int, [ctx_p, C.c_int64, c_u16p, c_u16p, c_i64p, C.c_int, C.c_int, c_dp, C.c_int64,
+                                         C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, c_fp]),
+    "cmx_backend_eval": (C.c_int, [ctx_p, c_dp, c_dp, c_dp]),
+    "cmx_backend_get_plane": (C.c_int, [ctx_p, C.c_int, c_fp]),
+    "cmx_backend_get_alpha": (C.c_int, [ctx_p, c_dp]),
+    "cmx_traj_temp_start_ns": (C.c_int64, [C.c_double, C.c_int, C.c_double]),
+    "cmx_accum_capacity": (C.c_size_t, [ctx_p]),
+    "cmx_set_accum_buffer": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),
+    "cmx_accum_ptr": (C.c_void_p, [ctx_p]),
+    "cmx_accum_count": (C.c_size_t, [ctx_p]),
+    "cmx_frontend_accumulate": (C.c_int, [ctx_p, c_dp, C.c_int]),
+    "cmx_frontend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_backend_accumulate": (C.c_int, [ctx_p, c_dp, C.c_int]),
+    "cmx_backend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_timing_enable": (C.c_int, [ctx_p, C.c_int]),
+    "cmx_timing_get": (C.c_int, [ctx_p, c_dp, c_i64p]),
+}
+
+_LIB = None
+
+
+class CmaxHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("cmax-hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+def build(force=False):
+    """Compile libcmaxhip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(SO_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+def lib():
+    """Load the HIP extension; raises if it is missing (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("libcmaxhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the event-warping path)")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(ctx, status):
+    if status != OK:
+        L = lib()
+        msg = L.cmx_last_error(ctx).decode() if ctx else ""
+        raise CmaxHipError(status, (L.cmx_status_string(status).decode() + (": " + msg if msg else "")))

@@ -1,0 +1,829 @@
+// cmx_capi.cpp -- the extern "C" boundary declared in include/cmax_hip.h: context management, event upload
+// (SoA packing, per-batch time tables), evaluation sequencing on a HIP stream.  All compute is in
+// cmx_kernels.hip; there is NO CPU fallback: every entry point fails loudly if HIP is unavailable.
+#include "../../include/cmax_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cmx_internal.hpp"
+
+using namespace cmx;
+
+namespace {
+
+enum { KIND_FE = 1, KIND_BE = 2 };
+
+struct TimedSpan { int cls; hipEvent_t a, b; };
+
+}  // namespace
+
+struct cmx_ctx {
+  int kind = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // sensor + LUT
+  int W = 0, H = 0;
+  double *d_lut = nullptr;
+
+  // packed events
+  uint32_t *d_xy = nullptr;
+  size_t xy_cap = 0;
+  int n_packed = 0, per_batch = 1, nb = 0;
+  bool have_data = false;
+
+  // config shared by both ends
+  int batch = 100, sample_rate = 1, measure = CMX_VARIANCE;
+  double sigma = 0;
+  int radius = 0;
+  float taps[2 * kMaxRadius + 1] = {1.f};
+  int grad_mode = CMX_GRAD_PLANES, splat_mode = 0;
+
+  // front end
+  double fx = 0, fy = 0, cx = 0, cy = 0;
+  double *d_batch_dt = nullptr;
+  size_t batch_cap = 0;
+
+  // back end
+  int Wp = 0, Hp = 0, order = 0, K = 0, num_fixed = 0;
+  long long *d_batch_t = nullptr;
+  PoseEntry *d_poses = nullptr;
+  size_t batch_t_cap = 0, poses_cap = 0;
+  SplineArgs *d_spline = nullptr, *h_spline = nullptr;  // h_spline: pinned staging
+  std::vector<Quat> knots0;
+  float *d_IG = nullptr, *d_IGp = nullptr;
+  bool ig_nonzero = false, first_iter = true;
+  double *d_alpha = nullptr;
+
+  // image planes
+  int imgW = 0, imgH = 0;  // W,H (front end) or Wp,Hp (back end)
+  float *d_accum = nullptr;
+  size_t accum_cap = 0, accum_count = 0;
+  bool accum_external = false;
+  float *d_scratch = nullptr;  // blurred-plane readback scratch
+  size_t scratch_cap = 0;
+  int last_P = 0;              // derivative planes produced by the last accumulate()
+  bool accumulated = false;
+
+  // reductions
+  double *d_partials = nullptr, *d_sums = nullptr;
+  size_t partials_cap = 0, sums_cap = 0;
+  double *h_result = nullptr, *d_result = nullptr;  // mapped pinned host
+  size_t result_cap = 0;
+
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  double t_ms[CMX_T_COUNT] = {0};
+  int64_t t_n[CMX_T_COUNT] = {0};
+};
+
+namespace {
+
+int fail(cmx_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail((c), CMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int ensure(cmx_ctx *c, T *&ptr, size_t &cap, size_t need) {
+  if (need <= cap && ptr) return CMX_OK;
+  if (ptr) HIP_TRY(c, hipFree(ptr));
+  ptr = nullptr;
+  cap = 0;
+  size_t n = need ? need : 1;
+  HIP_TRY(c, hipMalloc((void **)&ptr, n * sizeof(T)));
+  cap = n;
+  return CMX_OK;
+}
+
+int bind(cmx_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return CMX_OK;
+}
+
+// ---- ros::Time arithmetic (roscpp noetic semantics), needed to reproduce the per-batch pose time:
+//   time_batch = time_first + (time_last - time_first) * 0.5         [Duration*double -> fromSec: floor + round]
+//   reference: local_image_warped_events.cpp:68-75, event_pano_warper.cpp:239-242
+long long time_batch_ns(long long t_first, long long t_last) {
+  const long long d = t_last - t_first;
+  long long ds = d / 1000000000LL, dn = d % 1000000000LL;
+  if (dn < 0) { dn += 1000000000LL; ds -= 1; }
+  const double half = ((double)ds + 1e-9 * (double)dn) * 0.5;
+  const long long hs = (long long)floor(half);
+  const long long hn = (long long)round((half - (double)hs) * 1e9);
+  return t_first + hs * 1000000000LL + hn;
+}
+double time_to_sec(long long t_ns) {  // ros::Time::toSec
+  return (double)(t_ns / 1000000000LL) + 1e-9 * (double)(t_ns % 1000000000LL);
+}
+
+// cv::GaussianBlur(Size(0,0), sigma) on CV_32F: ksize = cvRound(sigma*8+1)|1; fp64 kernel normalised, cast to fp32
+int setup_blur(cmx_ctx *c, double sigma) {
+  c->sigma = sigma;
+  if (!(sigma > 0)) {
+    c->radius = 0;
+    c->taps[0] = 1.f;
+    return CMX_OK;
+  }
+  const int n = ((int)lrint(sigma * 4 * 2 + 1)) | 1;
+  const int r = n / 2;
+  if (r > kMaxRadius) return fail(c, CMX_ERR_INVALID_ARG, "blur_sigma %.3f needs radius %d > %d", sigma, r, kMaxRadius);
+  double t[2 * kMaxRadius + 1], sum = 0;
+  const double scale2X = -0.5 / (sigma * sigma);
+  for (int i = 0; i < n; i++) {
+    const double x = i - (n - 1) * 0.5;
+    t[i] = exp(scale2X * x * x);
+    sum += t[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; i++) c->taps[i] = (float)(t[i] * sum);
+  c->radius = r;
+  return CMX_OK;
+}
+
+// ---- timing helpers
+hipEvent_t get_event(cmx_ctx *c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+struct Span {
+  cmx_ctx *c;
+  TimedSpan s{};
+  bool on;
+  Span(cmx_ctx *ctx, int cls) : c(ctx), on(ctx->timing) {
+    if (on) {
+      s.cls = cls;
+      s.a = get_event(c);
+      s.b = get_event(c);
+      hipEventRecord(s.a, c->stream);
+    }
+  }
+  ~Span() {
+    if (on) {
+      hipEventRecord(s.b, c->stream);
+      c->spans.push_back(s);
+    }
+  }
+};
+void collect_spans(cmx_ctx *c) {  // call after the stream has been synchronised
+  for (auto &s : c->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      c->t_ms[s.cls] += ms;
+      c->t_n[s.cls] += 1;
+    }
+    c->event_pool.push_back(s.a);
+    c->event_pool.push_back(s.b);
+  }
+  c->spans.clear();
+}
+
+int create_common(cmx_ctx **out, int kind, int device, int W, int H, const double *lut) {
+  if (!out) return CMX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || !lut) return CMX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CMX_ERR_HIP;  // no CPU fallback
+  if (device < 0 || device >= ndev) return CMX_ERR_INVALID_ARG;
+  cmx_ctx *c = new cmx_ctx();
+  c->kind = kind;
+  c->device = device;
+  c->W = W;
+  c->H = H;
+  *out = c;  // returned even on failure below so the caller can read cmx_last_error and destroy it
+  HIP_TRY(c, hipSetDevice(device));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  const size_t nl = (size_t)W * H * 3;
+  HIP_TRY(c, hipMalloc((void **)&c->d_lut, nl * sizeof(double)));
+  HIP_TRY(c, hipMemcpy(c->d_lut, lut, nl * sizeof(double), hipMemcpyHostToDevice));
+  c->result_cap = 4096;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
+  return CMX_OK;
+}
+
+int ensure_accum(cmx_ctx *c, size_t need) {
+  if (c->accum_external) {
+    if (need > c->accum_cap)
+      return fail(c, CMX_ERR_INVALID_ARG, "external accumulation buffer too small: %zu < %zu floats", c->accum_cap, need);
+    return CMX_OK;
+  }
+  return ensure(c, c->d_accum, c->accum_cap, need);
+}
+
+// image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
+int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
+  const int W = c->imgW, H = c->imgH;
+  const size_t np = (size_t)W * H;
+  ImgArgs a{};
+  a.W = W;
+  a.H = H;
+  a.r = c->radius;
+  memcpy(a.taps, c->taps, sizeof(a.taps));
+  if (c->kind == KIND_FE) {
+    a.src_a = c->d_accum;
+    a.src_b = nullptr;
+    a.igp = nullptr;
+    a.alpha = nullptr;
+    a.dplanes = c->d_accum + np;
+  } else {
+    a.src_a = c->d_accum;
+    a.src_b = c->d_accum + np;
+    a.igp = c->ig_nonzero ? c->d_IGp : nullptr;
+    a.alpha = c->d_alpha;
+    a.dplanes = c->d_accum + 2 * np;
+  }
+  a.P = P;
+  a.out_blur0 = out_blur0;
+  a.out_blurd = out_blurd;
+  a.tiles_x = (W + kTileX - 1) / kTileX;
+  a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  const size_t nq = 2 + 2 * (size_t)P;
+  int rc = ensure(c, c->d_partials, c->partials_cap, nq * a.nblk);
+  if (rc) return rc;
+  rc = ensure(c, c->d_sums, c->sums_cap, nq);
+  if (rc) return rc;
+  if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many derivative planes (%d)", P);
+  a.partials = c->d_partials;
+  {
+    Span sp(c, CMX_T_IMAGE);
+    launch_image_moments(a, c->stream);
+    FinalizeArgs f{};
+    f.P = P;
+    f.nblk = a.nblk;
+    f.measure = c->measure;
+    f.npix = (double)np;
+    f.partials = c->d_partials;
+    f.sums = c->d_sums;
+    f.result = c->d_result;
+    launch_finalize(f, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
+}
+
+int sync_and_collect(cmx_ctx *c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->timing) collect_spans(c);
+  return CMX_OK;
+}
+
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
+  if (n < 0 || n > 0x7fffffffLL) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
+  if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
+  for (int64_t i = 0; i < n; i++)
+    if (x[i] >= c->W || y[i] >= c->H)
+      return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, x[i], y[i], c->W, c->H);
+  return CMX_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== generic
+extern "C" {
+
+const char *cmx_version(void) { return "cmax-hip 0.1 (gfx950)"; }
+
+int cmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *cmx_last_error(const cmx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char *cmx_status_string(int s) {
+  switch (s) {
+    case CMX_OK: return "ok";
+    case CMX_ERR_INVALID_ARG: return "invalid argument";
+    case CMX_ERR_EVENT_RANGE: return "event coordinates outside the sensor";
+    case CMX_ERR_HIP: return "HIP runtime error (no GPU / launch failure)";
+    case CMX_ERR_SPLINE_RANGE: return "batch time outside the spline's knot support";
+    case CMX_ERR_STATE: return "call sequence error";
+    case CMX_ERR_TIME_ORDER: return "event batch spans a negative time interval";
+    default: return "unknown status";
+  }
+}
+
+void cmx_destroy(cmx_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  hipFree(c->d_lut);
+  hipFree(c->d_xy);
+  hipFree(c->d_batch_dt);
+  hipFree(c->d_batch_t);
+  hipFree(c->d_poses);
+  hipFree(c->d_spline);
+  if (c->h_spline) hipHostFree(c->h_spline);
+  hipFree(c->d_IG);
+  hipFree(c->d_IGp);
+  hipFree(c->d_alpha);
+  if (!c->accum_external) hipFree(c->d_accum);
+  hipFree(c->d_scratch);
+  hipFree(c->d_partials);
+  hipFree(c->d_sums);
+  if (c->h_result) hipHostFree(c->h_result);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int cmx_set_option(cmx_ctx *c, int key, int value) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  switch (key) {
+    case CMX_OPT_GRAD_MODE:
+      if (value != CMX_GRAD_PLANES && value != CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "bad grad mode %d", value);
+      if (value == CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "CMX_GRAD_ADJOINT not available in this build");
+      c->grad_mode = value;
+      return CMX_OK;
+    case CMX_OPT_SPLAT_MODE:
+      if (value != 0) return fail(c, CMX_ERR_INVALID_ARG, "splat mode %d not available in this build", value);
+      c->splat_mode = value;
+      return CMX_OK;
+    default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
+  }
+}
+
+int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind(c);
+  if (rc) return rc;
+  if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) { HIP_TRY(c, hipStreamDestroy(c->stream)); c->stream = nullptr; c->own_stream = false; }
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return CMX_OK;
+}
+
+int cmx_timing_enable(cmx_ctx *c, int on) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  c->timing = on != 0;
+  return CMX_OK;
+}
+int cmx_timing_get(cmx_ctx *c, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  for (int i = 0; i < CMX_T_COUNT; i++) {
+    if (ms) ms[i] = c->t_ms[i];
+    if (launches) launches[i] = c->t_n[i];
+    c->t_ms[i] = 0;
+    c->t_n[i] = 0;
+  }
+  return CMX_OK;
+}
+
+size_t cmx_accum_capacity(const cmx_ctx *c) {
+  if (!c) return 0;
+  if (c->kind == KIND_FE) return (size_t)4 * c->W * c->H;
+  const int P = 3 * (c->K - c->num_fixed);
+  return (size_t)(2 + (P > 0 ? P : 0)) * c->Wp * c->Hp;
+}
+int cmx_set_accum_buffer(cmx_ctx *c, void *device_ptr, size_t n_floats) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->accum_external && c->d_accum) HIP_TRY(c, hipFree(c->d_accum));
+  c->d_accum = (float *)device_ptr;
+  c->accum_cap = device_ptr ? n_floats : 0;
+  c->accum_external = device_ptr != nullptr;
+  c->accumulated = false;
+  return CMX_OK;
+}
+void *cmx_accum_ptr(const cmx_ctx *c) { return c ? c->d_accum : nullptr; }
+size_t cmx_accum_count(const cmx_ctx *c) { return c ? c->accum_count : 0; }
+
+int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots) {
+  const double t = t_beg + idx_traj_beg * dt_knots;
+  return (int64_t)(1e9 * t);
+}
+
+// =============================================================================================== front end
+int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *lut) {
+  int rc = create_common(out, KIND_FE, device, W, H, lut);
+  if (rc) return rc;
+  (*out)->imgW = W;
+  (*out)->imgH = H;
+  return CMX_OK;
+}
+
+int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                            int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
+                            double blur_sigma, int contrast_measure) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  int rc = bind(c);
+  if (rc) return rc;
+  c->have_data = false;
+  c->accumulated = false;
+  if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
+  if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
+    return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d is not implemented on the GPU (variance / mean-square only)",
+                contrast_measure);
+  rc = check_events(c, n, x, y, t_ns);
+  if (rc) return rc;
+  rc = setup_blur(c, blur_sigma);
+  if (rc) return rc;
+  c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy;
+  c->batch = event_batch_size;
+  c->measure = contrast_measure;
+
+  // SoA packing + per-batch dt = time_batch.toSec() - time_ref.toSec()  (local_image_warped_events.cpp:68-75)
+  const int nb = (int)((n + event_batch_size - 1) / event_batch_size);
+  std::vector<uint32_t> xy((size_t)n);
+  for (int64_t i = 0; i < n; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+  std::vector<double> dts((size_t)nb);
+  const double tref = time_to_sec(t_ref_ns);
+  for (int b = 0; b < nb; b++) {
+    const int64_t beg = (int64_t)b * event_batch_size;
+    const int64_t end = (beg + event_batch_size < n) ? beg + event_batch_size : n;
+    if (t_ns[end - 1] < t_ns[beg]) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", b);
+    dts[b] = time_to_sec(time_batch_ns(t_ns[beg], t_ns[end - 1])) - tref;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = ensure(c, c->d_xy, c->xy_cap, (size_t)n);
+  if (rc) return rc;
+  rc = ensure(c, c->d_batch_dt, c->batch_cap, (size_t)nb);
+  if (rc) return rc;
+  if (n) {
+    HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_batch_dt, dts.data(), (size_t)nb * sizeof(double), hipMemcpyHostToDevice));
+  }
+  c->n_packed = (int)n;
+  c->per_batch = event_batch_size;
+  c->nb = nb;
+  c->have_data = true;
+  return CMX_OK;
+}
+
+static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+  const size_t np = (size_t)c->W * c->H;
+  int rc = ensure_accum(c, nplanes * np);
+  if (rc) return rc;
+  {
+    Span sp(c, CMX_T_ZERO);
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, nplanes * np * sizeof(float), c->stream));
+  }
+  FeSplatArgs a{};
+  a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
+  a.wx = omega[0]; a.wy = omega[1]; a.wz = omega[2];
+  a.W = c->W; a.H = c->H;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.xy = c->d_xy;
+  a.batch_dt = c->d_batch_dt;
+  a.lut = c->d_lut;
+  a.planes = c->d_accum;
+  {
+    Span sp(c, CMX_T_SPLAT);
+    launch_fe_splat(a, nplanes > 1, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->accum_count = nplanes * np;
+  c->last_P = nplanes - 1;
+  c->accumulated = true;
+  return CMX_OK;
+}
+
+int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
+  if (!omega) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
+  int rc = bind(c);
+  if (rc) return rc;
+  return fe_accumulate(c, omega, want_grad ? 4 : 1);
+}
+
+int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
+  if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
+  if (grad && c->last_P != 3) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+  int rc = bind(c);
+  if (rc) return rc;
+  rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  if (rc) return rc;
+  rc = sync_and_collect(c);
+  if (rc) return rc;
+  *contrast = c->h_result[0];
+  if (grad) for (int k = 0; k < 3; k++) grad[k] = c->h_result[2 + k];
+  return CMX_OK;
+}
+
+int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
+  int rc = cmx_frontend_accumulate(c, omega, grad != nullptr);
+  if (rc) return rc;
+  return cmx_frontend_finish(c, contrast, grad);
+}
+
+int cmx_frontend_get_iwe(cmx_ctx *c, const double omega[3], int blur, float *iwe, float *deriv) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
+  if (!omega || !iwe) return fail(c, CMX_ERR_INVALID_ARG, "null argument");
+  int rc = bind(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->W * c->H;
+  const int nplanes = deriv ? 4 : 1;
+  rc = fe_accumulate(c, omega, nplanes);
+  if (rc) return rc;
+  rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
+  if (rc) return rc;
+  const float *src = c->d_accum;
+  if (blur && c->radius > 0) {
+    rc = run_image_and_finalize(c, nplanes - 1, c->d_scratch, c->d_scratch + np);
+    if (rc) return rc;
+    src = c->d_scratch;
+  }
+  HIP_TRY(c, hipMemcpyAsync(iwe, src, np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (deriv) {
+    float *inter = c->d_scratch + 4 * np;
+    launch_interleave3(src + np, inter, (int)np, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(deriv, inter, 3 * np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  return sync_and_collect(c);
+}
+
+// =============================================================================================== back end
+int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lut, int Wp, int Hp) {
+  if (Wp < 4 || Hp < 4 || Wp > 65535 || Hp > 65535) { if (out) *out = nullptr; return CMX_ERR_INVALID_ARG; }
+  int rc = create_common(out, KIND_BE, device, W, H, lut);
+  if (rc) return rc;
+  cmx_ctx *c = *out;
+  c->Wp = Wp; c->Hp = Hp;
+  c->imgW = Wp; c->imgH = Hp;
+  const size_t np = (size_t)Wp * Hp;
+  HIP_TRY(c, hipMalloc((void **)&c->d_IG, np * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_IGp, np * sizeof(float)));
+  HIP_TRY(c, hipMemset(c->d_IG, 0, np * sizeof(float)));
+  HIP_TRY(c, hipMemset(c->d_IGp, 0, np * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_alpha, sizeof(double)));
+  HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_spline, sizeof(SplineArgs)));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_spline, sizeof(SplineArgs), hipHostMallocDefault));
+  return CMX_OK;
+}
+
+int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                           int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
+                           int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
+                           double blur_sigma, int contrast_measure, const float *IG) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  int rc = bind(c);
+  if (rc) return rc;
+  c->have_data = false;
+  c->accumulated = false;
+  if (order != 2 && order != 4) return fail(c, CMX_ERR_INVALID_ARG, "spline order %d unsupported (2 = linear, 4 = cubic)", order);
+  if (K < order || K > kMaxKnots) return fail(c, CMX_ERR_INVALID_ARG, "K=%d outside [%d, %d]", K, order, kMaxKnots);
+  if (num_fixed < 0 || num_fixed > K) return fail(c, CMX_ERR_INVALID_ARG, "num_fixed=%d outside [0, K]", num_fixed);
+  if (!knots_xyzw || dt_ns <= 0) return fail(c, CMX_ERR_INVALID_ARG, "bad spline description");
+  if (event_batch_size <= 0 || event_sample_rate <= 0) return fail(c, CMX_ERR_INVALID_ARG, "batch size / sample rate must be > 0");
+  if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
+    return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d unsupported in the back end", contrast_measure);
+  rc = check_events(c, n, x, y, t_ns);
+  if (rc) return rc;
+  rc = setup_blur(c, blur_sigma);
+  if (rc) return rc;
+
+  // Batches: for (beg = 0; beg < n-1; beg += B) { end = (n-beg > B) ? beg+B : n; }  -- a trailing batch holding
+  // exactly the last single event is skipped (event_pano_warper.cpp:188-196); inside a batch events are taken
+  // with stride event_sample_rate restarting at the batch start (:262).
+  const int B = event_batch_size, rate = event_sample_rate;
+  const int per_batch = (B + rate - 1) / rate;
+  std::vector<uint32_t> xy;
+  std::vector<long long> bt;
+  xy.reserve((size_t)(n / rate + B));
+  for (int64_t beg = 0; beg < n - 1; beg += B) {
+    const int64_t end = (n - beg > B) ? beg + B : n;
+    if (t_ns[end - 1] < t_ns[beg]) return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", (long long)beg);
+    const long long tb = time_batch_ns(t_ns[beg], t_ns[end - 1]);
+    const long long st = tb - start_ns;
+    if (st < 0 || st / dt_ns + order > K)
+      return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", tb, K,
+                  (long long)start_ns, (long long)dt_ns);
+    bt.push_back(tb);
+    for (int64_t e = beg; e < end; e += rate)
+      xy.push_back((uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u));
+  }
+  const int nb = (int)bt.size();
+  c->order = order; c->K = K; c->num_fixed = num_fixed;
+  c->batch = B; c->sample_rate = rate; c->measure = contrast_measure;
+  c->knots0.resize((size_t)K);
+  for (int i = 0; i < K; i++) c->knots0[i] = Quat{knots_xyzw[4 * i], knots_xyzw[4 * i + 1], knots_xyzw[4 * i + 2], knots_xyzw[4 * i + 3]};
+  memset(c->h_spline, 0, sizeof(SplineArgs));
+  c->h_spline->order = order;
+  c->h_spline->K = K;
+  c->h_spline->start_ns = start_ns;
+  c->h_spline->dt_ns = dt_ns;
+  blending_matrix(order, c->h_spline->blend);
+
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = ensure(c, c->d_xy, c->xy_cap, xy.size());
+  if (rc) return rc;
+  rc = ensure(c, c->d_batch_t, c->batch_t_cap, (size_t)nb);
+  if (rc) return rc;
+  rc = ensure(c, c->d_poses, c->poses_cap, (size_t)nb);
+  if (rc) return rc;
+  if (!xy.empty()) HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
+  const size_t np = (size_t)c->Wp * c->Hp;
+  if (IG) {
+    HIP_TRY(c, hipMemcpy(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice));
+    c->ig_nonzero = false;
+    for (size_t i = 0; i < np; i++)
+      if (IG[i] != 0.f) { c->ig_nonzero = true; break; }
+  } else {
+    HIP_TRY(c, hipMemset(c->d_IG, 0, np * sizeof(float)));
+    c->ig_nonzero = false;
+  }
+  HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
+  c->h_result[4095] = 0.0;  // alpha mirror
+  c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
+  c->n_packed = (int)xy.size();
+  c->per_batch = per_batch;
+  c->nb = nb;
+  c->have_data = true;
+  return CMX_OK;
+}
+
+static int be_accumulate(cmx_ctx *c, const double *drotv, bool deriv) {
+  const size_t np = (size_t)c->Wp * c->Hp;
+  const int Kopt = c->K - c->num_fixed;
+  const int P = deriv ? 3 * Kopt : 0;
+  int rc = ensure_accum(c, (size_t)(2 + P) * np);
+  if (rc) return rc;
+  // knot_i <- exp(drot_i) * knot_i for the non-fixed knots (CopyAndIncrementalUpdate, trajectory.cpp:240-263)
+  for (int i = 0; i < c->K; i++) {
+    Quat q = c->knots0[i];
+    if (i >= c->num_fixed) {
+      const double *d = drotv + 3 * (i - c->num_fixed);
+      q = q_mul(so3_exp(d[0], d[1], d[2]), q);
+    }
+    c->h_spline->knots[i] = q;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_spline, c->h_spline, sizeof(SplineArgs), hipMemcpyHostToDevice, c->stream));
+  {
+    Span sp(c, CMX_T_POSE);
+    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, deriv, c->d_poses, c->stream);
+  }
+  {
+    Span sp(c, CMX_T_ZERO);
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)(2 + P) * np * sizeof(float), c->stream));
+  }
+  BeSplatArgs a{};
+  a.W = c->W;
+  a.Wp = c->Wp; a.Hp = c->Hp;
+  a.fx = (double)((c->Wp / 360.0) * 180.0 / 3.1415926535897932384626433832795);  // focalFromFOV(.., 360, 180)
+  a.fy = (double)((c->Hp / 180.0) * 180.0 / 3.1415926535897932384626433832795);
+  a.cxp = (double)c->Wp / 2.0;
+  a.cyp = (double)c->Hp / 2.0;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.order = c->order;
+  a.num_fixed = c->num_fixed;
+  a.xy = c->d_xy;
+  a.poses = c->d_poses;
+  a.lut = c->d_lut;
+  a.planes = c->d_accum;
+  {
+    Span sp(c, CMX_T_SPLAT);
+    launch_be_splat(a, deriv, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->accum_count = (size_t)(2 + P) * np;
+  c->last_P = P;
+  c->accumulated = true;
+  return CMX_OK;
+}
+
+int cmx_backend_accumulate(cmx_ctx *c, const double *drotv, int want_grad) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
+  if (!drotv && c->K > c->num_fixed) return fail(c, CMX_ERR_INVALID_ARG, "null drotv");
+  int rc = bind(c);
+  if (rc) return rc;
+  return be_accumulate(c, drotv, want_grad != 0);
+}
+
+static int be_first_iter(cmx_ctx *c) {
+  // first evaluation of the window: IGp <- IG, alpha <- event-density ratio (event_pano_warper.cpp:201-210)
+  const size_t np = (size_t)c->Wp * c->Hp;
+  if (!c->first_iter) return CMX_OK;
+  if (c->ig_nonzero) {
+    HIP_TRY(c, hipMemcpyAsync(c->d_IGp, c->d_IG, np * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    AlphaArgs a{};
+    a.igp = c->d_IGp;
+    a.il_old = c->d_accum;
+    a.il_new = c->d_accum + np;
+    a.npix = (int)np;
+    a.nblk = 1024;
+    int rc = ensure(c, c->d_partials, c->partials_cap, (size_t)5 * a.nblk);
+    if (rc) return rc;
+    a.partials = c->d_partials;
+    a.alpha = c->d_alpha;
+    a.result_alpha = c->d_result + 4095;
+    launch_alpha(a, c->stream);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    HIP_TRY(c, hipMemsetAsync(c->d_alpha, 0, sizeof(double), c->stream));  // countNonZero(IGp) < 1 => alpha = 0
+    c->h_result[4095] = 0.0;
+  }
+  c->first_iter = false;
+  return CMX_OK;
+}
+
+int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
+  if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
+  const int P = 3 * (c->K - c->num_fixed);
+  if (grad && c->last_P != P) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+  int rc = bind(c);
+  if (rc) return rc;
+  rc = be_first_iter(c);
+  if (rc) return rc;
+  rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
+  if (rc) return rc;
+  rc = sync_and_collect(c);
+  if (rc) return rc;
+  *contrast = c->h_result[0];
+  if (grad) for (int k = 0; k < P; k++) grad[k] = c->h_result[2 + k];
+  return CMX_OK;
+}
+
+int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
+  int rc = cmx_backend_accumulate(c, drotv, grad != nullptr);
+  if (rc) return rc;
+  return cmx_backend_finish(c, contrast, grad);
+}
+
+int cmx_backend_get_plane(cmx_ctx *c, int which, float *host) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "no evaluation has run in this window");
+  if (!host) return fail(c, CMX_ERR_INVALID_ARG, "null host buffer");
+  int rc = bind(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->Wp * c->Hp;
+  const float *src = nullptr;
+  if (which == CMX_PLANE_IL_OLD) src = c->d_accum;
+  else if (which == CMX_PLANE_IL_NEW) src = c->d_accum + np;
+  else if (which == CMX_PLANE_IWE || (which >= CMX_PLANE_DERIV0 && which < CMX_PLANE_DERIV0 + c->last_P)) {
+    const int P = (which == CMX_PLANE_IWE) ? 0 : c->last_P;
+    rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)(1 + P) * np);
+    if (rc) return rc;
+    rc = be_first_iter(c);
+    if (rc) return rc;
+    rc = run_image_and_finalize(c, P, c->d_scratch, P ? c->d_scratch + np : nullptr);
+    if (rc) return rc;
+    src = (which == CMX_PLANE_IWE) ? c->d_scratch : c->d_scratch + (size_t)(1 + which - CMX_PLANE_DERIV0) * np;
+  } else {
+    return fail(c, CMX_ERR_INVALID_ARG, "plane %d not available", which);
+  }
+  HIP_TRY(c, hipMemcpyAsync(host, src, np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return sync_and_collect(c);
+}
+
+int cmx_backend_get_alpha(cmx_ctx *c, double *alpha) {
+  if (!c || c->kind != KIND_BE || !alpha) return fail(c, CMX_ERR_INVALID_ARG, "bad argument");
+  int rc = bind(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *alpha = c->h_result[4095];
+  return CMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+"""Host-side mirror of the reference's evaluator interface over the C ABI (include/cmax_hip.h).
+
+Names follow the reference so the parity tests read like its own call sites:
+
+  FrontendEvaluator  <->  cmax_slam::AngVelEstimator's hot-path members
+      set_packet                     event_subset_ / time_packet_ hand-over   (ang_vel_estimator.cpp:137-147)
+      computeImageOfWarpedEvents     local_image_warped_events.cpp:10-57
+      contrast_f / contrast_df / contrast_fdf   local_contrast_{f,df,fdf}   (local_optim_contrast_gsl.cpp:20-70)
+
+  BackendEvaluator   <->  PoseGraphOptimizer + EventWarper hot-path members
+      set_window                     processTimeWindow hand-over             (pose_graph_optimizer.cpp:283-293)
+      computeImageOfWarpedEvents     event_pano_warper.cpp:167-231
+      contrast_f / contrast_df / contrast_fdf   global_contrast_{f,df,fdf}  (global_optim_contrast_gsl_analytical.cpp:17-81)
+
+contrast_* return the GSL-side values: f = -contrast, df = -gradient.  eval() returns the un-negated pair.
+All compute happens in libcmaxhip.so's HIP kernels; numpy only carries host buffers across the ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (GRAD_ADJOINT, GRAD_PLANES, MEAN_SQUARE, VARIANCE, CmaxHipError, c_dp, c_fp, c_i64p, c_u16p,
+                   check)
+
+__all__ = ["FrontendEvaluator", "BackendEvaluator", "CmaxHipError", "VARIANCE", "MEAN_SQUARE", "GRAD_PLANES",
+           "GRAD_ADJOINT"]
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+class _Evaluator:
+    def __init__(self):
+        self._L = _lib.lib()
+        self._ctx = _lib.ctx_p()
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.cmx_destroy(self._ctx)
+            self._ctx = _lib.ctx_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, status):
+        check(self._ctx, status)
+
+    def set_option(self, key, value):
+        self._ck(self._L.cmx_set_option(self._ctx, int(key), int(value)))
+
+    def set_grad_mode(self, mode):
+        self.set_option(_lib.OPT_GRAD_MODE, mode)
+
+    def set_stream(self, hip_stream_handle):
+        """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(self._L.cmx_set_stream(self._ctx, C.c_void_p(hip_stream_handle or None)))
+
+    # split-phase plumbing (multi-GPU): the accumulation planes between splat and blur/reduce
+    def accum_capacity(self):
+        return int(self._L.cmx_accum_capacity(self._ctx))
+
+    def set_accum_buffer(self, device_ptr, n_floats):
+        self._ck(self._L.cmx_set_accum_buffer(self._ctx, C.c_void_p(device_ptr), int(n_floats)))
+
+    def accum_ptr(self):
+        return self._L.cmx_accum_ptr(self._ctx)
+
+    def accum_count(self):
+        return int(self._L.cmx_accum_count(self._ctx))
+
+    def timing_enable(self, on=True):
+        self._ck(self._L.cmx_timing_enable(self._ctx, int(bool(on))))
+
+    def timing_get(self):
+        """{'splat': (ms, launches), ...} accumulated since the last call."""
+        ms = np.zeros(_lib.T_COUNT)
+        n = np.zeros(_lib.T_COUNT, np.int64)
+        self._ck(self._L.cmx_timing_get(self._ctx, _dp(ms), n.ctypes.data_as(c_i64p)))
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.T_NAMES)}
+
+
+class FrontendEvaluator(_Evaluator):
+    def __init__(self, W, H, lut, device=0):
+        super().__init__()
+        self.W, self.H = int(W), int(H)
+        lut = _c(lut, np.float64).reshape(-1)
+        if lut.size != self.W * self.H * 3:
+            raise ValueError("lut must hold W*H*3 doubles")
+        self._ck(self._L.cmx_frontend_create(C.byref(self._ctx), int(device), self.W, self.H, _dp(lut)))
+        self.n_events = 0
+
+    def set_packet(self, x, y, t_ns, t_ref_ns, fx, fy, cx, cy, event_batch_size=100, blur_sigma=1.0,
+                   contrast_measure=VARIANCE):
+        x, y, t = _c(x, np.uint16), _c(y, np.uint16), _c(t_ns, np.int64)
+        if not (len(x) == len(y) == len(t)):
+            raise ValueError("x, y, t_ns must have equal length")
+        self._ck(self._L.cmx_frontend_set_packet(
+            self._ctx, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p), t.ctypes.data_as(c_i64p),
+            int(t_ref_ns), float(fx), float(fy), float(cx), float(cy), int(event_batch_size), float(blur_sigma),
+            int(contrast_measure)))
+        self.n_events = len(x)
+
+    def eval(self, ang_vel, want_grad=True):
+        """(contrast, gradient[3] | None) -- what computeContrast returns."""
+        om = _c(ang_vel, np.float64)
+        c = C.c_double()
+        g = np.zeros(3)
+        self._ck(self._L.cmx_frontend_eval(self._ctx, _dp(om), C.byref(c), _dp(g) if want_grad else None))
+        return c.value, (g if want_grad else None)
+
+    def accumulate(self, ang_vel, want_grad=True):
+        om = _c(ang_vel, np.float64)
+        self._ck(self._L.cmx_frontend_accumulate(self._ctx, _dp(om), int(bool(want_grad))))
+
+    def finish(self, want_grad=True):
+        c = C.c_double()
+        g = np.zeros(3)
+        self._ck(self._L.cmx_frontend_finish(self._ctx, C.byref(c), _dp(g) if want_grad else None))
+        return c.value, (g if want_grad else None)
+
+    # --- reference-named entry points
+    def computeImageOfWarpedEvents(self, ang_vel, want_deriv=False, blur=True):
+        """image_warped (H x W fp32) [, image_warped_deriv (H x W x 3 fp32)]."""
+        om = _c(ang_vel, np.float64)
+        iwe = np.empty((self.H, self.W), np.float32)
+        d = np.empty((self.H, self.W, 3), np.float32) if want_deriv else None
+        self._ck(self._L.cmx_frontend_get_iwe(self._ctx, _dp(om), int(bool(blur)), iwe.ctypes.data_as(c_fp),
+                                              d.ctypes.data_as(c_fp) if want_deriv else None))
+        return (iwe, d) if want_deriv else iwe
+
+    def contrast_fdf(self, v):
+        c, g = self.eval(v, True)
+        return -c, -g
+
+    def contrast_f(self, v):
+        return -self.eval(v, False)[0]
+
+    def contrast_df(self, v):
+        return -self.eval(v, True)[1]
+
+
+class BackendEvaluator(_Evaluator):
+    def __init__(self, W, H, lut, pano_width, pano_height, device=0):
+        super().__init__()
+        self.W, self.H, self.Wp, self.Hp = int(W), int(H), int(pano_width), int(pano_height)
+        lut = _c(lut, np.float64).reshape(-1)
+        if lut.size != self.W * self.H * 3:
+            raise ValueError("lut must hold W*H*3 doubles")
+        self._ck(self._L.cmx_backend_create(C.byref(self._ctx), int(device), self.W, self.H, _dp(lut), self.Wp, self.Hp))
+        self.K = self.num_fixed = 0
+
+    @property
+    def num_params(self):
+        return 3 * (self.K - self.num_fixed)
+
+    def set_window(self, x, y, t_ns, order, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns,
+                   event_batch_size=100, event_sample_rate=1, blur_sigma=1.0, contrast_measure=VARIANCE, IG=None):
+        x, y, t = _c(x, np.uint16), _c(y, np.uint16), _c(t_ns, np.int64)
+        if not (len(x) == len(y) == len(t)):
+            raise ValueError("x, y, t_ns must have equal length")
+        k = _c(knots_xyzw, np.float64).reshape(-1, 4)
+        ig = None
+        if IG is not None:
+            ig = _c(IG, np.float32)
+            if ig.size != self.Wp * self.Hp:
+                raise ValueError("IG must be Hp x Wp")
+        self._ck(self._L.cmx_backend_set_window(
+            self._ctx, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p), t.ctypes.data_as(c_i64p),
+            int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns),
+            int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
+            ig.ctypes.data_as(c_fp) if ig is not None else None))
+        self.K, self.num_fixed = k.shape[0], int(num_fixed)
+
+    def eval(self, drotv, want_grad=True):
+        d = _c(drotv, np.float64).reshape(-1)
+        if d.size != self.num_params:
+            raise ValueError("drotv must hold 3*(K-num_fixed) doubles")
+        c = C.c_double()
+        g = np.zeros(max(self.num_params, 1))
+        self._ck(self._L.cmx_backend_eval(self._ctx, _dp(d), C.byref(c), _dp(g) if want_grad else None))
+        return c.value, (g[:self.num_params] if want_grad else None)
+
+    def accumulate(self, drotv, want_grad=True):
+        d = _c(drotv, np.float64).reshape(-1)
+        self._ck(self._L.cmx_backend_accumulate(self._ctx, _dp(d), int(bool(want_grad))))
+
+    def finish(self, want_grad=True):
+        c = C.c_double()
+        g = np.zeros(max(self.num_params, 1))
+        self._ck(self._L.cmx_backend_finish(self._ctx, C.byref(c), _dp(g) if want_grad else None))
+        return c.value, (g[:self.num_params] if want_grad else None)
+
+    def get_plane(self, which):
+        out = np.empty((self.Hp, self.Wp), np.float32)
+        self._ck(self._L.cmx_backend_get_plane(self._ctx, int(which), out.ctypes.data_as(c_fp)))
+        return out
+
+    @property
+    def alpha(self):
+        a = C.c_double()
+        self._ck(self._L.cmx_backend_get_alpha(self._ctx, C.byref(a)))
+        return a.value
+
+    # --- reference-named entry points
+    def computeImageOfWarpedEvents(self, drotv, want_deriv=False):
+        """iwe (blurred I = IL + alpha*IGp) [, list of blurred derivative planes] at the updated trajectory."""
+        self.accumulate(drotv, want_deriv)
+        iwe = self.get_plane(_lib.PLANE_IWE)
+        if not want_deriv:
+            return iwe
+        return iwe, np.stack([self.get_plane(_lib.PLANE_DERIV0 + j) for j in range(self.num_params)])
+
+    def contrast_fdf(self, v):
+        c, g = self.eval(v, True)
+        return -c, -g
+
+    def contrast_f(self, v):
+        return -self.eval(v, False)[0]
+
+    def contrast_df(self, v):
+        return -self.eval(v, True)[1]

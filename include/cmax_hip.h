@@ -1,0 +1,159 @@
+/*
+ * cmax_hip.h -- C ABI of libcmaxhip.so: MI355X (gfx950) evaluator for cmax_slam's event-warping hot path.
+ *
+ * This is the drop-in boundary.  The reference sits behind GSL's
+ *   gsl_multimin_function_fdf { f, df, fdf, n, params }
+ * filled at src/frontend/local_optim_contrast_gsl.cpp:87-96 and src/backend/global_optim_contrast_gsl.cpp:23-33.
+ * The bodies of local_contrast_{f,df,fdf} / global_contrast_{f,df,fdf} become ~10-line calls into the entry
+ * points below (INTEGRATION.md shows them); everything they used to compute on the CPU
+ *   (computeImageOfWarpedEvents + computeContrast) runs as hand-written HIP kernels.
+ *
+ * Conventions
+ *   - plain C types only; every entry point returns an int status (CMX_OK == 0) and never aborts the host
+ *     (the reference's glog CHECK / Basalt assert / std::out_of_range abort paths become error codes).
+ *   - a context owns all device memory; inputs are copied at set_*; outputs go to caller buffers.
+ *   - one context per path (front end / back end); contexts are independent and may be driven from two
+ *     host threads concurrently (src/node.cpp:22 + src/cmax_slam.cpp:92); one context is not thread-safe.
+ *   - eval() is synchronous: it returns when contrast / gradient are on the host.
+ *   - contrast and gradient are returned with the reference's sign (maximised quantity); the GSL glue
+ *     negates them exactly as local_optim_contrast_gsl.cpp:48-55 does.
+ *   - quaternions are (x, y, z, w) (Eigen coeffs() order); matrices row-major.
+ */
+#ifndef CMAX_HIP_H
+#define CMAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmx_ctx cmx_ctx;
+
+enum {
+  CMX_OK = 0,
+  CMX_ERR_INVALID_ARG = 1,  /* null pointer, bad size, unsupported spline order, ... */
+  CMX_ERR_EVENT_RANGE = 2,  /* an event has x >= W or y >= H (reference: std::out_of_range from .at()) */
+  CMX_ERR_HIP = 3,          /* a HIP runtime call failed; see cmx_last_error() */
+  CMX_ERR_SPLINE_RANGE = 4, /* a batch time lies outside the knot support (reference: BASALT_ASSERT abort) */
+  CMX_ERR_STATE = 5,        /* eval before set_packet / set_window, wrong context kind, ... */
+  CMX_ERR_TIME_ORDER = 6    /* a batch spans a negative time interval (reference: CHECK_GE abort) */
+};
+
+/* contrast_measure: include/frontend/local_focus_funcs.h:7-11 (back end: VARIANCE / MEAN_SQUARE only) */
+enum { CMX_VARIANCE = 0, CMX_MEAN_SQUARE = 1, CMX_GRADIENT_MAGNITUDE = 2 };
+
+/* how the analytic gradient is formed */
+enum {
+  CMX_GRAD_PLANES = 0, /* faithful: scatter P derivative planes, blur them, reduce (reference data flow) */
+  CMX_GRAD_ADJOINT = 1 /* equivalent: blur is linear => grad_k = sum_events <dW_k, G^T 2(G I - mu)/N>; one extra
+                          pass over the events gathers from one plane; no derivative planes */
+};
+
+/* cmx_set_option keys */
+enum {
+  CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_PLANES (default) | CMX_GRAD_ADJOINT */
+  CMX_OPT_SPLAT_MODE = 2  /* 0 = global float atomics (default), 1 = LDS-tiled (binned) */
+};
+
+const char *cmx_version(void);
+int cmx_device_count(void);
+const char *cmx_last_error(const cmx_ctx *ctx);
+const char *cmx_status_string(int status);
+void cmx_destroy(cmx_ctx *ctx);
+int cmx_set_option(cmx_ctx *ctx, int key, int value);
+/* run the context's work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
+
+/* ------------------------------------------------------------------ front end -------------------------
+ * replaces AngVelEstimator::computeImageOfWarpedEvents + computeContrast
+ *   (src/frontend/local_image_warped_events.cpp:10-170, src/frontend/local_focus_funcs.cpp:82-120)
+ * as called from local_contrast_fdf (src/frontend/local_optim_contrast_gsl.cpp:20-56). */
+
+/* lut: W*H*3 fp64 bearing vectors, index (y*W+x)*3 -- the reference's precomputed_bearing_vectors
+ * (src/cmax_slam.cpp:106-120); copied to the device once. */
+int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *lut);
+
+/* State AngVelEstimator hands over before a solve (src/frontend/ang_vel_estimator.cpp:137-147):
+ * event_subset_ (SoA here; polarity is never read), time_packet_, camera_matrix_ (fx,fy,cx,cy),
+ * warp_opt.{event_batch_size, blur_sigma}, process_opt.contrast_measure.  Uploads once; every
+ * evaluation of the solve reuses it. */
+int cmx_frontend_set_packet(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                            int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
+                            double blur_sigma, int contrast_measure);
+
+/* local_contrast_fdf body: contrast (and d contrast / d omega if grad != NULL; grad == NULL is the cost-only
+ * fast path used by local_contrast_f, src/frontend/local_optim_contrast_gsl.cpp:58-63). */
+int cmx_frontend_eval(cmx_ctx *ctx, const double omega[3], double *contrast, double *grad /* [3] or NULL */);
+
+/* computeImageOfWarpedEvents for display / inspection: iwe = H*W fp32 (required), deriv = H*W*3 interleaved
+ * fp32 (CV_32FC3 layout) or NULL.  blur = 0 is the display overload (local_image_warped_events.cpp:41-57). */
+int cmx_frontend_get_iwe(cmx_ctx *ctx, const double omega[3], int blur, float *iwe, float *deriv);
+
+/* ------------------------------------------------------------------ back end --------------------------
+ * replaces PoseGraphOptimizer::copyAndUpdateTraj + EventWarper::computeImageOfWarpedEvents + computeContrast
+ *   (src/backend/trajectory.cpp:240-263,501-522; src/backend/event_pano_warper.cpp:128-336;
+ *    src/backend/global_focus_funcs.cpp:52-80)
+ * as called from global_contrast_fdf (src/backend/global_optim_contrast_gsl_analytical.cpp:17-68). */
+
+/* Wp x Hp panorama: fx = Wp/2pi, fy = Hp/pi (include/backend/equirectangular_camera.h:64-67). */
+int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lut, int Wp, int Hp);
+
+/* State PoseGraphOptimizer::processTimeWindow hands over (src/backend/pose_graph_optimizer.cpp:283-293):
+ *   window events; the temp trajectory CopyAndIncrementalUpdate builds = knots [idx_cp_traj_beg_, size) of traj_
+ *   with start_ns = int64(1e9*(t_beg_ + idx_cp_traj_beg_*dt_knots_)) (cmx_traj_temp_start_ns) and dt_ns;
+ *   order = 2 (linear, So3Spline<2>) or 4 (cubic, So3Spline<4>); num_fixed = idx_cp_opt_beg_ - idx_cp_traj_beg_;
+ *   t_next_win_beg = t_win_beg_ + win_stride_; warp_opt_.{event_batch_size, event_sample_rate, blur_sigma};
+ *   IG = the persistent global map (Hp*Wp fp32) or NULL for an all-zero map.  Also performs setFirstIter(true):
+ *   alpha is recomputed by the first evaluation of the window (event_pano_warper.cpp:201-210). */
+int cmx_backend_set_window(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                           int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
+                           int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
+                           double blur_sigma, int contrast_measure, const float *IG);
+
+/* global_contrast_fdf body: drotv = 3*(K-num_fixed) incremental rotation vectors applied by LEFT
+ * multiplication to the non-fixed knots (trajectory.cpp:236 / :497); grad has the same length or is NULL. */
+int cmx_backend_eval(cmx_ctx *ctx, const double *drotv, double *contrast, double *grad);
+
+enum { CMX_PLANE_IL_OLD = 0, CMX_PLANE_IL_NEW = 1, CMX_PLANE_IWE = 2, CMX_PLANE_DERIV0 = 16 };
+/* planes of the LAST evaluation (what updateIG / publishEventImage read, event_pano_warper.cpp:109-126):
+ * IL_old / IL_new are raw; IWE is the blurred I = IL + alpha*IGp; CMX_PLANE_DERIV0+j is blurred derivative
+ * plane j (only after an evaluation with CMX_GRAD_PLANES and grad != NULL). host: Hp*Wp fp32. */
+int cmx_backend_get_plane(cmx_ctx *ctx, int which, float *host);
+int cmx_backend_get_alpha(cmx_ctx *ctx, double *alpha);
+/* int64_t(1e9 * (t_beg + idx_traj_beg*dt_knots)) -- the (double)->ns truncation of trajectory.cpp:255-256 */
+int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots);
+
+/* ------------------------------------------------------------------ split-phase (multi-GPU) ------------
+ * The IWE is a sum over events, the contrast a non-linear function of the SUMMED image, so ranks exchange
+ * between splat and blur/reduce.  Each rank loads its contiguous range of event
+ * batches with set_packet / set_window, then per evaluation:
+ *     cmx_*_accumulate(ctx, x, want_grad)     zero + splat the rank's partial planes
+ *     all-reduce(sum) cmx_accum_ptr(ctx) [cmx_accum_count floats]      (RCCL, caller-side)
+ *     cmx_*_finish(ctx, &contrast, grad)      blur + reduce on the summed planes
+ *   with CMX_GRAD_ADJOINT the planes are I only and finish() returns the rank's PARTIAL gradient
+ *   (sum over its own events): all-reduce(sum) that small vector too.
+ * cmx_set_accum_buffer lets the caller own the accumulation memory (e.g. a torch tensor, so
+ * torch.distributed can all-reduce it in place); it must hold cmx_accum_capacity(ctx) floats. */
+size_t cmx_accum_capacity(const cmx_ctx *ctx);             /* floats needed for the worst case of this context */
+int cmx_set_accum_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_floats);
+void *cmx_accum_ptr(const cmx_ctx *ctx);                   /* device pointer of the accumulation planes */
+size_t cmx_accum_count(const cmx_ctx *ctx);                /* floats written by the last accumulate() */
+int cmx_frontend_accumulate(cmx_ctx *ctx, const double omega[3], int want_grad);
+int cmx_frontend_finish(cmx_ctx *ctx, double *contrast, double *grad);
+int cmx_backend_accumulate(cmx_ctx *ctx, const double *drotv, int want_grad);
+int cmx_backend_finish(cmx_ctx *ctx, double *contrast, double *grad);
+
+/* ------------------------------------------------------------------ timing hooks ------------------------
+ * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
+ * cmx_timing_enable(ctx,1) makes every evaluation record events around its kernels;
+ * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
+enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COUNT = 5 };
+int cmx_timing_enable(cmx_ctx *ctx, int on);
+int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMAX_HIP_H */
