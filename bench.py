@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X event-warping path (BASELINE.json metric).
+
+A "step" is one full cost+gradient evaluation (what local_contrast_fdf does once: warp + splat every event of
+the packet, blur, variance and its analytic gradient) over one batch of synthetic input:
+  N = 1 : BASELINE config 2 -- 1M synthetic events, 640x480 IWE, front-end CMax, on one MI355X.
+  N > 1 : the same problem scaled to N x 1M events over the same 0.05 s packet, sharded by contiguous event-batch
+          ranges, one process per GPU, RCCL all-reduce of the partial planes between splat and blur (weak scaling).
+`value` = events warped by all ranks per second, inputs resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend|backend] [--no-cpu-baseline]
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_event(workload, order, want_grad, adjoint):
+    """ALGORITHMIC bytes per warped event for the splat kernel:
+    4 B packed coords + 24 B fp64 LUT gather + 4 px x (4 B read + 4 B write) per image the event touches."""
+    imgs = 1
+    if want_grad and not adjoint:
+        imgs += 3 if workload == "frontend" else 3 * order
+    return 4 + 24 + imgs * 4 * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="frontend", choices=["frontend", "backend"])
+    ap.add_argument("--events", type=int, default=None, help="events per GPU (default: config's own)")
+    ap.add_argument("--grad-mode", default="planes", choices=["planes", "adjoint"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from cmax_slam_amd import _lib, evaluator, synth
+    from cmax_slam_amd.dist import ShardedEvaluator, attach_torch_accum, batch_range
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    adjoint = args.grad_mode == "adjoint"
+    # ------------------------------------------------------------------ synthetic workload (seeded)
+    if args.workload == "frontend":
+        per_gpu = args.events or 1_000_000
+        p = synth.config2(per_gpu * world)
+        beg, end = batch_range(len(p.x), p.batch, rank, world)
+        ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=local_rank)
+        ev.set_packet(p.x[beg:end], p.y[beg:end], p.t_ns[beg:end], p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma,
+                      _lib.VARIANCE)
+        x0 = np.array([0.3, -0.5, 0.2])  # a mid-solve angular velocity (omega_true = 0.6,-0.9,0.4)
+        order = 0
+        name = "cmax_slam front-end fdf: %d synthetic events/GPU, 640x480 IWE, batch 100, sigma 1, variance" % per_gpu
+        n_total, img = len(p.x), "%dx%d" % (p.W, p.H)
+        workload_obj = p
+    else:
+        per_gpu = args.events or 5_000_000
+        w = synth.config3(per_gpu * world)
+        beg, end = batch_range(len(w.x), w.batch, rank, world)
+        ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=local_rank)
+        ev.set_window(w.x[beg:end], w.y[beg:end], w.t_ns[beg:end], w.order, w.knots_init, w.start_ns, w.dt_ns,
+                      w.num_fixed, w.t_next_win_beg_ns, w.batch, w.sample_rate, w.sigma, _lib.VARIANCE)
+        x0 = np.zeros(w.P)
+        order = w.order
+        name = "cmax_slam back-end BA fdf: %d synthetic events/GPU, cubic 10-knot SO(3) spline (P=21), 1024x1024 pano" % per_gpu
+        n_total, img = len(w.x), "%dx%d" % (w.Wp, w.Hp)
+        workload_obj = w
+    if adjoint:
+        ev.set_grad_mode(_lib.GRAD_ADJOINT)
+
+    if world > 1:
+        accum, stream = attach_torch_accum(ev, device)
+        sh = ShardedEvaluator(ev, accum, grad_is_partial=adjoint)
+        def step():
+            with torch.cuda.stream(stream):
+                return sh.eval(x0, True)
+    else:
+        def step():
+            return ev.eval(x0, True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev.timing_enable(True)   # HIP events around the kernels, on the stream they are launched on
+    ev.timing_get()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c, g = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tim = ev.timing_get()
+    ev.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total * args.steps / elapsed
+        splat_ms, splat_n = tim["splat"]
+        gather_ms, gather_n = tim["gather"]
+        ev_per_launch = end - beg
+        bpe = alg_bytes_per_event(args.workload, order, True, adjoint)
+        avg_ms = splat_ms / max(splat_n, 1)
+        achieved = ev_per_launch * bpe / (avg_ms * 1e-3) / 1e9 if splat_n else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("%s_%s" % (args.workload, args.grad_mode))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "warped-events/sec/GPU (1M ev, 640x480 IWE) + CMax iters/sec",
+            "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 warp / f32 accumulate", "data": "synthetic",
+            "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)",
+                       "grad_mode": args.grad_mode, "parallelism": "events sharded by batch range x%d, all-reduce of partial planes" % world
+                       if world > 1 else "single GPU"},
+            "per_gpu_value": value / world,
+            "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
+            "roofline": {"bound": "hbm", "kernel": "splat", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "alg_bytes_per_event": bpe, "events_per_launch": int(ev_per_launch), "avg_launch_ms": avg_ms},
+            "contrast": c,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, workload_obj, x0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, obj, x0):
+    """The CPU oracle ("port": plain-C restatement of the reference path, 1 thread like the reference) timed on
+    this box's host cores on the same workload; bounded to ~args.cpu_seconds of CPU work."""
+    from oracle import pyoracle as po
+    po.build()
+    if args.workload == "frontend":
+        ref = po.Frontend(obj.W, obj.H, obj.lut, obj.fx, obj.fy, obj.cx, obj.cy, obj.batch, obj.sigma, po.VARIANCE)
+        ref.set_packet(obj.x, obj.y, obj.t_ns, obj.t_ref_ns)
+    else:
+        ref = po.Backend(obj.W, obj.H, obj.lut, obj.Wp, obj.Hp, obj.order, obj.batch, obj.sample_rate, obj.sigma, po.VARIANCE)
+        ref.set_window(obj.x, obj.y, obj.t_ns, obj.knots_init, obj.start_ns, obj.dt_ns, obj.num_fixed, obj.t_next_win_beg_ns)
+    ref.eval(x0, True)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref.eval(x0, True)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or n >= 2000:
+            break
+    return {"value": len(obj.x) * n / el, "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": "%d full fdf evaluations of the same %d-event workload (%.1f s), single thread like the reference"
+                      % (n, len(obj.x), el),
+            "ms_per_step": el / n * 1e3}
+
+
+if __name__ == "__main__":
+    main()

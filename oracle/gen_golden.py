@@ -1,0 +1,135 @@
+"""Generate the golden fixtures under tests/golden/ (run in the build container, where /root/reference exists).
+
+  spline_vectors.npz   produced by the REFERENCE's own vendored Basalt/Sophus compiled from /root/reference
+                       (oracle/_ref/libbasalt_ref.so): So3Spline<2>/<4>::evaluate value + Jacobians, SO3 exp/log,
+                       left-multiplicative knot update.  These PIN oracle/so3_spline.c.
+  frontend_small.npz   seeded inputs + the oracle's own outputs (regression vectors; the reference has no
+  backend_small.npz    fixtures for the IWE path and cannot be built here: parity unpinned at the OpenCV/ROS boundary)
+
+usage: python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cmax_slam_amd import synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def rand_knots(rng, K, s):
+    q = np.array([0, 0, 0, 1.0])
+    ks = []
+    for _ in range(K):
+        ks.append(q.copy())
+        q = po.left_update(np.array([q]), [rng.normal(0, s, 3)], 0, use_ref=True)[0]
+    return np.array(ks)
+
+
+def gen_spline():
+    po.build()
+    assert po.ref_lib() is not None, "needs the compiled reference (make -C oracle ref)"
+    rng = np.random.default_rng(20240314)
+    out = {}
+    for order in (2, 4):
+        cases = []
+        for trial in range(60):
+            K = order + int(rng.integers(0, 7))
+            s = [0.02, 0.5, 1e-7, 1.5, 0.0][trial % 5]
+            knots = rand_knots(rng, K, s)
+            dt_ns = int(rng.choice([50_000_000, 10_000_000, 33_333_333]))
+            start = 1_000_000_000 + int(rng.integers(0, 1000))
+            t = start + int(rng.integers(0, (K - order + 1) * dt_ns))
+            if trial % 10 == 0:
+                t = start + (K - order) * dt_ns  # exactly on a knot (u = 0)
+            q, R, J, idx = po.spline_eval(order, knots, start, dt_ns, t, use_ref=True)
+            pad = np.zeros((10, 4))
+            pad[:K] = knots
+            cases.append((K, dt_ns, start, t, pad, q, R, J, idx))
+        out["o%d_K" % order] = np.array([c[0] for c in cases])
+        out["o%d_dt_ns" % order] = np.array([c[1] for c in cases], np.int64)
+        out["o%d_start_ns" % order] = np.array([c[2] for c in cases], np.int64)
+        out["o%d_t_ns" % order] = np.array([c[3] for c in cases], np.int64)
+        out["o%d_knots" % order] = np.array([c[4] for c in cases])
+        out["o%d_quat" % order] = np.array([c[5] for c in cases])
+        out["o%d_R" % order] = np.array([c[6] for c in cases])
+        out["o%d_J" % order] = np.array([c[7] for c in cases])
+        out["o%d_idx" % order] = np.array([c[8] for c in cases])
+    w = np.concatenate([rng.normal(0, s, (25, 3)) for s in (1e-12, 1e-3, 1.0, 2.5)])
+    out["exp_w"] = w
+    out["exp_q"] = np.array([po.so3_exp(v, use_ref=True) for v in w])
+    out["log_w"] = np.array([po.so3_log(q, use_ref=True) for q in out["exp_q"]])
+    k0 = rand_knots(rng, 8, 0.3)
+    d = rng.normal(0, 0.05, (5, 3))
+    out["upd_knots"] = k0
+    out["upd_drot"] = d
+    out["upd_out"] = po.left_update(k0, d, 3, use_ref=True)
+    np.savez_compressed(os.path.join(OUT, "spline_vectors.npz"), **out)
+    print("spline_vectors.npz written (from the compiled reference Basalt)")
+
+
+def gen_frontend():
+    p = synth.frontend_packet(2500, 64, 48, 55.0, 57.0, 31.5, 23.5, T=0.05, omega_true=(1.5, -2.0, 1.0), seed=77, n_arcs=12)
+    fe = po.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, 100, 1.0, po.VARIANCE)
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    oms = np.array([[0, 0, 0], [1.5, -2.0, 1.0], [-3.0, 0.5, 4.0]], np.float64)
+    out = dict(W=p.W, H=p.H, fx=p.fx, fy=p.fy, cx=p.cx, cy=p.cy, x=p.x, y=p.y, t_ns=p.t_ns, t_ref_ns=p.t_ref_ns, omegas=oms)
+    raw, blur, der, cv, gv, cm, gm = [], [], [], [], [], [], []
+    for om in oms:
+        raw.append(fe.iwe(om, blur=False))
+        b, d = fe.iwe(om, deriv=True, blur=True)
+        blur.append(b)
+        der.append(d)
+        c, g = fe.eval(om)
+        cv.append(c)
+        gv.append(g)
+    fm = po.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, 100, 1.0, po.MEAN_SQUARE)
+    fm.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in oms:
+        c, g = fm.eval(om)
+        cm.append(c)
+        gm.append(g)
+    out.update(iwe_raw=np.array(raw), iwe_blur=np.array(blur), deriv_blur=np.array(der, np.float32),
+               contrast_var=np.array(cv), grad_var=np.array(gv), contrast_ms=np.array(cm), grad_ms=np.array(gm))
+    np.savez_compressed(os.path.join(OUT, "frontend_small.npz"), **out)
+    print("frontend_small.npz written")
+
+
+def gen_backend():
+    out = {}
+    for tag, order, K, nf, T in (("lin", 2, 5, 1, 0.2), ("cub", 4, 8, 3, 0.25)):
+        w = synth.backend_window(3000, 64, 48, 55.0, 57.0, 31.5, 23.5, 128, 64, order, K, nf, T, seed=31, n_arcs=12,
+                                 knot_sigma=0.05)
+        be = po.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, order, 100, 1, 1.0, po.VARIANCE)
+        IG = None
+        if tag == "lin":
+            b0 = po.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, order, 100, 1, 1.0, po.VARIANCE)
+            b0.set_window(w.x, w.y, w.t_ns, w.knots_true, w.start_ns, w.dt_ns, nf, w.t_next_win_beg_ns)
+            b0.iwe(np.zeros(w.P))
+            IG = b0.IL_old * 1.3
+        be.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, nf, w.t_next_win_beg_ns, IG)
+        rng = np.random.default_rng(5)
+        d = rng.normal(0, 0.01, w.P)
+        c0, g0 = be.eval(np.zeros(w.P))
+        alpha = be.alpha
+        c1, g1 = be.eval(d)
+        iwe, planes = be.iwe(d, planes=True)
+        out.update({tag + "_" + k: v for k, v in dict(
+            W=w.W, H=w.H, fx=w.fx, fy=w.fy, cx=w.cx, cy=w.cy, Wp=w.Wp, Hp=w.Hp, order=order, K=K, num_fixed=nf,
+            x=w.x, y=w.y, t_ns=w.t_ns, knots=w.knots_init, start_ns=w.start_ns, dt_ns=w.dt_ns,
+            t_next=w.t_next_win_beg_ns, IG=(IG if IG is not None else np.zeros((w.Hp, w.Wp), np.float32)), drot=d,
+            c0=c0, g0=g0, alpha=alpha, c1=c1, g1=g1, iwe=iwe, IL_old=be.IL_old.copy(), IL_new=be.IL_new.copy(),
+            plane_first=planes[0], plane_last=planes[-1], plane_sums=planes.sum(axis=(1, 2), dtype=np.float64)).items()})
+    np.savez_compressed(os.path.join(OUT, "backend_small.npz"), **out)
+    print("backend_small.npz written")
+
+
+if __name__ == "__main__":
+    gen_spline()
+    gen_frontend()
+    gen_backend()

@@ -1,0 +1,197 @@
+"""CPU: properties of the oracle that the reference's arithmetic implies (no fixtures needed)."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import synth
+
+
+@pytest.fixture(scope="module")
+def pkt():
+    return synth.frontend_packet(20_000, 120, 90, 100.0, 100.0, 59.5, 44.5, seed=21)
+
+
+def _fe(oracle, p, **kw):
+    fe = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, kw.get("batch", 100), kw.get("sigma", 1.0),
+                         kw.get("measure", 0))
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    return fe
+
+
+def test_gaussian_kernel_rule(oracle):
+    # ksize = cvRound(sigma*8+1)|1 on CV_32F; taps symmetric, sum 1
+    assert [oracle.lib().orc_gauss_ksize(s) for s in (0.5, 1.0, 1.5, 2.0, 3.0)] == [5, 9, 13, 17, 25]
+    k = oracle.gauss_kernel(1.0)
+    assert len(k) == 9 and abs(k.sum() - 1) < 1e-6
+    np.testing.assert_array_equal(k, k[::-1])
+    ref = np.exp(-0.5 * np.arange(-4, 5) ** 2.0)
+    np.testing.assert_allclose(k, ref / ref.sum(), rtol=1e-6)
+
+
+def test_blur_reflect101_and_mass(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.random((20, 31)).astype(np.float32)
+    out = oracle.gaussian_blur(img, 1.0)
+    # against a direct numpy evaluation with reflect-101 padding
+    k = oracle.gauss_kernel(1.0).astype(np.float64)
+    pad = np.pad(img.astype(np.float64), 4, mode="reflect")
+    tmp = sum(k[j] * pad[:, j:j + 31] for j in range(9))
+    ref = sum(k[j] * tmp[j:j + 20, :] for j in range(9))
+    np.testing.assert_allclose(out, ref, rtol=2e-6)
+    const = oracle.gaussian_blur(np.full((12, 12), 3.0, np.float32), 1.0)
+    np.testing.assert_allclose(const, 3.0, rtol=1e-6)
+    multi = rng.random((9, 14, 3)).astype(np.float32)  # CV_32FC3: channels blurred independently
+    om = oracle.gaussian_blur(multi, 1.0)
+    for c in range(3):
+        np.testing.assert_array_equal(om[..., c], oracle.gaussian_blur(multi[..., c].copy(), 1.0))
+
+
+def test_time_batch_is_ros_duration_arithmetic(oracle):
+    # (t_last - t_first) * 0.5 goes through Duration::fromSec: round to the nearest ns (half away from zero)
+    assert oracle.time_batch_ns(1_000_000_000, 1_000_000_003) == 1_000_000_002
+    assert oracle.time_batch_ns(1_000_000_000, 1_000_000_001) == 1_000_000_001
+    assert oracle.time_batch_ns(5, 5) == 5
+    t0, t1 = 1_700_000_000_123_456_789, 1_700_000_003_987_654_321
+    assert abs(oracle.time_batch_ns(t0, t1) - (t0 + t1) // 2) <= 1
+
+
+def test_votes_conserve_mass_and_respect_border(oracle, pkt):
+    fe = _fe(oracle, pkt)
+    raw = fe.iwe((0.6, -0.9, 0.4), blur=False)
+    assert raw[0].max() == 0 and raw[:, 0].max() == 0 and raw[-1].max() == 0 and raw[:, -1].max() == 0
+    assert raw.sum(dtype=np.float64) <= len(pkt.x) + 1e-3
+    assert abs(raw.sum(dtype=np.float64) - round(raw.sum(dtype=np.float64))) < 2e-2  # each accepted event adds weight 1
+
+
+def test_gradient_matches_finite_differences(oracle, pkt):
+    # the analytic gradient differentiates the bilinear weights only: it equals the derivative of the cost
+    # except when an event crosses a pixel-cell boundary inside the FD step
+    for measure in (0, 1):
+        fe = _fe(oracle, pkt, measure=measure)
+        w = np.array([0.3, -0.5, 0.2])
+        c, g = fe.eval(w)
+        h = 1e-5
+        fd = np.array([(fe.eval(w + h * e, False)[0] - fe.eval(w - h * e, False)[0]) / (2 * h) for e in np.eye(3)])
+        assert np.abs(fd - g).max() < 2e-2 * np.abs(g).max()
+
+
+def test_contrast_peaks_near_true_motion(oracle, pkt):
+    fe = _fe(oracle, pkt)
+    c_true = fe.eval(pkt.omega_true, False)[0]
+    assert c_true > 1.15 * fe.eval((0, 0, 0), False)[0]
+    assert c_true > fe.eval(pkt.omega_true * 1.5, False)[0]
+
+
+def test_f_equals_fdf_cost(oracle, pkt):
+    fe = _fe(oracle, pkt)
+    assert fe.eval((0.1, 0.2, 0.3), False)[0] == fe.eval((0.1, 0.2, 0.3), True)[0]
+
+
+def test_invalid_coordinates_raise(oracle, pkt):
+    fe = oracle.Frontend(pkt.W, pkt.H, pkt.lut, pkt.fx, pkt.fy, pkt.cx, pkt.cy)
+    x = pkt.x.copy()
+    x[3] = pkt.W
+    fe.set_packet(x, pkt.y, pkt.t_ns, pkt.t_ref_ns)
+    with pytest.raises(ValueError):
+        fe.eval((0, 0, 0))
+
+
+# ------------------------------------------------------------------ back end
+@pytest.fixture(scope="module")
+def win():
+    return synth.backend_window(15_000, 120, 90, 100.0, 100.0, 59.5, 44.5, 256, 128, 4, 9, 3, 0.3, seed=2)
+
+
+def _be(oracle, w, knots=None, IG=None, **kw):
+    be = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, kw.get("batch", 100), kw.get("rate", 1), kw.get("sigma", 1.0),
+                        kw.get("measure", 0))
+    be.set_window(w.x, w.y, w.t_ns, w.knots_init if knots is None else knots, w.start_ns, w.dt_ns, w.num_fixed,
+                  w.t_next_win_beg_ns, IG)
+    return be
+
+
+def test_equirect_projection_and_jacobian(oracle):
+    Wp, Hp = 1024, 512
+    px, _ = oracle.equirect_project(Wp, Hp, [0, 0, 1.0])
+    np.testing.assert_allclose(px, [512, 256])  # optical axis -> panorama centre
+    px, _ = oracle.equirect_project(Wp, Hp, [1.0, 0, 0])
+    np.testing.assert_allclose(px, [512 + 256, 256])  # +90 deg azimuth = W/4
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        P = rng.normal(size=3)
+        P[2] = abs(P[2]) + 0.2
+        _, J = oracle.equirect_project(Wp, Hp, P)
+        h = 1e-6
+        fd = np.array([(oracle.equirect_project(Wp, Hp, P + h * e, False)[0] - oracle.equirect_project(Wp, Hp, P - h * e, False)[0])
+                       / (2 * h) for e in np.eye(3)]).T
+        np.testing.assert_allclose(J, fd, rtol=2e-4, atol=2e-3)
+
+
+def test_trailing_single_event_batch_is_skipped(oracle, win):
+    # for (beg; beg < end-1; beg += B): with n = k*B + 1 the last event forms a batch that is never processed
+    w = win
+    n = 1001
+    w2 = synth.BackendWindow(w.W, w.H, w.fx, w.fy, w.cx, w.cy, w.Wp, w.Hp, w.order, w.x[:n], w.y[:n], w.t_ns[:n],
+                             w.knots_true, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    w3 = synth.BackendWindow(w.W, w.H, w.fx, w.fy, w.cx, w.cy, w.Wp, w.Hp, w.order, w.x[:n - 1], w.y[:n - 1], w.t_ns[:n - 1],
+                             w.knots_true, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    a, b = _be(oracle, w2), _be(oracle, w3)
+    np.testing.assert_array_equal(a.iwe(np.zeros(w.P)), b.iwe(np.zeros(w.P)))
+
+
+def test_sampling_restarts_at_batch_start(oracle, win):
+    w = win
+    full = _be(oracle, w, rate=1, sigma=0.0)
+    samp = _be(oracle, w, rate=7, sigma=0.0)
+    i_full = full.iwe(np.zeros(w.P))
+    i_s = samp.iwe(np.zeros(w.P))
+    n_s = sum(len(range(b, min(b + 100, len(w.x)), 7)) for b in range(0, len(w.x) - 1, 100))
+    assert abs(i_s.sum(dtype=np.float64) - n_s) < 0.02 * n_s  # nearly all land inside the panorama
+    assert i_s.sum() < i_full.sum()
+
+
+def test_old_new_split(oracle, win):
+    w = win
+    be = _be(oracle, w, sigma=0.0)
+    be.iwe(np.zeros(w.P))
+    n_old = int((w.t_ns < w.t_next_win_beg_ns).sum())
+    assert abs(be.IL_old.sum(dtype=np.float64) - n_old) < 0.02 * n_old
+    np.testing.assert_array_equal(be.IL, be.IL_old + be.IL_new)
+
+
+def test_backend_gradient_matches_finite_differences(oracle, win):
+    w = win
+    be = _be(oracle, w)
+    P = w.P
+    c, g = be.eval(np.zeros(P))
+    h = 1e-3  # the cost is accumulated in fp32: a smaller step drowns in rounding noise
+    for k in (0, 5, P - 4):
+        e = np.zeros(P)
+        e[k] = h
+        fd = (be.eval(e, False)[0] - be.eval(-e, False)[0]) / (2 * h)
+        assert abs(fd - g[k]) < 5e-2 * np.abs(g).max()
+
+
+def test_alpha_first_iteration_only(oracle, win):
+    w = win
+    b0 = _be(oracle, w, knots=w.knots_true)
+    b0.iwe(np.zeros(w.P))
+    IG = b0.IL_old * 2.0
+    be = _be(oracle, w, IG=IG)
+    be.eval(np.zeros(w.P), False)
+    a = be.alpha
+    assert a > 0
+    assert a == pytest.approx(oracle.lib().orc_be_alpha(
+        be.IGp.ctypes.data_as(oracle.c_fp), be.IL.ctypes.data_as(oracle.c_fp), be.IL.size))
+    be.eval(np.full(w.P, 0.01), False)
+    assert be.alpha == a  # frozen after the first evaluation of the window
+    be0 = _be(oracle, w)
+    be0.eval(np.zeros(w.P), False)
+    assert be0.alpha == 0.0  # empty global map => alpha = 0 (countNonZero < 1)
+
+
+def test_spline_range_error(oracle, win):
+    w = win
+    be = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, 4)
+    be.set_window(w.x, w.y, w.t_ns, w.knots_init[:5], w.start_ns, w.dt_ns, 3, w.t_next_win_beg_ns)
+    with pytest.raises(ValueError):
+        be.eval(np.zeros(6))

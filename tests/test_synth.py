@@ -1,0 +1,34 @@
+"""CPU: the seeded synthetic generators are deterministic and well-formed."""
+import numpy as np
+
+from cmax_slam_amd import synth
+from cmax_slam_amd.dist import batch_range
+
+
+def test_frontend_packet_is_deterministic_sorted_in_range():
+    a = synth.frontend_packet(5000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=1)
+    b = synth.frontend_packet(5000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=1)
+    np.testing.assert_array_equal(a.x, b.x)
+    np.testing.assert_array_equal(a.t_ns, b.t_ns)
+    assert len(a.x) == 5000 and a.x.max() < 240 and a.y.max() < 180
+    assert np.all(np.diff(a.t_ns) >= 0) and a.t_ns[0] >= synth.T0_NS
+    assert a.t_ns[0] < a.t_ref_ns < a.t_ns[-1]
+
+
+def test_backend_window_shapes():
+    w = synth.backend_window(4000, 120, 90, 100.0, 100.0, 59.5, 44.5, 256, 128, 4, 10, 3, 0.35, seed=2)
+    assert w.K == 10 and w.P == 21 and len(w.x) == 4000
+    assert np.all(np.diff(w.t_ns) >= 0)
+    assert w.t_ns[-1] < w.start_ns + (w.K - w.order + 1) * w.dt_ns
+    np.testing.assert_allclose(np.linalg.norm(w.knots_init, axis=1), 1.0, atol=1e-12)
+    np.testing.assert_array_equal(w.knots_init[:3], w.knots_true[:3])  # fixed knots are not perturbed
+
+
+def test_batch_range_partitions_whole_batches():
+    for n, B, world in ((1000, 100, 2), (1001, 100, 3), (99, 100, 8), (40_000_000, 100, 8), (0, 100, 2)):
+        spans = [batch_range(n, B, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 == b0 and a0 <= a1
+        for a0, a1 in spans[:-1]:
+            assert (a0 % B == 0 or a0 == n) and (a1 % B == 0 or a1 == n)
