@@ -53,6 +53,7 @@ SYMBOLS = {
     "cmx_frontend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
     "cmx_backend_accumulate": (C.c_int, [ctx_p, c_dp, C.c_int]),
     "cmx_backend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_get_stats": (C.c_int, [ctx_p, c_dp]),
     "cmx_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "cmx_timing_get": (C.c_int, [ctx_p, c_dp, c_i64p]),
 }

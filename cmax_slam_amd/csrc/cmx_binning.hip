@@ -1,0 +1,179 @@
+// cmx_binning.hip -- one-time (per packet / per window) sort of the events by DESTINATION tile, and the
+// LDS-privatised splat kernels that consume the sorted order.
+//
+// Why: on gfx950 every device-scope fp32 atomic executes memory-side (the 8 XCD L2s are not coherent): one 32-byte
+// fabric transaction per vote, ~18.7 G/s (profiles/r01a_*).  Motion-compensated events pile onto a few edge
+// pixels, so a workgroup that owns a small image window can absorb thousands of votes per pixel in LDS
+// (ds_add_f32) and emit ONE global atomic per touched pixel.  Events are sorted by the 32x32 tile their vote lands
+// in under the parameters of the first evaluation; during the solve the parameters move a little, so each
+// workgroup's LDS window is the tile plus a 16-pixel margin, and any vote that still leaves the window takes the
+// plain global-atomic path -- the result is exact for any parameters, only the speed depends on the binning.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "cmx_internal.hpp"
+#include "cmx_warp.hpp"
+
+namespace cmx {
+
+__global__ __launch_bounds__(256) void fe_bin_keys_kernel(FeSplatArgs a, int tiles_x, int ntiles, uint32_t *keys,
+                                                          uint32_t *idx) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    const FeWarp w = fe_warp_event<false>(a, i);
+    keys[i] = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    idx[i] = (uint32_t)i;
+  }
+}
+__global__ __launch_bounds__(256) void be_bin_keys_kernel(BeSplatArgs a, int tiles_x, int ntiles, uint32_t *keys,
+                                                          uint32_t *idx) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    const BeWarp w = be_warp_event<false>(a, i);
+    keys[i] = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    idx[i] = (uint32_t)i;
+  }
+}
+static int grid_for(int n) {
+  int b = (n + 255) / 256;
+  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+}
+void launch_fe_bin_keys(const FeSplatArgs &a, int tiles_x, int ntiles, uint32_t *keys, uint32_t *idx, hipStream_t s) {
+  hipLaunchKernelGGL(fe_bin_keys_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a, tiles_x, ntiles, keys, idx);
+}
+void launch_be_bin_keys(const BeSplatArgs &a, int tiles_x, int ntiles, uint32_t *keys, uint32_t *idx, hipStream_t s) {
+  hipLaunchKernelGGL(be_bin_keys_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a, tiles_x, ntiles, keys, idx);
+}
+
+int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                   uint32_t *vout, unsigned n, int end_bit, hipStream_t s) {
+  return (int)rocprim::radix_sort_pairs(temp, *temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+}
+
+__global__ __launch_bounds__(256) void apply_perm_kernel(const uint32_t *xy, const uint32_t *idx_sorted, int per_batch,
+                                                         int n, uint32_t *sxy, uint32_t *sbatch) {
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const uint32_t i = idx_sorted[j];
+    sxy[j] = xy[i];
+    sbatch[j] = i / (uint32_t)per_batch;
+  }
+}
+void launch_apply_perm(const uint32_t *xy, const uint32_t *idx_sorted, int per_batch, int n, uint32_t *sxy,
+                       uint32_t *sbatch, hipStream_t s) {
+  hipLaunchKernelGGL(apply_perm_kernel, dim3(grid_for(n)), dim3(256), 0, s, xy, idx_sorted, per_batch, n, sxy, sbatch);
+}
+
+// tile_start[t] = first sorted position whose key >= t   (t = 0 .. ntiles+1)
+__global__ void tile_lower_bound_kernel(const uint32_t *keys, int n, int count, int *tile_start) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < (uint32_t)t) lo = mid + 1;
+    else hi = mid;
+  }
+  tile_start[t] = lo;
+}
+void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int count, int *tile_start, hipStream_t s) {
+  hipLaunchKernelGGL(tile_lower_bound_kernel, dim3((count + 255) / 256), dim3(256), 0, s, keys_sorted, n, count, tile_start);
+}
+
+// ---------------------------------------------------------------------------------------------- LDS splats
+// One workgroup = one chunk of sorted events.  win: kBinWindow^2 fp32 per plane.
+__device__ __forceinline__ void vote4_lds(float *win, int lx, int ly, float dx, float dy) {
+  float *q = win + ly * kBinWindow + lx;
+  lds_add_f32(q, (1.f - dx) * (1.f - dy));
+  lds_add_f32(q + 1, dx * (1.f - dy));
+  lds_add_f32(q + kBinWindow, (1.f - dx) * dy);
+  lds_add_f32(q + kBinWindow + 1, dx * dy);
+}
+__device__ __forceinline__ void vote4_global(float *img, int W, int xx, int yy, float dx, float dy) {
+  float *q = img + (size_t)yy * W + xx;
+  atomic_add_f32(q, (1.f - dx) * (1.f - dy));
+  atomic_add_f32(q + 1, dx * (1.f - dy));
+  atomic_add_f32(q + W, (1.f - dx) * dy);
+  atomic_add_f32(q + W + 1, dx * dy);
+}
+
+__global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
+  __shared__ float win[kBinWindow * kBinWindow];
+  const Chunk c = b.chunks[blockIdx.x];
+  const bool has_win = c.wx0 > -100000000;
+  const int tid = threadIdx.x;
+  if (has_win) {
+    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) win[p] = 0.f;
+    __syncthreads();
+  }
+  unsigned nfall = 0;
+  for (int j = c.beg + tid; j < c.end; j += 256) {
+    const FeWarp w = fe_warp_core<false>(a, b.sxy[j], a.batch_dt[b.sbatch[j]]);
+    if (w.ok) {
+      const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
+      if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
+        vote4_lds(win, lx, ly, w.dx, w.dy);
+      } else {
+        vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
+        nfall++;
+      }
+    }
+  }
+  if (nfall) atomicAdd(b.fallback, nfall);
+  if (has_win) {
+    __syncthreads();
+    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
+      const float v = win[p];
+      if (v != 0.f) {
+        const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
+        atomic_add_f32(a.planes + (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx), v);
+      }
+    }
+  }
+}
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s) {
+  if (b.nchunks <= 0) return;
+  hipLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+}
+
+__global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
+  __shared__ float win[2 * kBinWindow * kBinWindow];  // IL_old window, IL_new window
+  const Chunk c = b.chunks[blockIdx.x];
+  const bool has_win = c.wx0 > -100000000;
+  const int tid = threadIdx.x;
+  const size_t np = (size_t)a.Wp * a.Hp;
+  if (has_win) {
+    for (int p = tid; p < 2 * kBinWindow * kBinWindow; p += 256) win[p] = 0.f;
+    __syncthreads();
+  }
+  unsigned nfall = 0;
+  for (int j = c.beg + tid; j < c.end; j += 256) {
+    const BeWarp w = be_warp_core<false>(a, b.sxy[j], (int)b.sbatch[j]);
+    if (w.ok) {
+      const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
+      if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
+        vote4_lds(win + (w.is_old ? 0 : kBinWindow * kBinWindow), lx, ly, w.dx, w.dy);
+      } else {
+        vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
+        nfall++;
+      }
+    }
+  }
+  if (nfall) atomicAdd(b.fallback, nfall);
+  if (has_win) {
+    __syncthreads();
+    for (int p = tid; p < 2 * kBinWindow * kBinWindow; p += 256) {
+      const float v = win[p];
+      if (v != 0.f) {
+        const int plane = p / (kBinWindow * kBinWindow);
+        const int q = p - plane * (kBinWindow * kBinWindow);
+        const int ly = q / kBinWindow, lx = q - ly * kBinWindow;
+        atomic_add_f32(a.planes + (size_t)plane * np + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), v);
+      }
+    }
+  }
+}
+void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s) {
+  if (b.nchunks <= 0) return;
+  hipLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+}
+
+}  // namespace cmx

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,30 @@ struct cmx_ctx {
   size_t scratch_cap = 0;
   int last_P = 0;              // derivative planes produced by the last accumulate()
   bool accumulated = false;
+
+  // adjoint-gradient scratch: blurred plane B, Itilde = G^T(B - mu), per-block gradient partials
+  float *d_B = nullptr, *d_itilde = nullptr;
+  size_t B_cap = 0, itilde_cap = 0;
+  double *d_gpartials = nullptr;
+  size_t gpartials_cap = 0;
+  bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
+  double last_x[3 * kMaxKnots] = {0};  // parameters of the last accumulate (the gather pass re-warps the events)
+
+  // LDS-privatised splat (CMX_OPT_SPLAT_MODE = 1): events sorted by destination tile, chunk table
+  bool bin_valid = false;
+  uint32_t *d_keys = nullptr, *d_keys_s = nullptr, *d_idx = nullptr, *d_idx_s = nullptr, *d_sxy = nullptr, *d_sbatch = nullptr;
+  size_t bin_cap = 0;
+  void *d_sort_temp = nullptr;
+  size_t sort_temp_cap = 0;
+  int *d_tile_start = nullptr;
+  size_t tile_start_cap = 0;
+  Chunk *d_chunks = nullptr;
+  size_t chunks_cap = 0;
+  int nchunks = 0;
+  unsigned *d_fallback = nullptr;
+  int64_t rebin_count = 0;
+  double last_fallback_frac = 0;
+  bool last_used_lds = false;
 
   // reductions
   double *d_partials = nullptr, *d_sums = nullptr;
@@ -241,6 +266,124 @@ int ensure_accum(cmx_ctx *c, size_t need) {
   return ensure(c, c->d_accum, c->accum_cap, need);
 }
 
+
+// ---- sort the events by destination tile under the CURRENT parameters and build the chunk table
+int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
+  const int n = c->n_packed;
+  const int W = c->imgW, H = c->imgH;
+  const int tiles_x = (W + kBinTile - 1) / kBinTile, tiles_y = (H + kBinTile - 1) / kBinTile;
+  const int ntiles = tiles_x * tiles_y;
+  int rc;
+  if ((size_t)n > c->bin_cap || !c->d_keys) {
+    uint32_t **ptrs[6] = {&c->d_keys, &c->d_keys_s, &c->d_idx, &c->d_idx_s, &c->d_sxy, &c->d_sbatch};
+    for (auto p : ptrs) {
+      if (*p) HIP_TRY(c, hipFree(*p));
+      *p = nullptr;
+      HIP_TRY(c, hipMalloc((void **)p, (size_t)(n > 0 ? n : 1) * sizeof(uint32_t)));
+    }
+    c->bin_cap = (size_t)(n > 0 ? n : 1);
+  }
+  if (!c->d_fallback) {
+    HIP_TRY(c, hipMalloc((void **)&c->d_fallback, sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(c->d_fallback, 0, sizeof(unsigned), c->stream));
+  }
+  rc = ensure(c, c->d_tile_start, c->tile_start_cap, (size_t)ntiles + 2);
+  if (rc) return rc;
+  std::vector<int> ts((size_t)ntiles + 2, 0);
+  if (n > 0) {
+    if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
+    else launch_be_bin_keys(*be, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
+    int end_bit = 1;
+    while ((1 << end_bit) <= ntiles) end_bit++;
+    size_t tb = 0;
+    if (sort_pairs_u32(nullptr, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+      return fail(c, CMX_ERR_HIP, "rocprim radix sort (size query) failed");
+    if (tb > c->sort_temp_cap) {
+      if (c->d_sort_temp) HIP_TRY(c, hipFree(c->d_sort_temp));
+      c->d_sort_temp = nullptr;
+      HIP_TRY(c, hipMalloc(&c->d_sort_temp, tb));
+      c->sort_temp_cap = tb;
+    }
+    if (sort_pairs_u32(c->d_sort_temp, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+      return fail(c, CMX_ERR_HIP, "rocprim radix sort failed");
+    launch_apply_perm(c->d_xy, c->d_idx_s, c->per_batch, n, c->d_sxy, c->d_sbatch, c->stream);
+    launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(ts.data(), c->d_tile_start, ((size_t)ntiles + 2) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  // chunk table: hot tiles are split so that ~3 workgroups per CU exist; big chunks amortise the window flush
+  int M = n / 768;
+  M = M < 2048 ? 2048 : (M > 32768 ? 32768 : M);
+  M = (M + 255) / 256 * 256;
+  std::vector<Chunk> chunks;
+  for (int t = 0; t <= ntiles; t++) {
+    const int beg = ts[t], end = ts[t + 1];
+    if (end <= beg) continue;
+    const bool sentinel = (t == ntiles);
+    const int wx0 = sentinel ? -200000000 : (t % tiles_x) * kBinTile - kBinMargin;
+    const int wy0 = sentinel ? -200000000 : (t / tiles_x) * kBinTile - kBinMargin;
+    for (int b = beg; b < end; b += M) chunks.push_back(Chunk{wx0, wy0, b, (b + M < end) ? b + M : end});
+  }
+  std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return (a.end - a.beg) > (b.end - b.beg); });
+  rc = ensure(c, c->d_chunks, c->chunks_cap, chunks.size());
+  if (rc) return rc;
+  if (!chunks.empty())
+    HIP_TRY(c, hipMemcpyAsync(c->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // chunks vector goes out of scope
+  c->nchunks = (int)chunks.size();
+  c->bin_valid = true;
+  c->rebin_count++;
+  c->last_fallback_frac = 0;
+  return CMX_OK;
+}
+
+BinnedEvents binned(const cmx_ctx *c) {
+  BinnedEvents b{};
+  b.sxy = c->d_sxy;
+  b.sbatch = c->d_sbatch;
+  b.chunks = c->d_chunks;
+  b.nchunks = c->nchunks;
+  b.fallback = c->d_fallback;
+  return b;
+}
+
+FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]) {
+  FeSplatArgs a{};
+  a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
+  a.wx = omega[0]; a.wy = omega[1]; a.wz = omega[2];
+  a.W = c->W; a.H = c->H;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.xy = c->d_xy;
+  a.batch_dt = c->d_batch_dt;
+  a.lut = c->d_lut;
+  a.planes = c->d_accum;
+  return a;
+}
+
+BeSplatArgs be_args(const cmx_ctx *c) {
+  BeSplatArgs a{};
+  a.W = c->W;
+  a.Wp = c->Wp; a.Hp = c->Hp;
+  a.fx = (double)((c->Wp / 360.0) * 180.0 / 3.1415926535897932384626433832795);  // focalFromFOV(.., 360, 180)
+  a.fy = (double)((c->Hp / 180.0) * 180.0 / 3.1415926535897932384626433832795);
+  a.cxp = (double)c->Wp / 2.0;
+  a.cyp = (double)c->Hp / 2.0;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.order = c->order;
+  a.num_fixed = c->num_fixed;
+  a.xy = c->d_xy;
+  a.poses = c->d_poses;
+  a.lut = c->d_lut;
+  a.planes = c->d_accum;
+  return a;
+}
+
+bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: image larger than the kernel
+  return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
+}
+
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -286,14 +429,101 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     f.partials = c->d_partials;
     f.sums = c->d_sums;
     f.result = c->d_result;
+    f.fallback = c->d_fallback;
     launch_finalize(f, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }
 
+
+// adjoint gradient: image pass (keeps the blurred plane B) -> sums -> Itilde = G^T(B - mu) -> gather over the
+// events -> finalize (contrast from the moments, gradient = (2/N) * sum of the gather partials)
+int run_adjoint(cmx_ctx *c, int P) {
+  const int W = c->imgW, H = c->imgH;
+  const size_t np = (size_t)W * H;
+  int rc = ensure(c, c->d_B, c->B_cap, np);
+  if (rc) return rc;
+  rc = ensure(c, c->d_itilde, c->itilde_cap, np);
+  if (rc) return rc;
+  ImgArgs a{};
+  a.W = W; a.H = H; a.r = c->radius;
+  memcpy(a.taps, c->taps, sizeof(a.taps));
+  if (c->kind == KIND_FE) {
+    a.src_a = c->d_accum;
+  } else {
+    a.src_a = c->d_accum;
+    a.src_b = c->d_accum + np;
+    a.igp = c->ig_nonzero ? c->d_IGp : nullptr;
+    a.alpha = c->d_alpha;
+  }
+  a.P = 0;
+  a.out_blur0 = c->d_B;
+  a.tiles_x = (W + kTileX - 1) / kTileX;
+  a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  rc = ensure(c, c->d_partials, c->partials_cap, (size_t)2 * a.nblk);
+  if (rc) return rc;
+  rc = ensure(c, c->d_sums, c->sums_cap, 2);
+  if (rc) return rc;
+  const int gb = gather_blocks(c->n_packed);
+  rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * (P > 0 ? P : 1));
+  if (rc) return rc;
+  if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
+  a.partials = c->d_partials;
+  FinalizeArgs f{};
+  f.P = 0;
+  f.nblk = a.nblk;
+  f.measure = c->measure;
+  f.npix = (double)np;
+  f.partials = c->d_partials;
+  f.sums = c->d_sums;
+  f.result = c->d_result;
+  f.gpartials = c->d_gpartials;
+  f.gblocks = gb;
+  f.gP = P;
+  f.fallback = c->d_fallback;
+  {
+    Span sp(c, CMX_T_IMAGE);
+    launch_image_moments(a, c->stream);
+    launch_reduce_partials(f, c->stream);
+    AdjointArgs ad{};
+    ad.W = W; ad.H = H; ad.r = c->radius;
+    memcpy(ad.taps, c->taps, sizeof(ad.taps));
+    ad.B = c->d_B;
+    ad.nblk = a.nblk;
+    ad.tiles_x = a.tiles_x;
+    ad.npix = (double)np;
+    ad.subtract_mean = (c->measure == CMX_MEAN_SQUARE) ? 0 : 1;
+    ad.out = c->d_itilde;
+    launch_adjoint(ad, c->d_sums, c->stream);
+  }
+  {
+    Span sp(c, CMX_T_GATHER);
+    if (c->kind == KIND_FE) {
+      FeGatherArgs g{};
+      g.ev = fe_args(c, c->last_x);
+      g.itilde = c->d_itilde;
+      g.gpartials = c->d_gpartials;
+      if (c->n_packed > 0) launch_fe_gather(g, c->stream);
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P * sizeof(double), c->stream));
+    } else {
+      BeGatherArgs g{};
+      g.ev = be_args(c);
+      g.itilde = c->d_itilde;
+      g.P = P;
+      g.gpartials = c->d_gpartials;
+      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->stream);
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * (P > 0 ? P : 1) * sizeof(double), c->stream));
+    }
+  }
+  launch_finalize_only(f, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
+}
+
 int sync_and_collect(cmx_ctx *c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->last_used_lds && c->n_packed > 0) c->last_fallback_frac = c->h_result[4094] / (double)c->n_packed;
   if (c->timing) collect_spans(c);
   return CMX_OK;
 }
@@ -355,6 +585,14 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_scratch);
   hipFree(c->d_partials);
   hipFree(c->d_sums);
+  hipFree(c->d_keys); hipFree(c->d_keys_s); hipFree(c->d_idx); hipFree(c->d_idx_s); hipFree(c->d_sxy); hipFree(c->d_sbatch);
+  hipFree(c->d_sort_temp);
+  hipFree(c->d_tile_start);
+  hipFree(c->d_chunks);
+  hipFree(c->d_fallback);
+  hipFree(c->d_B);
+  hipFree(c->d_itilde);
+  hipFree(c->d_gpartials);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -365,12 +603,12 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
   switch (key) {
     case CMX_OPT_GRAD_MODE:
       if (value != CMX_GRAD_PLANES && value != CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "bad grad mode %d", value);
-      if (value == CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "CMX_GRAD_ADJOINT not available in this build");
       c->grad_mode = value;
       return CMX_OK;
     case CMX_OPT_SPLAT_MODE:
-      if (value != 0) return fail(c, CMX_ERR_INVALID_ARG, "splat mode %d not available in this build", value);
+      if (value != 0 && value != 1) return fail(c, CMX_ERR_INVALID_ARG, "bad splat mode %d", value);
       c->splat_mode = value;
+      c->bin_valid = false;
       return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
@@ -389,6 +627,15 @@ int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
   }
+  return CMX_OK;
+}
+
+int cmx_get_stats(cmx_ctx *c, double stats[4]) {
+  if (!c || !stats) return CMX_ERR_INVALID_ARG;
+  stats[0] = (double)c->rebin_count;
+  stats[1] = c->last_fallback_frac;
+  stats[2] = (double)c->nchunks;
+  stats[3] = (double)c->n_packed;
   return CMX_OK;
 }
 
@@ -488,6 +735,7 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   c->per_batch = event_batch_size;
   c->nb = nb;
   c->have_data = true;
+  c->bin_valid = false;
   return CMX_OK;
 }
 
@@ -499,19 +747,18 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
     Span sp(c, CMX_T_ZERO);
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, nplanes * np * sizeof(float), c->stream));
   }
-  FeSplatArgs a{};
-  a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
-  a.wx = omega[0]; a.wy = omega[1]; a.wz = omega[2];
-  a.W = c->W; a.H = c->H;
-  a.per_batch = c->per_batch;
-  a.n = c->n_packed;
-  a.xy = c->d_xy;
-  a.batch_dt = c->d_batch_dt;
-  a.lut = c->d_lut;
-  a.planes = c->d_accum;
+  FeSplatArgs a = fe_args(c, omega);
+  for (int k = 0; k < 3; k++) c->last_x[k] = omega[k];
+  const bool use_lds = c->splat_mode == 1 && nplanes == 1 && c->n_packed > 0;
+  if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
+    rc = do_binning(c, &a, nullptr);
+    if (rc) return rc;
+  }
   {
     Span sp(c, CMX_T_SPLAT);
-    launch_fe_splat(a, nplanes > 1, c->stream);
+    c->last_used_lds = use_lds;
+    if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream);
+    else launch_fe_splat(a, nplanes > 1, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   c->accum_count = nplanes * np;
@@ -526,17 +773,20 @@ int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
   if (!omega) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
   int rc = bind(c);
   if (rc) return rc;
-  return fe_accumulate(c, omega, want_grad ? 4 : 1);
+  c->last_adjoint = want_grad && adjoint_ok(c);
+  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1);
 }
 
 int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
   if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
-  if (grad && c->last_P != 3) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+  if (grad && c->last_P != 3 && !c->last_adjoint)
+    return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
   int rc = bind(c);
   if (rc) return rc;
-  rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
+  else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;
@@ -559,6 +809,7 @@ int cmx_frontend_get_iwe(cmx_ctx *c, const double omega[3], int blur, float *iwe
   if (rc) return rc;
   const size_t np = (size_t)c->W * c->H;
   const int nplanes = deriv ? 4 : 1;
+  c->last_adjoint = false;
   rc = fe_accumulate(c, omega, nplanes);
   if (rc) return rc;
   rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
@@ -677,12 +928,15 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   c->per_batch = per_batch;
   c->nb = nb;
   c->have_data = true;
+  c->bin_valid = false;
   return CMX_OK;
 }
 
-static int be_accumulate(cmx_ctx *c, const double *drotv, bool deriv) {
+static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   const size_t np = (size_t)c->Wp * c->Hp;
   const int Kopt = c->K - c->num_fixed;
+  c->last_adjoint = want_grad && adjoint_ok(c);
+  const bool deriv = want_grad && !c->last_adjoint;
   const int P = deriv ? 3 * Kopt : 0;
   int rc = ensure_accum(c, (size_t)(2 + P) * np);
   if (rc) return rc;
@@ -698,30 +952,23 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool deriv) {
   HIP_TRY(c, hipMemcpyAsync(c->d_spline, c->h_spline, sizeof(SplineArgs), hipMemcpyHostToDevice, c->stream));
   {
     Span sp(c, CMX_T_POSE);
-    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, deriv, c->d_poses, c->stream);
+    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad, c->d_poses, c->stream);
   }
   {
     Span sp(c, CMX_T_ZERO);
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)(2 + P) * np * sizeof(float), c->stream));
   }
-  BeSplatArgs a{};
-  a.W = c->W;
-  a.Wp = c->Wp; a.Hp = c->Hp;
-  a.fx = (double)((c->Wp / 360.0) * 180.0 / 3.1415926535897932384626433832795);  // focalFromFOV(.., 360, 180)
-  a.fy = (double)((c->Hp / 180.0) * 180.0 / 3.1415926535897932384626433832795);
-  a.cxp = (double)c->Wp / 2.0;
-  a.cyp = (double)c->Hp / 2.0;
-  a.per_batch = c->per_batch;
-  a.n = c->n_packed;
-  a.order = c->order;
-  a.num_fixed = c->num_fixed;
-  a.xy = c->d_xy;
-  a.poses = c->d_poses;
-  a.lut = c->d_lut;
-  a.planes = c->d_accum;
+  BeSplatArgs a = be_args(c);
+  const bool use_lds = c->splat_mode == 1 && !deriv && c->n_packed > 0;
+  if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
+    rc = do_binning(c, nullptr, &a);
+    if (rc) return rc;
+  }
   {
     Span sp(c, CMX_T_SPLAT);
-    launch_be_splat(a, deriv, c->stream);
+    c->last_used_lds = use_lds;
+    if (use_lds) launch_be_splat_lds(a, binned(c), c->stream);
+    else launch_be_splat(a, deriv, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   c->accum_count = (size_t)(2 + P) * np;
@@ -771,12 +1018,14 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
   if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
   const int P = 3 * (c->K - c->num_fixed);
-  if (grad && c->last_P != P) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+  if (grad && c->last_P != P && !c->last_adjoint)
+    return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
   int rc = bind(c);
   if (rc) return rc;
   rc = be_first_iter(c);
   if (rc) return rc;
-  rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, P);
+  else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;

@@ -60,12 +60,41 @@ struct ImgArgs {
   int tiles_x;
 };
 
+// adjoint pass:  Itilde = G^T (B - mu)   with B the blurred image, G the REFLECT_101 separable Gaussian
+struct AdjointArgs {
+  int W, H, r;
+  float taps[2 * kMaxRadius + 1];
+  const float *B;          // blurred plane 0 (written by image_moments)
+  int nblk, tiles_x;
+  double npix;
+  int subtract_mean;       // 1 = variance, 0 = mean square
+  float *out;              // Itilde
+};
+
+struct FeGatherArgs {
+  FeSplatArgs ev;          // same event / camera description as the splat
+  const float *itilde;
+  double *gpartials;       // [nblocks][3]
+};
+
+struct BeGatherArgs {
+  BeSplatArgs ev;
+  const float *itilde;
+  int P;                   // 3 * (K - num_fixed)
+  int chunk;               // events per workgroup iteration (multiple of 256)
+  double *gpartials;       // [nblocks][P]
+};
+
 struct FinalizeArgs {
   int P, nblk, measure;
   double npix;
   const double *partials;  // [2+2P][nblk]
   double *sums;            // [2+2P] device scratch
   double *result;          // mapped host: [0]=contrast, [1]=mean, [2..2+P) = gradient
+  // adjoint mode: gradient = (2/N) * sum over blocks of gpartials[b][k]
+  const double *gpartials;
+  int gblocks, gP;
+  unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
 };
 
 struct AlphaArgs {
@@ -77,6 +106,32 @@ struct AlphaArgs {
   double *result_alpha;  // mapped host copy
 };
 
+// ---- LDS-privatised splat (events sorted by destination tile once per packet / window) ----------------
+constexpr int kBinTile = 32;     // destination tile edge (pixels)
+constexpr int kBinMargin = 16;   // window = tile + margin on every side: 64 x 64 fp32 per plane in LDS
+constexpr int kBinWindow = kBinTile + 2 * kBinMargin;
+
+struct Chunk { int wx0, wy0, beg, end; };  // LDS window origin (pixels) and the sorted-event range; wx0 < -1e8: no window
+
+struct BinnedEvents {
+  const uint32_t *sxy;     // packed events in sorted order
+  const uint32_t *sbatch;  // batch index of each sorted event
+  const Chunk *chunks;
+  int nchunks;
+  unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
+};
+
+// binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
+void launch_fe_bin_keys(const FeSplatArgs &a, int tiles_x, int ntiles, uint32_t *keys, uint32_t *idx, hipStream_t s);
+void launch_be_bin_keys(const BeSplatArgs &a, int tiles_x, int ntiles, uint32_t *keys, uint32_t *idx, hipStream_t s);
+int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                   uint32_t *vout, unsigned n, int end_bit, hipStream_t s);  // rocprim radix sort (library op)
+void launch_apply_perm(const uint32_t *xy, const uint32_t *idx_sorted, int per_batch, int n, uint32_t *sxy,
+                       uint32_t *sbatch, hipStream_t s);
+void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int ntiles_plus2, int *tile_start, hipStream_t s);
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s);
+void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s);
+
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_be_pose_table(const SplineArgs *d_spline, const long long *d_batch_t, int nb, int order, bool want_j,
                           PoseEntry *out, hipStream_t s);
@@ -84,6 +139,12 @@ void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
+void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s);
+void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
+void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
+int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the number of blocks (rows of gpartials)
+int launch_be_gather(const BeGatherArgs &a, hipStream_t s);
+int gather_blocks(int n);
 void launch_interleave3(const float *planes, float *out, int npix, hipStream_t s);
 size_t image_lds_bytes(int r);
 

@@ -14,56 +14,28 @@
 // -ffp-contract=off so the fp64 warp, the fp32 weights and the fp32 blur are bit-identical to the CPU path for
 // identical inputs; the only reordering is the fp32 atomic accumulation.
 #include "cmx_internal.hpp"
+#include "cmx_warp.hpp"
 
 namespace cmx {
-
-// fire-and-forget fp32 atomic add (global_atomic_add_f32, no return value); needs -munsafe-fp-atomics
-__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---------------------------------------------------------------------------------------------- K1
 template <bool DERIV>
 __global__ __launch_bounds__(256) void fe_splat_kernel(FeSplatArgs a) {
-  const int W = a.W, H = a.H;
-  const size_t np = (size_t)W * H;
+  const int W = a.W;
+  const size_t np = (size_t)W * a.H;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const uint32_t e = a.xy[i];
-    const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
-    const double dt = a.batch_dt[i / a.per_batch];
-    const double *b = a.lut + 3 * ((size_t)ey * W + ex);
-    const double px = b[0], py = b[1], pz = b[2];
-    // p' = p + (omega*dt) x p   (first-order rotation)
-    const double drx = a.wx * dt, dry = a.wy * dt, drz = a.wz * dt;
-    const double rx = px + (dry * pz - drz * py);
-    const double ry = py + (drz * px - drx * pz);
-    const double rz = pz + (drx * py - dry * px);
-    const double iz = 1.0 / rz;
-    const double cxn = rx * iz, cyn = ry * iz;
-    const double u = a.fx * cxn + a.cx;
-    const double v = a.fy * cyn + a.cy;
-    const int xx = (int)u, yy = (int)v;
-    if (1 <= xx && xx < W - 2 && 1 <= yy && yy < H - 2) {
-      const float dx = (float)(u - xx), dy = (float)(v - yy);
-      float *q = a.planes + (size_t)yy * W + xx;
+    const FeWarp w = fe_warp_event<DERIV>(a, i);
+    if (w.ok) {
+      const float dx = w.dx, dy = w.dy;
+      float *q = a.planes + (size_t)w.yy * W + w.xx;
       atomic_add_f32(q, (1.f - dx) * (1.f - dy));
       atomic_add_f32(q + 1, dx * (1.f - dy));
       atomic_add_f32(q + W, (1.f - dx) * dy);
       atomic_add_f32(q + W + 1, dx * dy);
       if (DERIV) {
-        // J = diag(fx,fy) * J_proj(2x3) * [(-dt) p]_x   evaluated in the reference's operation order
-        const double vx = (-dt) * px, vy = (-dt) * py, vz = (-dt) * pz;
-        const double a02 = -cxn * iz, a12 = -cyn * iz;
-        double c[6];
-        c[0] = a02 * (-vy);
-        c[1] = iz * (-vz) + a02 * vx;
-        c[2] = iz * vy;
-        c[3] = iz * vz + a12 * (-vy);
-        c[4] = a12 * vx;
-        c[5] = iz * (-vx);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const float r0 = (float)(a.fx * c[k]), r1 = (float)(a.fy * c[3 + k]);
+          const float r0 = w.r0[k], r1 = w.r1[k];
           float *d = q + (size_t)(1 + k) * np;
           atomic_add_f32(d, r0 * (-(1.f - dy)) + r1 * (-(1.f - dx)));
           atomic_add_f32(d + 1, r0 * (1.f - dy) + r1 * (-dx));
@@ -127,64 +99,31 @@ void launch_be_pose_table(const SplineArgs *d_spline, const long long *d_batch_t
 // ---------------------------------------------------------------------------------------------- K2
 template <int N, bool DERIV>
 __global__ __launch_bounds__(256) void be_splat_kernel(BeSplatArgs a) {
-  const int Wp = a.Wp, Hp = a.Hp;
-  const size_t np = (size_t)Wp * Hp;
+  const int Wp = a.Wp;
+  const size_t np = (size_t)Wp * a.Hp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const uint32_t e = a.xy[i];
-    const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
-    const bool is_old = (e >> 31) != 0;
-    const PoseEntry &pe = a.poses[i / a.per_batch];
-    const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
-    const double b0 = b[0], b1 = b[1], b2 = b[2];
-    // e_ray_w = R * bearing
-    const double x = pe.R[0] * b0 + pe.R[1] * b1 + pe.R[2] * b2;
-    const double y = pe.R[3] * b0 + pe.R[4] * b1 + pe.R[5] * b2;
-    const double z = pe.R[6] * b0 + pe.R[7] * b1 + pe.R[8] * b2;
-    // equirectangular projection
-    const double phi = atan2(x, z);
-    const double rho = sqrt(x * x + y * y + z * z);
-    const double theta = asin(y / rho);
-    const double pxm = a.cxp + phi * a.fx;
-    const double pym = a.cyp + theta * a.fy;
-    const int xx = (int)pxm, yy = (int)pym;
-    if (1 <= xx && xx < Wp - 2 && 1 <= yy && yy < Hp - 2) {
-      const float dx = (float)(pxm - xx), dy = (float)(pym - yy);
-      const size_t off = (size_t)yy * Wp + xx;
-      float *q = a.planes + (is_old ? 0 : np) + off;
+    const BeWarp w = be_warp_event<DERIV>(a, i);
+    if (w.ok) {
+      const float dx = w.dx, dy = w.dy;
+      const size_t off = (size_t)w.yy * Wp + w.xx;
+      float *q = a.planes + (w.is_old ? 0 : np) + off;
       atomic_add_f32(q, (1.f - dx) * (1.f - dy));
       atomic_add_f32(q + 1, dx * (1.f - dy));
       atomic_add_f32(q + Wp, (1.f - dx) * dy);
       atomic_add_f32(q + Wp + 1, dx * dy);
       if (DERIV) {
-        const double Ydivrho = y / rho;
-        const double XdivZ = x / z;
-        const double tmp1 = a.fx / ((1 + XdivZ * XdivZ) * z);
-        const double tmp2 = -a.fy / sqrt(1 - Ydivrho * Ydivrho);
-        const double tmp3 = Ydivrho / (rho * rho);
-        const float d00 = (float)tmp1, d02 = (float)(-tmp1 * XdivZ);
-        const float d10 = (float)(tmp2 * tmp3 * x), d11 = (float)(tmp2 * (tmp3 * y - 1 / rho)),
-                    d12 = (float)(tmp2 * tmp3 * z);
-        const float rbx = (float)x, rby = (float)y, rbz = (float)z;
-        // dpm_ddrot = dpm_drb(2x3) * (-[rb]x)(3x3), fp32 accumulation in k order (d01 == 0)
-        float m[6];
-        m[0] = 0.f * (-rbz) + d02 * rby;  // d00*0 + d01*(-rb.z) + d02*rb.y
-        m[1] = d00 * rbz + d02 * (-rbx);
-        m[2] = d00 * (-rby) + 0.f * rbx;
-        m[3] = d11 * (-rbz) + d12 * rby;
-        m[4] = d10 * rbz + d12 * (-rbx);
-        m[5] = d10 * (-rby) + d11 * rbx;
+        const PoseEntry &pe = a.poses[w.batch];
         const int jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
-        const float w00a = -(1.f - dy), w00b = -(1.f - dx);
 #pragma unroll
         for (int c = 0; c < 3 * N; c++) {
           const int j = jbase + c;
           if (j >= 0) {
             // jac = dpm_ddrot(2x3) * ddrot_ddrot_cp(3x3N): fp64 accumulation, fp32 result
             const double j0 = (double)pe.Jcp[c], j1 = (double)pe.Jcp[3 * N + c], j2 = (double)pe.Jcp[6 * N + c];
-            const float r0 = (float)((double)m[0] * j0 + (double)m[1] * j1 + (double)m[2] * j2);
-            const float r1 = (float)((double)m[3] * j0 + (double)m[4] * j1 + (double)m[5] * j2);
+            const float r0 = (float)((double)w.m[0] * j0 + (double)w.m[1] * j1 + (double)w.m[2] * j2);
+            const float r1 = (float)((double)w.m[3] * j0 + (double)w.m[4] * j1 + (double)w.m[5] * j2);
             float *d = a.planes + (size_t)(2 + j) * np + off;
-            atomic_add_f32(d, r0 * w00a + r1 * w00b);
+            atomic_add_f32(d, r0 * (-(1.f - dy)) + r1 * (-(1.f - dx)));
             atomic_add_f32(d + 1, r0 * (1.f - dy) + r1 * (-dx));
             atomic_add_f32(d + Wp, r0 * (-dy) + r1 * (1.f - dx));
             atomic_add_f32(d + Wp + 1, r0 * dy + r1 * dx);
@@ -344,7 +283,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(FinalizeArgs a) {
 // contrast / gradient from the moments (fp64):
 //   variance:     contrast = (sqrt(max(E[I^2]-mu^2,0)))^2 ; grad_k = 2*(E[I D_k] - mu*E[D_k])
 //   mean square:  contrast = E[I^2]                        ; grad_k = 2*E[I D_k]
-__global__ void finalize_kernel(FinalizeArgs a) {
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  __shared__ double red[4];
   const int t = threadIdx.x;
   const double N = a.npix;
   const double mu = a.sums[0] / N;
@@ -360,16 +300,216 @@ __global__ void finalize_kernel(FinalizeArgs a) {
     }
     a.result[0] = c;
     a.result[1] = mu;
+    if (a.fallback) {
+      a.result[4094] = (double)(*a.fallback);
+      *a.fallback = 0u;
+    } else {
+      a.result[4094] = 0.0;
+    }
   }
   for (int k = t; k < a.P; k += blockDim.x) {
     const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
     a.result[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
   }
+  // adjoint mode: grad_k = (2/N) * sum_events <dW_k, Itilde>: block-parallel sum over the gather kernel's partials
+  for (int k = 0; k < a.gP; k++) {
+    double s = 0;
+    for (int b = t; b < a.gblocks; b += 256) s += a.gpartials[(size_t)b * a.gP + k];
+    s = block_sum(s, red);
+    if (t == 0) a.result[2 + k] = 2.0 * s / N;
+  }
 }
 
-void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
+void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 + 2 * a.P), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, a);
+}
+void launch_finalize_only(const FinalizeArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, a);
+}
+void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
+  launch_reduce_partials(a, s);
+  launch_finalize_only(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------- adjoint blur
+// Itilde = G^T (B - mu):  the transpose of the REFLECT_101 separable Gaussian = zero-padded convolution plus the
+// taps that the forward pass reflected across the border, folded back onto the pixels they came from:
+//   (Gx^T b)_q = sum_j g_j b^(q-j)  +  [1<=q<=r] sum_{m=0}^{r-q} g_{q+m} b_m  +  [W-1-r<=q<=W-2] sum_m g_{(W-1-q)+m} b_{W-1-m}
+// (b^ = b inside the image, 0 outside; needs W,H > 2r).
+__global__ __launch_bounds__(kImgThreads) void adjoint_kernel(AdjointArgs a, const double *sums) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int r = a.r, W = a.W, H = a.H;
+  const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
+  float *raw = reinterpret_cast<float *>(smem_raw + 4 * sizeof(double));
+  float *rowb = raw + rawW * rawH;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
+  const float mu = a.subtract_mean ? (float)(sums[0] / a.npix) : 0.f;
+  for (int idx = tid; idx < rawW * rawH; idx += kImgThreads) {
+    const int ly = idx / rawW, lx = idx - ly * rawW;
+    const int gx = x0 + lx - r, gy = y0 + ly - r;
+    float v = 0.f;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = a.B[(size_t)gy * W + gx] - mu;
+    raw[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kTileX * rawH; idx += kImgThreads) {
+    const int ly = idx >> 6, lx = idx & 63;
+    const float *S = raw + ly * rawW + lx;
+    float s = a.taps[0] * S[0];
+    for (int j = 1; j <= 2 * r; j++) s += a.taps[j] * S[j];
+    const int gx = x0 + lx;
+    const float *Srow = raw + ly * rawW;  // raw column of global x is (x - x0 + r)
+    if (1 <= gx && gx <= r) {
+      for (int m = 0; m <= r - gx; m++) s += a.taps[r + gx + m] * Srow[m - x0 + r];
+    }
+    if (W - 1 - r <= gx && gx <= W - 2) {
+      const int d = W - 1 - gx;
+      for (int m = 0; m <= r - d; m++) s += a.taps[r + d + m] * Srow[(W - 1 - m) - x0 + r];
+    }
+    rowb[idx] = s;
+  }
+  __syncthreads();
+  const int tx = tid & 63, tq = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int gy = y0 + tq * 4 + j, gx = x0 + tx;
+    if (gx < W && gy < H) {
+      const int ly = tq * 4 + j + r;
+      const float *T = rowb + ly * kTileX + tx;
+      float s = a.taps[r] * T[0];
+      for (int t = 1; t <= r; t++) s += a.taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
+      const float *Tcol = rowb + tx;  // rowb row of global y is (y - y0 + r)
+      if (1 <= gy && gy <= r) {
+        for (int m = 0; m <= r - gy; m++) s += a.taps[r + gy + m] * Tcol[(m - y0 + r) * kTileX];
+      }
+      if (H - 1 - r <= gy && gy <= H - 2) {
+        const int d = H - 1 - gy;
+        for (int m = 0; m <= r - d; m++) s += a.taps[r + d + m] * Tcol[((H - 1 - m) - y0 + r) * kTileX];
+      }
+      a.out[(size_t)gy * W + gx] = s;
+    }
+  }
+}
+
+void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s) {
+  hipLaunchKernelGGL(adjoint_kernel, dim3(a.nblk), dim3(kImgThreads), image_lds_bytes(a.r), s, a, sums);
+}
+
+// ---------------------------------------------------------------------------------------------- gather passes
+// d(contrast)/d(theta_k) = (2/N) sum_events [ r0_k * dItilde/dx(at the event) + r1_k * dItilde/dy ] where the
+// bilinear-interpolation derivatives are exactly the signed-weight sums the reference scatters into its derivative
+// images (local_image_warped_events.cpp:163-166, event_pano_warper.cpp:327-330).
+__device__ __forceinline__ void bilinear_grad(const float *it, int W, int xx, int yy, float dx, float dy, float &A, float &B) {
+  const float *q = it + (size_t)yy * W + xx;
+  const float i00 = q[0], i01 = q[1], i10 = q[W], i11 = q[W + 1];
+  A = (1.f - dy) * (i01 - i00) + dy * (i11 - i10);
+  B = (1.f - dx) * (i10 - i00) + dx * (i11 - i01);
+}
+
+int gather_blocks(int n) {
+  int blocks = (n + 255) / 256;
+  const int cap = 768;  // 3 workgroups per CU
+  return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+}
+
+__global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
+  __shared__ double red[4];
+  const FeSplatArgs &a = g.ev;
+  double acc[3] = {0, 0, 0};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    const FeWarp w = fe_warp_event<true>(a, i);
+    if (w.ok) {
+      float A, B;
+      bilinear_grad(g.itilde, a.W, w.xx, w.yy, w.dx, w.dy, A, B);
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[k] += (double)w.r0[k] * (double)A + (double)w.r1[k] * (double)B;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double t = block_sum(acc[k], red);
+    if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * 3 + k] = t;
+  }
+}
+
+int launch_fe_gather(const FeGatherArgs &a, hipStream_t s) {
+  const int blocks = gather_blocks(a.ev.n);
+  hipLaunchKernelGGL(fe_gather_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return blocks;
+}
+
+// back end: per event V = (dItilde/dx, dItilde/dy) * dpm_ddrot (3-vector); events of one batch share the 3x3N
+// spline Jacobian, so V is summed per batch first (segmented wave reduction over the contiguous batch runs, then
+// LDS), and one small mat-vec per batch maps it onto the 3N knot parameters the batch touches.
+constexpr int kMaxSlots = 260;  // batches a 256-event chunk can touch (per_batch >= 1)
+constexpr int kMaxGradLDS = 3 * kMaxKnots;
+
+template <int N>
+__global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
+  __shared__ double shV[kMaxSlots * 3];
+  __shared__ double shG[kMaxGradLDS];
+  const BeSplatArgs &a = g.ev;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int j = tid; j < g.P; j += 256) shG[j] = 0;
+  for (int j = tid; j < kMaxSlots * 3; j += 256) shV[j] = 0;
+  __syncthreads();
+  for (int base = blockIdx.x * 256; base < a.n; base += gridDim.x * 256) {
+    const int i = base + tid;
+    const int batch0 = base / a.per_batch;
+    double V0 = 0, V1 = 0, V2 = 0;
+    int batch = -1;
+    if (i < a.n) {
+      const BeWarp w = be_warp_event<true>(a, i);
+      batch = w.batch;
+      if (w.ok) {
+        float A, B;
+        bilinear_grad(g.itilde, a.Wp, w.xx, w.yy, w.dx, w.dy, A, B);
+        V0 = (double)A * (double)w.m[0] + (double)B * (double)w.m[3];
+        V1 = (double)A * (double)w.m[1] + (double)B * (double)w.m[4];
+        V2 = (double)A * (double)w.m[2] + (double)B * (double)w.m[5];
+      }
+    }
+    // segmented reduction over contiguous runs of equal batch id inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t0 = __shfl_down(V0, o, 64), t1 = __shfl_down(V1, o, 64), t2 = __shfl_down(V2, o, 64);
+      const int bo = __shfl_down(batch, o, 64);
+      if (lane + o < 64 && bo == batch) { V0 += t0; V1 += t1; V2 += t2; }
+    }
+    const int bprev = __shfl_up(batch, 1, 64);
+    if (batch >= 0 && (lane == 0 || bprev != batch)) {
+      double *p = shV + 3 * (batch - batch0);
+      atomicAdd(p, V0);
+      atomicAdd(p + 1, V1);
+      atomicAdd(p + 2, V2);
+    }
+    __syncthreads();
+    const int last = min(a.n - 1, base + 255);
+    const int nslots = last / a.per_batch - batch0 + 1;
+    if (tid < nslots) {
+      const PoseEntry &pe = a.poses[batch0 + tid];
+      const double v0 = shV[3 * tid], v1 = shV[3 * tid + 1], v2 = shV[3 * tid + 2];
+      shV[3 * tid] = 0; shV[3 * tid + 1] = 0; shV[3 * tid + 2] = 0;
+      const int jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
+#pragma unroll
+      for (int c = 0; c < 3 * N; c++) {
+        const int j = jbase + c;
+        if (j >= 0)
+          atomicAdd(&shG[j], v0 * (double)pe.Jcp[c] + v1 * (double)pe.Jcp[3 * N + c] + v2 * (double)pe.Jcp[6 * N + c]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < g.P; j += 256) g.gpartials[(size_t)blockIdx.x * g.P + j] = shG[j];
+}
+
+int launch_be_gather(const BeGatherArgs &a, hipStream_t s) {
+  const int blocks = gather_blocks(a.ev.n);
+  if (a.ev.order == 2) hipLaunchKernelGGL(be_gather_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(be_gather_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+  return blocks;
 }
 
 // ---------------------------------------------------------------------------------------------- K4 alpha

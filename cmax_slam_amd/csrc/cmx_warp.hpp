@@ -1,0 +1,126 @@
+// cmx_warp.hpp -- the per-event warps (device inline), shared by the splat, gather and binning kernels.
+//   front end: first-order rotation + pinhole      (reference local_image_warped_events.cpp:94-145)
+//   back end : R*b + equirectangular projection    (reference event_pano_warper.cpp:262-296,
+//                                                   equirectangular_camera.h:18-45)
+// fp64 geometry exactly as the reference (compile with -ffp-contract=off), fp32 bilinear offsets.
+#pragma once
+#include "cmx_internal.hpp"
+
+namespace cmx {
+
+// fire-and-forget fp32 atomic add (global_atomic_add_f32, no return value); needs -munsafe-fp-atomics
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// LDS fp32 atomic add (ds_add_f32)
+__device__ __forceinline__ void lds_add_f32(float *p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// per-event front-end warp: fp64 first-order rotation + pinhole; fp32 bilinear offsets; optional 2x3 Jacobian rows
+struct FeWarp {
+  int xx, yy;
+  float dx, dy;
+  bool ok;
+  float r0[3], r1[3];
+};
+
+template <bool DERIV>
+__device__ __forceinline__ FeWarp fe_warp_core(const FeSplatArgs &a, uint32_t e, double dt) {
+  FeWarp w;
+  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
+  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
+  const double px = b[0], py = b[1], pz = b[2];
+  // p' = p + (omega*dt) x p   (first-order rotation)
+  const double drx = a.wx * dt, dry = a.wy * dt, drz = a.wz * dt;
+  const double rx = px + (dry * pz - drz * py);
+  const double ry = py + (drz * px - drx * pz);
+  const double rz = pz + (drx * py - dry * px);
+  const double iz = 1.0 / rz;
+  const double cxn = rx * iz, cyn = ry * iz;
+  const double u = a.fx * cxn + a.cx;
+  const double v = a.fy * cyn + a.cy;
+  w.xx = (int)u;
+  w.yy = (int)v;
+  w.ok = (1 <= w.xx && w.xx < a.W - 2 && 1 <= w.yy && w.yy < a.H - 2);
+  w.dx = (float)(u - w.xx);
+  w.dy = (float)(v - w.yy);
+  if (DERIV) {
+    // J = diag(fx,fy) * J_proj(2x3) * [(-dt) p]_x   evaluated in the reference's operation order
+    const double vx = (-dt) * px, vy = (-dt) * py, vz = (-dt) * pz;
+    const double a02 = -cxn * iz, a12 = -cyn * iz;
+    w.r0[0] = (float)(a.fx * (a02 * (-vy)));
+    w.r0[1] = (float)(a.fx * (iz * (-vz) + a02 * vx));
+    w.r0[2] = (float)(a.fx * (iz * vy));
+    w.r1[0] = (float)(a.fy * (iz * vz + a12 * (-vy)));
+    w.r1[1] = (float)(a.fy * (a12 * vx));
+    w.r1[2] = (float)(a.fy * (iz * (-vx)));
+  }
+  return w;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ FeWarp fe_warp_event(const FeSplatArgs &a, int i) {
+  return fe_warp_core<DERIV>(a, a.xy[i], a.batch_dt[i / a.per_batch]);
+}
+
+// per-event back-end warp: R*b, equirectangular projection (fp64), optional fp32 d(pixel)/d(rotation) 2x3
+struct BeWarp {
+  int xx, yy;
+  float dx, dy;
+  bool ok, is_old;
+  int batch;
+  float m[6];
+};
+
+template <bool DERIV>
+__device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e, int batch) {
+  BeWarp w;
+  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
+  w.is_old = (e >> 31) != 0;
+  w.batch = batch;
+  const PoseEntry &pe = a.poses[w.batch];
+  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
+  const double b0 = b[0], b1 = b[1], b2 = b[2];
+  // e_ray_w = R * bearing
+  const double x = pe.R[0] * b0 + pe.R[1] * b1 + pe.R[2] * b2;
+  const double y = pe.R[3] * b0 + pe.R[4] * b1 + pe.R[5] * b2;
+  const double z = pe.R[6] * b0 + pe.R[7] * b1 + pe.R[8] * b2;
+  // equirectangular projection
+  const double phi = atan2(x, z);
+  const double rho = sqrt(x * x + y * y + z * z);
+  const double theta = asin(y / rho);
+  const double pxm = a.cxp + phi * a.fx;
+  const double pym = a.cyp + theta * a.fy;
+  w.xx = (int)pxm;
+  w.yy = (int)pym;
+  w.ok = (1 <= w.xx && w.xx < a.Wp - 2 && 1 <= w.yy && w.yy < a.Hp - 2);
+  w.dx = (float)(pxm - w.xx);
+  w.dy = (float)(pym - w.yy);
+  if (DERIV) {
+    const double Ydivrho = y / rho;
+    const double XdivZ = x / z;
+    const double tmp1 = a.fx / ((1 + XdivZ * XdivZ) * z);
+    const double tmp2 = -a.fy / sqrt(1 - Ydivrho * Ydivrho);
+    const double tmp3 = Ydivrho / (rho * rho);
+    const float d00 = (float)tmp1, d02 = (float)(-tmp1 * XdivZ);
+    const float d10 = (float)(tmp2 * tmp3 * x), d11 = (float)(tmp2 * (tmp3 * y - 1 / rho)),
+                d12 = (float)(tmp2 * tmp3 * z);
+    const float rbx = (float)x, rby = (float)y, rbz = (float)z;
+    // dpm_ddrot = dpm_drb(2x3) * (-[rb]x)(3x3), fp32 accumulation in k order (d01 == 0)
+    w.m[0] = 0.f * (-rbz) + d02 * rby;
+    w.m[1] = d00 * rbz + d02 * (-rbx);
+    w.m[2] = d00 * (-rby) + 0.f * rbx;
+    w.m[3] = d11 * (-rbz) + d12 * rby;
+    w.m[4] = d10 * rbz + d12 * (-rbx);
+    w.m[5] = d10 * (-rby) + d11 * rbx;
+  }
+  return w;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ BeWarp be_warp_event(const BeSplatArgs &a, int i) {
+  return be_warp_core<DERIV>(a, a.xy[i], i / a.per_batch);
+}
+
+}  // namespace cmx

@@ -60,6 +60,15 @@ class _Evaluator:
     def set_grad_mode(self, mode):
         self.set_option(_lib.OPT_GRAD_MODE, mode)
 
+    def set_splat_mode(self, mode):
+        """0 = global atomics, 1 = LDS-privatised (events sorted by destination tile)."""
+        self.set_option(_lib.OPT_SPLAT_MODE, mode)
+
+    def stats(self):
+        s = np.zeros(4)
+        self._ck(self._L.cmx_get_stats(self._ctx, _dp(s)))
+        return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3])}
+
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
         self._ck(self._L.cmx_set_stream(self._ctx, C.c_void_p(hip_stream_handle or None)))

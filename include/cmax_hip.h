@@ -54,7 +54,11 @@ enum {
 /* cmx_set_option keys */
 enum {
   CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_PLANES (default) | CMX_GRAD_ADJOINT */
-  CMX_OPT_SPLAT_MODE = 2  /* 0 = global float atomics (default), 1 = LDS-tiled (binned) */
+  CMX_OPT_SPLAT_MODE = 2  /* 0 = one global fp32 atomic per vote (default);
+                             1 = LDS-privatised: events are sorted once per packet/window by the 32x32 destination
+                                 tile of their vote, workgroups accumulate in LDS and flush touched pixels; votes that
+                                 leave a window (parameters drifted) take the global path, so results stay exact;
+                                 applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */
 };
 
 const char *cmx_version(void);
@@ -150,6 +154,9 @@ int cmx_backend_finish(cmx_ctx *ctx, double *contrast, double *grad);
  * cmx_timing_enable(ctx,1) makes every evaluation record events around its kernels;
  * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
 enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COUNT = 5 };
+/* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
+ * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events */
+int cmx_get_stats(cmx_ctx *ctx, double stats[4]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
 
