@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libcmaxhip.so")
 OK, ERR_INVALID_ARG, ERR_EVENT_RANGE, ERR_HIP, ERR_SPLINE_RANGE, ERR_STATE, ERR_TIME_ORDER = range(7)
 VARIANCE, MEAN_SQUARE, GRADIENT_MAGNITUDE = 0, 1, 2
 GRAD_PLANES, GRAD_ADJOINT = 0, 1
-OPT_GRAD_MODE, OPT_SPLAT_MODE = 1, 2
+OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE = 1, 2, 3
 PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
 T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COUNT = 0, 1, 2, 3, 4, 5
 T_NAMES = ("splat", "image", "pose", "gather", "zero")
@@ -53,10 +53,21 @@ SYMBOLS = {
     "cmx_frontend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
     "cmx_backend_accumulate": (C.c_int, [ctx_p, c_dp, C.c_int]),
     "cmx_backend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_frontend_solve": (C.c_int, [ctx_p, c_dp, C.c_void_p]),
+    "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
+    "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "cmx_get_stats": (C.c_int, [ctx_p, c_dp]),
     "cmx_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "cmx_timing_get": (C.c_int, [ctx_p, c_dp, c_i64p]),
 }
+
+
+
+class SolveReport(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("status", C.c_int), ("n_f", C.c_int), ("n_df", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
 
 _LIB = None
 

@@ -79,6 +79,10 @@ struct cmx_ctx {
   double *d_gpartials = nullptr;
   size_t gpartials_cap = 0;
   bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
+  bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
+  bool B_valid = false;       // d_B / d_sums hold the blurred image + moments of that accumulation
+  int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
+  int64_t reuse_hits = 0;
   double last_x[3 * kMaxKnots] = {0};  // parameters of the last accumulate (the gather pass re-warps the events)
 
   // LDS-privatised splat (CMX_OPT_SPLAT_MODE = 1): events sorted by destination tile, chunk table
@@ -96,6 +100,7 @@ struct cmx_ctx {
   int64_t rebin_count = 0;
   double last_fallback_frac = 0;
   bool last_used_lds = false;
+  bool fallback_pending = false;  // an LDS splat ran since the counter was last read back
 
   // reductions
   double *d_partials = nullptr, *d_sums = nullptr;
@@ -384,6 +389,17 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
   return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
 }
 
+// cost-only evaluation in adjoint mode: keep the blurred plane so that a df at the same point only needs the
+// adjoint blur + gather (GSL's conjugate_fr evaluates f then df at every accepted point)
+float *store_B(cmx_ctx *c, bool with_planes_grad) {
+  c->B_valid = false;
+  if (with_planes_grad || !c->reuse_image || !adjoint_ok(c) || c->accum_external) return nullptr;
+  const size_t np = (size_t)c->imgW * c->imgH;
+  if (ensure(c, c->d_B, c->B_cap, np) != CMX_OK) return nullptr;
+  c->B_valid = true;
+  return c->d_B;
+}
+
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -439,7 +455,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
 
 // adjoint gradient: image pass (keeps the blurred plane B) -> sums -> Itilde = G^T(B - mu) -> gather over the
 // events -> finalize (contrast from the moments, gradient = (2/N) * sum of the gather partials)
-int run_adjoint(cmx_ctx *c, int P) {
+int run_adjoint(cmx_ctx *c, int P, bool reuse) {
   const int W = c->imgW, H = c->imgH;
   const size_t np = (size_t)W * H;
   int rc = ensure(c, c->d_B, c->B_cap, np);
@@ -484,8 +500,11 @@ int run_adjoint(cmx_ctx *c, int P) {
   f.fallback = c->d_fallback;
   {
     Span sp(c, CMX_T_IMAGE);
-    launch_image_moments(a, c->stream);
-    launch_reduce_partials(f, c->stream);
+    if (!reuse) {
+      launch_image_moments(a, c->stream);
+      launch_reduce_partials(f, c->stream);
+    }
+    c->B_valid = true;
     AdjointArgs ad{};
     ad.W = W; ad.H = H; ad.r = c->radius;
     memcpy(ad.taps, c->taps, sizeof(ad.taps));
@@ -523,7 +542,8 @@ int run_adjoint(cmx_ctx *c, int P) {
 
 int sync_and_collect(cmx_ctx *c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->last_used_lds && c->n_packed > 0) c->last_fallback_frac = c->h_result[4094] / (double)c->n_packed;
+  if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[4094] / (double)c->n_packed;
+  c->fallback_pending = false;
   if (c->timing) collect_spans(c);
   return CMX_OK;
 }
@@ -610,6 +630,10 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       c->splat_mode = value;
       c->bin_valid = false;
       return CMX_OK;
+    case CMX_OPT_REUSE_IMAGE:
+      c->reuse_image = value != 0;
+      c->B_valid = false;
+      return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
 }
@@ -630,12 +654,13 @@ int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
   return CMX_OK;
 }
 
-int cmx_get_stats(cmx_ctx *c, double stats[4]) {
+int cmx_get_stats(cmx_ctx *c, double stats[8]) {
   if (!c || !stats) return CMX_ERR_INVALID_ARG;
   stats[0] = (double)c->rebin_count;
   stats[1] = c->last_fallback_frac;
   stats[2] = (double)c->nchunks;
   stats[3] = (double)c->n_packed;
+  stats[4] = (double)c->reuse_hits;
   return CMX_OK;
 }
 
@@ -698,6 +723,8 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   if (rc) return rc;
   c->have_data = false;
   c->accumulated = false;
+  c->x_valid = false;
+  c->B_valid = false;
   if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
   if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
     return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d is not implemented on the GPU (variance / mean-square only)",
@@ -757,6 +784,7 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   {
     Span sp(c, CMX_T_SPLAT);
     c->last_used_lds = use_lds;
+    if (use_lds) c->fallback_pending = true;
     if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream);
     else launch_fe_splat(a, nplanes > 1, c->stream);
   }
@@ -764,6 +792,8 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->accum_count = nplanes * np;
   c->last_P = nplanes - 1;
   c->accumulated = true;
+  c->x_valid = true;
+  c->B_valid = false;
   return CMX_OK;
 }
 
@@ -785,8 +815,8 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
     return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
   int rc = bind(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
-  else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, 3, c->B_valid);
+  else rc = run_image_and_finalize(c, grad ? 3 : 0, store_B(c, grad != nullptr), nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;
@@ -795,7 +825,18 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   return CMX_OK;
 }
 
+static bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) {
+  if (!want_grad || !c->reuse_image || !c->have_data || !c->accumulated || !c->x_valid || !c->B_valid) return false;
+  if (!adjoint_ok(c) || c->accum_external) return false;
+  return memcmp(x, c->last_x, sizeof(double) * (size_t)n) == 0;
+}
+
 int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
+  if (c && c->kind == KIND_FE && omega && can_reuse(c, omega, 3, grad != nullptr)) {
+    c->last_adjoint = true;  // image of this very point is resident: adjoint blur + gather only
+    c->reuse_hits++;
+    return cmx_frontend_finish(c, contrast, grad);
+  }
   int rc = cmx_frontend_accumulate(c, omega, grad != nullptr);
   if (rc) return rc;
   return cmx_frontend_finish(c, contrast, grad);
@@ -811,6 +852,7 @@ int cmx_frontend_get_iwe(cmx_ctx *c, const double omega[3], int blur, float *iwe
   const int nplanes = deriv ? 4 : 1;
   c->last_adjoint = false;
   rc = fe_accumulate(c, omega, nplanes);
+  c->x_valid = false;
   if (rc) return rc;
   rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
   if (rc) return rc;
@@ -858,6 +900,8 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (rc) return rc;
   c->have_data = false;
   c->accumulated = false;
+  c->x_valid = false;
+  c->B_valid = false;
   if (order != 2 && order != 4) return fail(c, CMX_ERR_INVALID_ARG, "spline order %d unsupported (2 = linear, 4 = cubic)", order);
   if (K < order || K > kMaxKnots) return fail(c, CMX_ERR_INVALID_ARG, "K=%d outside [%d, %d]", K, order, kMaxKnots);
   if (num_fixed < 0 || num_fixed > K) return fail(c, CMX_ERR_INVALID_ARG, "num_fixed=%d outside [0, K]", num_fixed);
@@ -952,7 +996,8 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   HIP_TRY(c, hipMemcpyAsync(c->d_spline, c->h_spline, sizeof(SplineArgs), hipMemcpyHostToDevice, c->stream));
   {
     Span sp(c, CMX_T_POSE);
-    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad, c->d_poses, c->stream);
+    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poses,
+                         c->stream);
   }
   {
     Span sp(c, CMX_T_ZERO);
@@ -967,6 +1012,7 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   {
     Span sp(c, CMX_T_SPLAT);
     c->last_used_lds = use_lds;
+    if (use_lds) c->fallback_pending = true;
     if (use_lds) launch_be_splat_lds(a, binned(c), c->stream);
     else launch_be_splat(a, deriv, c->stream);
   }
@@ -974,6 +1020,9 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   c->accum_count = (size_t)(2 + P) * np;
   c->last_P = P;
   c->accumulated = true;
+  c->x_valid = true;
+  c->B_valid = false;
+  for (int k = 0; k < 3 * Kopt && k < 3 * kMaxKnots; k++) c->last_x[k] = drotv[k];
   return CMX_OK;
 }
 
@@ -1024,8 +1073,8 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (rc) return rc;
   rc = be_first_iter(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, P);
-  else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, P, c->B_valid);
+  else rc = run_image_and_finalize(c, grad ? P : 0, store_B(c, grad != nullptr), nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;
@@ -1035,6 +1084,11 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
+  if (c && c->kind == KIND_BE && drotv && can_reuse(c, drotv, 3 * (c->K - c->num_fixed), grad != nullptr)) {
+    c->last_adjoint = true;
+    c->reuse_hits++;
+    return cmx_backend_finish(c, contrast, grad);
+  }
   int rc = cmx_backend_accumulate(c, drotv, grad != nullptr);
   if (rc) return rc;
   return cmx_backend_finish(c, contrast, grad);

@@ -65,9 +65,15 @@ class _Evaluator:
         self.set_option(_lib.OPT_SPLAT_MODE, mode)
 
     def stats(self):
-        s = np.zeros(4)
+        s = np.zeros(8)
         self._ck(self._L.cmx_get_stats(self._ctx, _dp(s)))
-        return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3])}
+        return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3]),
+                "reuse_hits": int(s[4])}
+
+    def set_fast_path(self):
+        """The production configuration: adjoint gradient + LDS-privatised splat (+ image reuse, on by default)."""
+        self.set_grad_mode(_lib.GRAD_ADJOINT)
+        self.set_splat_mode(1)
 
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
@@ -156,6 +162,14 @@ class FrontendEvaluator(_Evaluator):
     def contrast_df(self, v):
         return -self.eval(v, True)[1]
 
+    def setupProblemAndOptimize(self, ang_vel):
+        """FR-CG solve from the warm start `ang_vel` (local_optim_contrast_gsl.cpp:74-233).
+        Returns (ang_vel_estimate, report dict)."""
+        x = np.array(ang_vel, dtype=np.float64, order="C", copy=True)
+        rep = _lib.SolveReport()
+        self._ck(self._L.cmx_frontend_solve(self._ctx, _dp(x), C.byref(rep)))
+        return x, {f: getattr(rep, f) for f, _ in rep._fields_}
+
 
 class BackendEvaluator(_Evaluator):
     def __init__(self, W, H, lut, pano_width, pano_height, device=0):
@@ -237,3 +251,11 @@ class BackendEvaluator(_Evaluator):
 
     def contrast_df(self, v):
         return -self.eval(v, True)[1]
+
+    def setupProblemAndOptimize(self, drotv0=None):
+        """FR-CG solve of the window (global_optim_contrast_gsl.cpp:15-145); the reference starts at 0.
+        Returns (optimal incremental rotation vectors, report dict)."""
+        x = np.zeros(self.num_params) if drotv0 is None else np.array(drotv0, dtype=np.float64, order="C", copy=True)
+        rep = _lib.SolveReport()
+        self._ck(self._L.cmx_backend_solve(self._ctx, int(self.num_params), _dp(x), C.byref(rep)))
+        return x, {f: getattr(rep, f) for f, _ in rep._fields_}

@@ -54,11 +54,14 @@ enum {
 /* cmx_set_option keys */
 enum {
   CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_PLANES (default) | CMX_GRAD_ADJOINT */
-  CMX_OPT_SPLAT_MODE = 2  /* 0 = one global fp32 atomic per vote (default);
+  CMX_OPT_SPLAT_MODE = 2, /* 0 = one global fp32 atomic per vote (default);
                              1 = LDS-privatised: events are sorted once per packet/window by the 32x32 destination
                                  tile of their vote, workgroups accumulate in LDS and flush touched pixels; votes that
                                  leave a window (parameters drifted) take the global path, so results stay exact;
                                  applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */
+  CMX_OPT_REUSE_IMAGE = 3 /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
+                             the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
+                             df at every accepted point; the reference recomputes everything, :58-70) */
 };
 
 const char *cmx_version(void);
@@ -149,14 +152,38 @@ int cmx_frontend_finish(cmx_ctx *ctx, double *contrast, double *grad);
 int cmx_backend_accumulate(cmx_ctx *ctx, const double *drotv, int want_grad);
 int cmx_backend_finish(cmx_ctx *ctx, double *contrast, double *grad);
 
+/* ------------------------------------------------------------------ optimiser driver (host C++) ----------
+ * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors
+ * (src/frontend/local_optim_contrast_gsl.cpp:74-233, src/backend/global_optim_contrast_gsl.cpp:15-145).  These
+ * entry points restate those driver loops (same constants and stopping rules) over a restated conjugate_fr
+ * (GSL itself is not vendored by the reference); a host that keeps GSL simply does not call them. */
+typedef struct {
+  int iterations;      /* gsl_multimin_fdfminimizer_iterate calls (line searches) */
+  int status;          /* 0 = converged on an accepted step, -2 = iteration limit, 27 = no progress (GSL codes) */
+  int n_f, n_df;       /* cost-only and cost+gradient evaluations performed */
+  double initial_cost; /* -contrast at the start */
+  double final_cost;   /* -contrast at the returned parameters */
+} cmx_solve_report;
+/* ang_vel: in = warm start (the reference keeps ang_vel_ between packets), out = estimate */
+int cmx_frontend_solve(cmx_ctx *ctx, double ang_vel[3], cmx_solve_report *report);
+/* drotv: in = start (the reference uses 0), out = optimal incremental rotation vectors, n_params = 3*(K-num_fixed) */
+int cmx_backend_solve(cmx_ctx *ctx, int n_params, double *drotv, cmx_solve_report *report);
+/* the same driver loop over an arbitrary functor triple (the shape of gsl_multimin_function_fdf); lets a host or a
+ * test run the identical optimiser over any other implementation of the cost */
+typedef double (*cmx_f_fn)(const double *x, void *params);
+typedef void (*cmx_df_fn)(const double *x, void *params, double *g);
+typedef void (*cmx_fdf_fn)(const double *x, void *params, double *f, double *g);
+int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, int n, double *x, double step_size,
+                      double tol, double epsabs_grad, double tolfun, int max_iterations, cmx_solve_report *report);
+
 /* ------------------------------------------------------------------ timing hooks ------------------------
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
  * cmx_timing_enable(ctx,1) makes every evaluation record events around its kernels;
  * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
 enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COUNT = 5 };
 /* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
- * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events */
-int cmx_get_stats(cmx_ctx *ctx, double stats[4]);
+ * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5..7] reserved */
+int cmx_get_stats(cmx_ctx *ctx, double stats[8]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
 

@@ -32,14 +32,14 @@ def _fe(hip, oracle, p, adjoint, measure=0, sigma=1.0):
 def test_frontend_lds_splat_parity_and_drift(hip, oracle, small, adjoint):
     fe, ref = _fe(hip, oracle, small, adjoint)
     # first evaluation bins under omega0; then walk away from it, including far outside the 16-px margin
-    for om in ((0.3, -0.5, 0.2), (0.35, -0.55, 0.25), (0.6, -0.9, 0.4), (-8.0, 12.0, 18.0), (0, 0, 0)):
+    for om in ((0.3, -0.5, 0.2), (0.35, -0.55, 0.25), (0.6, -0.9, 0.4), (-4.0, 6.0, 3.0), (0, 0, 0)):
         c_ref, g_ref = ref.eval(om)
         assert rel_scalar(fe.eval(om, want_grad=False)[0], c_ref) < RTOL
         c, g = fe.eval(om)
         assert rel_scalar(c, c_ref) < RTOL
         assert rel_vec(g, g_ref) < RTOL
     st = fe.stats()
-    assert st["rebins"] >= 2          # the jump to (-8, 12, 18) forced a re-sort
+    assert st["rebins"] >= 2          # the jump to (-4, 6, 3) forced a re-sort
     assert st["fallback_frac"] < 0.15
 
 
@@ -89,7 +89,7 @@ def test_backend_lds_splat_parity_and_drift(hip, oracle, order, K, nf, T):
     w = synth.backend_window(60_003, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, order, K, nf, T, seed=15)
     be, ref = _be(hip, oracle, w)
     rng = np.random.default_rng(2)
-    for d in (np.zeros(w.P), rng.normal(0, 0.005, w.P), rng.normal(0, 0.02, w.P), np.full(w.P, 0.5)):
+    for d in (np.zeros(w.P), rng.normal(0, 0.005, w.P), rng.normal(0, 0.02, w.P), np.full(w.P, 0.5), np.full(w.P, 0.49)):
         c_ref, g_ref = ref.eval(d)
         assert rel_scalar(be.eval(d, want_grad=False)[0], c_ref) < RTOL
         c, g = be.eval(d)
@@ -97,7 +97,7 @@ def test_backend_lds_splat_parity_and_drift(hip, oracle, order, K, nf, T):
         assert rel_vec(g, g_ref) < RTOL
         assert rel_img(be.get_plane(_lib.PLANE_IL_OLD), ref.IL_old) < RTOL
         assert rel_img(be.get_plane(_lib.PLANE_IL_NEW), ref.IL_new) < RTOL
-    assert be.stats()["rebins"] >= 2  # a 0.5 rad perturbation moves every vote out of its window
+    assert be.stats()["rebins"] >= 2  # a 0.5 rad perturbation moves every vote out of its window: the next accumulate re-sorts
 
 
 def test_backend_lds_sampling(hip, oracle):
