@@ -53,6 +53,13 @@ SYMBOLS = {
     "cmx_frontend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
     "cmx_backend_accumulate": (C.c_int, [ctx_p, c_dp, C.c_int]),
     "cmx_backend_finish": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_frontend_finish_begin": (C.c_int, [ctx_p, C.c_int]),
+    "cmx_frontend_finish_end": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_backend_finish_begin": (C.c_int, [ctx_p, C.c_int]),
+    "cmx_backend_finish_end": (C.c_int, [ctx_p, c_dp, c_dp]),
+    "cmx_grad_ptr": (C.c_void_p, [ctx_p]),
+    "cmx_grad_count": (C.c_size_t, [ctx_p]),
+    "cmx_set_grad_buffer": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),
     "cmx_frontend_solve": (C.c_int, [ctx_p, c_dp, C.c_void_p]),
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,
@@ -92,6 +99,15 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise ImportError("libcmaxhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback for the event-warping path)")
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME, libamdhip64.so.7).  A process that uses both must
+        # load torch's copy first, otherwise torch finds the device already owned by the system runtime and reports
+        # "No HIP GPUs are available".  Loading torch first makes both share one runtime; hosts that never use torch
+        # (the C++/ROS integration) are unaffected.  Opt out with CMAX_HIP_NO_TORCH=1.
+        if not os.environ.get("CMAX_HIP_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void be_bin_keys_kernel(BeSplatArgs a, int til
                                                           uint32_t *idx) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
     const BeWarp w = be_warp_event<false>(a, i);
-    keys[i] = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    // the IL_old / IL_new split is a property of the event (its timestamp), so it can be part of the sort key:
+    // every chunk then votes into ONE plane and needs one LDS window
+    keys[i] = w.ok ? (uint32_t)(2 * ((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) + (w.is_old ? 0 : 1)) : (uint32_t)(2 * ntiles);
     idx[i] = (uint32_t)i;
   }
 }
@@ -80,12 +82,23 @@ void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int count, int 
 
 // ---------------------------------------------------------------------------------------------- LDS splats
 // One workgroup = one chunk of sorted events.  win: kBinWindow^2 fp32 per plane.
-__device__ __forceinline__ void vote4_lds(float *win, int lx, int ly, float dx, float dy) {
-  float *q = win + ly * kBinWindow + lx;
-  lds_add_f32(q, (1.f - dx) * (1.f - dy));
-  lds_add_f32(q + 1, dx * (1.f - dy));
-  lds_add_f32(q + kBinWindow, (1.f - dx) * dy);
-  lds_add_f32(q + kBinWindow + 1, dx * dy);
+// LDS accumulators are 64-bit fixed point (2^-30 units), not fp32: on gfx950 ds_add_f32 retires ONE lane at a time
+// (193 G lane-atomics/s for any address pattern) while ds_add_u64 runs at 1.7 T/s (tools/microbench/lds_atomics.hip).
+// Integer adds also commute, so a window's sum does not depend on the order the votes arrive in; the quantisation
+// (<= 2^-31 per vote) is far below fp32's own rounding of the reference's accumulators.
+typedef unsigned long long fix_t;
+constexpr float kFixScale = 1073741824.0f;        // 2^30
+constexpr double kFixInv = 1.0 / 1073741824.0;
+__device__ __forceinline__ fix_t to_fix(float w) { return (fix_t)(unsigned)(w * kFixScale + 0.5f); }
+__device__ __forceinline__ void lds_add_fix(fix_t *p, fix_t v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void vote4_lds(fix_t *win, int lx, int ly, float dx, float dy) {
+  fix_t *q = win + ly * kBinStride + lx;
+  lds_add_fix(q, to_fix((1.f - dx) * (1.f - dy)));
+  lds_add_fix(q + 1, to_fix(dx * (1.f - dy)));
+  lds_add_fix(q + kBinStride, to_fix((1.f - dx) * dy));
+  lds_add_fix(q + kBinStride + 1, to_fix(dx * dy));
 }
 __device__ __forceinline__ void vote4_global(float *img, int W, int xx, int yy, float dx, float dy) {
   float *q = img + (size_t)yy * W + xx;
@@ -95,37 +108,57 @@ __device__ __forceinline__ void vote4_global(float *img, int W, int xx, int yy, 
   atomic_add_f32(q + W + 1, dx * dy);
 }
 
+constexpr int kUnroll = 4;  // events in flight per thread: the loop is latency-bound (dependent L2 gathers), not ALU-bound
+
 __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
-  __shared__ float win[kBinWindow * kBinWindow];
+  __shared__ fix_t win[kBinWindow * kBinStride];
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
-  if (has_win) {
-    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) win[p] = 0.f;
+  if (has_win && !(b.variant & 4)) {
+    for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
     __syncthreads();
   }
   unsigned nfall = 0;
-  for (int j = c.beg + tid; j < c.end; j += 256) {
-    const FeWarp w = fe_warp_core<false>(a, b.sxy[j], a.batch_dt[b.sbatch[j]]);
-    if (w.ok) {
-      const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
-      if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
-        vote4_lds(win, lx, ly, w.dx, w.dy);
-      } else {
-        vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
-        nfall++;
+  for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * kUnroll) {
+    uint32_t e[kUnroll], bi[kUnroll];
+    bool act[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const int j = j0 + u * 256;
+      act[u] = j < c.end;
+      e[u] = act[u] ? b.sxy[j] : 0u;
+      bi[u] = act[u] ? b.sbatch[j] : 0u;
+    }
+    double px[kUnroll], py[kUnroll], pz[kUnroll], dt[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
+      px[u] = l[0]; py[u] = l[1]; pz[u] = l[2];
+      dt[u] = a.batch_dt[bi[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const FeWarp w = fe_warp_math<false>(a, px[u], py[u], pz[u], dt[u]);
+      if ((b.variant & 1) && act[u] && w.ok && w.xx == -12345) nfall++;
+      if (act[u] && w.ok && !(b.variant & 1)) {
+        const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
+        if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
+          vote4_lds(win, lx, ly, w.dx, w.dy);
+        } else {
+          vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
+          nfall++;
+        }
       }
     }
   }
   if (nfall) atomicAdd(b.fallback, nfall);
-  if (has_win) {
+  if (has_win && !(b.variant & 2)) {
     __syncthreads();
     for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
-      const float v = win[p];
-      if (v != 0.f) {
-        const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
-        atomic_add_f32(a.planes + (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx), v);
-      }
+      const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
+      const fix_t v = win[ly * kBinStride + lx];
+      if (v != 0ull) atomic_add_f32(a.planes + (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx), (float)((double)v * kFixInv));
     }
   }
 }
@@ -135,39 +168,58 @@ void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_
 }
 
 __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
-  __shared__ float win[2 * kBinWindow * kBinWindow];  // IL_old window, IL_new window
+  __shared__ fix_t win[kBinWindow * kBinStride];  // one plane per chunk: the sort key separates IL_old / IL_new events
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
   const size_t np = (size_t)a.Wp * a.Hp;
   if (has_win) {
-    for (int p = tid; p < 2 * kBinWindow * kBinWindow; p += 256) win[p] = 0.f;
+    for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
     __syncthreads();
   }
   unsigned nfall = 0;
-  for (int j = c.beg + tid; j < c.end; j += 256) {
-    const BeWarp w = be_warp_core<false>(a, b.sxy[j], (int)b.sbatch[j]);
-    if (w.ok) {
-      const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
-      if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
-        vote4_lds(win + (w.is_old ? 0 : kBinWindow * kBinWindow), lx, ly, w.dx, w.dy);
-      } else {
-        vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
-        nfall++;
+  constexpr int U = 2;
+  for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * U) {
+    uint32_t e[U], bi[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = j0 + u * 256;
+      act[u] = j < c.end;
+      e[u] = act[u] ? b.sxy[j] : 0u;
+      bi[u] = act[u] ? b.sbatch[j] : 0u;
+    }
+    double b0[U], b1[U], b2[U], R[U][9];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
+      b0[u] = l[0]; b1[u] = l[1]; b2[u] = l[2];
+      const double *Rp = a.poses[bi[u]].R;
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[u][k] = Rp[k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const BeWarp w = be_warp_math<false>(a, e[u], (int)bi[u], b0[u], b1[u], b2[u], R[u]);
+      if (act[u] && w.ok) {
+        const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
+        if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
+          vote4_lds(win, lx, ly, w.dx, w.dy);
+        } else {
+          vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
+          nfall++;
+        }
       }
     }
   }
   if (nfall) atomicAdd(b.fallback, nfall);
   if (has_win) {
     __syncthreads();
-    for (int p = tid; p < 2 * kBinWindow * kBinWindow; p += 256) {
-      const float v = win[p];
-      if (v != 0.f) {
-        const int plane = p / (kBinWindow * kBinWindow);
-        const int q = p - plane * (kBinWindow * kBinWindow);
-        const int ly = q / kBinWindow, lx = q - ly * kBinWindow;
-        atomic_add_f32(a.planes + (size_t)plane * np + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), v);
-      }
+    float *dst = a.planes + (c.plane ? np : 0);
+    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
+      const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
+      const fix_t v = win[ly * kBinStride + lx];
+      if (v != 0ull) atomic_add_f32(dst + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), (float)((double)v * kFixInv));
     }
   }
 }

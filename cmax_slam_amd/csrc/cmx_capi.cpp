@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -78,6 +79,11 @@ struct cmx_ctx {
   size_t B_cap = 0, itilde_cap = 0;
   double *d_gpartials = nullptr;
   size_t gpartials_cap = 0;
+  double *d_gsum = nullptr;   // this rank's partial gradient sums [P] (caller-owned when external: RCCL reduces it in place)
+  size_t gsum_cap = 0;
+  bool gsum_external = false;
+  bool finish_pending = false; // finish_begin ran, finish_end has not
+  int pending_P = 0;
   bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
   bool B_valid = false;       // d_B / d_sums hold the blurred image + moments of that accumulation
@@ -110,6 +116,7 @@ struct cmx_ctx {
 
   // timing
   bool timing = false;
+  int timing_mask = 0;  // bit i: record HIP events around kernel class i
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;
   double t_ms[CMX_T_COUNT] = {0};
@@ -209,7 +216,7 @@ struct Span {
   cmx_ctx *c;
   TimedSpan s{};
   bool on;
-  Span(cmx_ctx *ctx, int cls) : c(ctx), on(ctx->timing) {
+  Span(cmx_ctx *ctx, int cls) : c(ctx), on(ctx->timing && ((ctx->timing_mask >> cls) & 1)) {
     if (on) {
       s.cls = cls;
       s.a = get_event(c);
@@ -277,7 +284,8 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   const int n = c->n_packed;
   const int W = c->imgW, H = c->imgH;
   const int tiles_x = (W + kBinTile - 1) / kBinTile, tiles_y = (H + kBinTile - 1) / kBinTile;
-  const int ntiles = tiles_x * tiles_y;
+  const int planes_per_tile = fe ? 1 : 2;  // back end: key = 2*tile + (IL_new ? 1 : 0)
+  const int ntiles = tiles_x * tiles_y * planes_per_tile;
   int rc;
   if ((size_t)n > c->bin_cap || !c->d_keys) {
     uint32_t **ptrs[6] = {&c->d_keys, &c->d_keys_s, &c->d_idx, &c->d_idx_s, &c->d_sxy, &c->d_sbatch};
@@ -297,7 +305,7 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   std::vector<int> ts((size_t)ntiles + 2, 0);
   if (n > 0) {
     if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
-    else launch_be_bin_keys(*be, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
+    else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
     int end_bit = 1;
     while ((1 << end_bit) <= ntiles) end_bit++;
     size_t tb = 0;
@@ -325,9 +333,10 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
     const int beg = ts[t], end = ts[t + 1];
     if (end <= beg) continue;
     const bool sentinel = (t == ntiles);
-    const int wx0 = sentinel ? -200000000 : (t % tiles_x) * kBinTile - kBinMargin;
-    const int wy0 = sentinel ? -200000000 : (t / tiles_x) * kBinTile - kBinMargin;
-    for (int b = beg; b < end; b += M) chunks.push_back(Chunk{wx0, wy0, b, (b + M < end) ? b + M : end});
+    const int tile = t / planes_per_tile, plane = t % planes_per_tile;
+    const int wx0 = sentinel ? -200000000 : (tile % tiles_x) * kBinTile - kBinMargin;
+    const int wy0 = sentinel ? -200000000 : (tile / tiles_x) * kBinTile - kBinMargin;
+    for (int b = beg; b < end; b += M) chunks.push_back(Chunk{wx0, wy0, b, (b + M < end) ? b + M : end, plane, 0});
   }
   std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return (a.end - a.beg) > (b.end - b.beg); });
   rc = ensure(c, c->d_chunks, c->chunks_cap, chunks.size());
@@ -349,6 +358,8 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.chunks = c->d_chunks;
   b.nchunks = c->nchunks;
   b.fallback = c->d_fallback;
+  static const int variant = getenv("CMX_DEBUG_VARIANT") ? atoi(getenv("CMX_DEBUG_VARIANT")) : 0;
+  b.variant = variant;
   return b;
 }
 
@@ -446,7 +457,12 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     f.sums = c->d_sums;
     f.result = c->d_result;
     f.fallback = c->d_fallback;
-    launch_finalize(f, c->stream);
+    if (P == 0 && a.nblk <= 2048) {
+      f.direct = 1;
+      launch_finalize_only(f, c->stream);
+    } else {
+      launch_finalize(f, c->stream);
+    }
   }
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
@@ -455,7 +471,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
 
 // adjoint gradient: image pass (keeps the blurred plane B) -> sums -> Itilde = G^T(B - mu) -> gather over the
 // events -> finalize (contrast from the moments, gradient = (2/N) * sum of the gather partials)
-int run_adjoint(cmx_ctx *c, int P, bool reuse) {
+int run_adjoint(cmx_ctx *c, int P, bool reuse, int phase = 0) {
   const int W = c->imgW, H = c->imgH;
   const size_t np = (size_t)W * H;
   int rc = ensure(c, c->d_B, c->B_cap, np);
@@ -485,6 +501,12 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse) {
   rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * (P > 0 ? P : 1));
   if (rc) return rc;
   if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
+  if (!c->gsum_external) {
+    rc = ensure(c, c->d_gsum, c->gsum_cap, (size_t)(P > 0 ? P : 1));
+    if (rc) return rc;
+  } else if ((size_t)P > c->gsum_cap) {
+    return fail(c, CMX_ERR_INVALID_ARG, "external gradient buffer too small: %zu < %d doubles", c->gsum_cap, P);
+  }
   a.partials = c->d_partials;
   FinalizeArgs f{};
   f.P = 0;
@@ -494,27 +516,40 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse) {
   f.partials = c->d_partials;
   f.sums = c->d_sums;
   f.result = c->d_result;
-  f.gpartials = c->d_gpartials;
-  f.gblocks = gb;
+  const bool direct = a.nblk <= 2048;  // few tiles: fold the moment reduction into the adjoint / finalize kernels
+  f.direct = direct ? 1 : 0;
+  if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
+    f.gpartials = c->d_gpartials;
+    f.gblocks = gb;
+  } else {           // split call: finalize reads the (all-reduced) per-parameter sums
+    f.gpartials = c->d_gsum;
+    f.gblocks = 1;
+  }
   f.gP = P;
   f.fallback = c->d_fallback;
+  if (phase == 2) {
+    launch_finalize_only(f, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
   {
     Span sp(c, CMX_T_IMAGE);
     if (!reuse) {
       launch_image_moments(a, c->stream);
-      launch_reduce_partials(f, c->stream);
+      if (!direct) launch_reduce_partials(f, c->stream);
     }
     c->B_valid = true;
     AdjointArgs ad{};
     ad.W = W; ad.H = H; ad.r = c->radius;
     memcpy(ad.taps, c->taps, sizeof(ad.taps));
     ad.B = c->d_B;
+    ad.partials = c->d_partials;
     ad.nblk = a.nblk;
     ad.tiles_x = a.tiles_x;
     ad.npix = (double)np;
     ad.subtract_mean = (c->measure == CMX_MEAN_SQUARE) ? 0 : 1;
     ad.out = c->d_itilde;
-    launch_adjoint(ad, c->d_sums, c->stream);
+    launch_adjoint(ad, direct ? nullptr : c->d_sums, c->stream);
   }
   {
     Span sp(c, CMX_T_GATHER);
@@ -523,6 +558,10 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse) {
       g.ev = fe_args(c, c->last_x);
       g.itilde = c->d_itilde;
       g.gpartials = c->d_gpartials;
+      if (c->splat_mode == 1 && c->bin_valid) {  // tile order: the same sorted arrays the LDS splat consumes
+        g.sxy = c->d_sxy;
+        g.sbatch = c->d_sbatch;
+      }
       if (c->n_packed > 0) launch_fe_gather(g, c->stream);
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P * sizeof(double), c->stream));
     } else {
@@ -534,6 +573,11 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse) {
       if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->stream);
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * (P > 0 ? P : 1) * sizeof(double), c->stream));
     }
+    if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, P, c->d_gsum, c->stream);
+  }
+  if (phase == 1) {
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
   }
   launch_finalize_only(f, c->stream);
   HIP_TRY(c, hipGetLastError());
@@ -613,6 +657,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_B);
   hipFree(c->d_itilde);
   hipFree(c->d_gpartials);
+  if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -667,6 +712,7 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
 int cmx_timing_enable(cmx_ctx *c, int on) {
   if (!c) return CMX_ERR_INVALID_ARG;
   c->timing = on != 0;
+  c->timing_mask = on;
   return CMX_OK;
 }
 int cmx_timing_get(cmx_ctx *c, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]) {
@@ -1092,6 +1138,66 @@ int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *
   int rc = cmx_backend_accumulate(c, drotv, grad != nullptr);
   if (rc) return rc;
   return cmx_backend_finish(c, contrast, grad);
+}
+
+// ---- three-phase finish for sharded adjoint evaluations: begin (image, adjoint blur, gather -> partial gradient
+// sums on the device), caller all-reduces cmx_grad_ptr(), end (finalize + read-back)
+static int finish_begin(cmx_ctx *c, int kind, int want_grad) {
+  if (!c || c->kind != kind) return fail(c, CMX_ERR_STATE, "wrong context kind");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish_begin without accumulate");
+  int rc = bind(c);
+  if (rc) return rc;
+  const int P = (kind == KIND_FE) ? 3 : 3 * (c->K - c->num_fixed);
+  if (kind == KIND_BE) {
+    rc = be_first_iter(c);
+    if (rc) return rc;
+  }
+  if (want_grad && c->last_adjoint) {
+    rc = run_adjoint(c, P, false, 1);
+    c->pending_P = P;
+  } else {
+    if (want_grad && c->last_P != P) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+    rc = run_image_and_finalize(c, want_grad ? P : 0, nullptr, nullptr);
+    c->pending_P = -1;  // nothing left to exchange: finish_end only synchronises
+  }
+  if (rc) return rc;
+  c->finish_pending = true;
+  return CMX_OK;
+}
+static int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad) {
+  if (!c || c->kind != kind) return fail(c, CMX_ERR_STATE, "wrong context kind");
+  if (!c->finish_pending) return fail(c, CMX_ERR_STATE, "finish_end without finish_begin");
+  if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
+  int rc = bind(c);
+  if (rc) return rc;
+  const int P = (kind == KIND_FE) ? 3 : 3 * (c->K - c->num_fixed);
+  if (c->pending_P >= 0) {
+    rc = run_adjoint(c, c->pending_P, false, 2);
+    if (rc) return rc;
+  }
+  c->finish_pending = false;
+  rc = sync_and_collect(c);
+  if (rc) return rc;
+  *contrast = c->h_result[0];
+  if (grad) for (int k = 0; k < P; k++) grad[k] = c->h_result[2 + k];
+  return CMX_OK;
+}
+int cmx_frontend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_FE, want_grad); }
+int cmx_frontend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_FE, contrast, grad); }
+int cmx_backend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_BE, want_grad); }
+int cmx_backend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_BE, contrast, grad); }
+void *cmx_grad_ptr(const cmx_ctx *c) { return c ? c->d_gsum : nullptr; }
+size_t cmx_grad_count(const cmx_ctx *c) { return (c && c->finish_pending && c->pending_P > 0) ? (size_t)c->pending_P : 0; }
+int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->gsum_external && c->d_gsum) HIP_TRY(c, hipFree(c->d_gsum));
+  c->d_gsum = (double *)device_ptr;
+  c->gsum_cap = device_ptr ? n_doubles : 0;
+  c->gsum_external = device_ptr != nullptr;
+  return CMX_OK;
 }
 
 int cmx_backend_get_plane(cmx_ctx *c, int which, float *host) {

@@ -65,6 +65,7 @@ struct AdjointArgs {
   int W, H, r;
   float taps[2 * kMaxRadius + 1];
   const float *B;          // blurred plane 0 (written by image_moments)
+  const double *partials;  // image_moments' per-tile moments (row 0 = sum B), used when no reduced sums are passed
   int nblk, tiles_x;
   double npix;
   int subtract_mean;       // 1 = variance, 0 = mean square
@@ -75,6 +76,8 @@ struct FeGatherArgs {
   FeSplatArgs ev;          // same event / camera description as the splat
   const float *itilde;
   double *gpartials;       // [nblocks][3]
+  const uint32_t *sxy;     // optional: events in destination-tile order (better LUT / Itilde locality) ...
+  const uint32_t *sbatch;  // ... with their batch indices; null = time order
 };
 
 struct BeGatherArgs {
@@ -95,6 +98,7 @@ struct FinalizeArgs {
   const double *gpartials;
   int gblocks, gP;
   unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
+  int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
 };
 
 struct AlphaArgs {
@@ -110,8 +114,11 @@ struct AlphaArgs {
 constexpr int kBinTile = 32;     // destination tile edge (pixels)
 constexpr int kBinMargin = 16;   // window = tile + margin on every side: 64 x 64 fp32 per plane in LDS
 constexpr int kBinWindow = kBinTile + 2 * kBinMargin;
+constexpr int kBinStride = 67;   // LDS row stride of a window (floats): odd, with stride+-1 poor in factors of 2, so votes along
+                                 // vertical / diagonal edges spread over the 32 LDS banks instead of piling onto one
 
-struct Chunk { int wx0, wy0, beg, end; };  // LDS window origin (pixels) and the sorted-event range; wx0 < -1e8: no window
+struct Chunk { int wx0, wy0, beg, end, plane, pad; };  // LDS window origin (pixels), sorted-event range, target plane
+                                                        // (back end: 0 = IL_old, 1 = IL_new); wx0 < -1e8: no window
 
 struct BinnedEvents {
   const uint32_t *sxy;     // packed events in sorted order
@@ -119,6 +126,7 @@ struct BinnedEvents {
   const Chunk *chunks;
   int nchunks;
   unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
+  int variant;             // debug/ablation bits (CMX_DEBUG_VARIANT): 1 = no votes, 2 = no flush, 4 = no zeroing
 };
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
@@ -141,6 +149,7 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
+void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the number of blocks (rows of gpartials)
 int launch_be_gather(const BeGatherArgs &a, hipStream_t s);

@@ -287,13 +287,32 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   __shared__ double red[4];
   const int t = threadIdx.x;
   const double N = a.npix;
-  const double mu = a.sums[0] / N;
+  double s0, s1;
+  if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
+    double p0 = 0, p1 = 0;
+    for (int b = t; b < a.nblk; b += 256) {
+      p0 += a.partials[b];
+      p1 += a.partials[(size_t)a.nblk + b];
+    }
+    s0 = block_sum(p0, red);
+    s1 = block_sum(p1, red);
+    __syncthreads();
+    if (t == 0) { red[0] = s0; red[1] = s1; }
+    __syncthreads();
+    s0 = red[0];
+    s1 = red[1];
+    __syncthreads();
+  } else {
+    s0 = a.sums[0];
+    s1 = a.sums[1];
+  }
+  const double mu = s0 / N;
   if (t == 0) {
     double c;
     if (a.measure == 1) {
-      c = a.sums[1] / N;
+      c = s1 / N;
     } else {
-      double var = a.sums[1] / N - mu * mu;
+      double var = s1 / N - mu * mu;
       if (var < 0) var = 0;
       const double sd = sqrt(var);
       c = sd * sd;
@@ -318,6 +337,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     s = block_sum(s, red);
     if (t == 0) a.result[2 + k] = 2.0 * s / N;
   }
+}
+
+// per-parameter sum of the gather kernel's block partials -> gsum[P] (the buffer ranks all-reduce)
+__global__ __launch_bounds__(256) void reduce_gpartials_kernel(const double *gpartials, int gblocks, int P, double *gsum) {
+  __shared__ double red[4];
+  const int k = blockIdx.x;
+  double s = 0;
+  for (int b = threadIdx.x; b < gblocks; b += 256) s += gpartials[(size_t)b * P + k];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gsum[k] = s;
+}
+void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(reduce_gpartials_kernel, dim3(P), dim3(256), 0, s, gpartials, gblocks, P, gsum);
 }
 
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s) {
@@ -345,7 +378,22 @@ __global__ __launch_bounds__(kImgThreads) void adjoint_kernel(AdjointArgs a, con
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
   const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
-  const float mu = a.subtract_mean ? (float)(sums[0] / a.npix) : 0.f;
+  float mu = 0.f;
+  if (a.subtract_mean) {
+    if (sums) {
+      mu = (float)(sums[0] / a.npix);
+    } else {  // few tiles: every workgroup sums the per-tile moments itself (saves a launch)
+      double *red = reinterpret_cast<double *>(smem_raw);
+      double p = 0;
+      for (int b = tid; b < a.nblk; b += kImgThreads) p += a.partials[b];
+      const double s = block_sum(p, red);
+      __syncthreads();
+      if (tid == 0) red[0] = s;
+      __syncthreads();
+      mu = (float)(red[0] / a.npix);
+      __syncthreads();
+    }
+  }
   for (int idx = tid; idx < rawW * rawH; idx += kImgThreads) {
     const int ly = idx / rawW, lx = idx - ly * rawW;
     const int gx = x0 + lx - r, gy = y0 + ly - r;
@@ -418,13 +466,41 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   __shared__ double red[4];
   const FeSplatArgs &a = g.ev;
   double acc[3] = {0, 0, 0};
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const FeWarp w = fe_warp_event<true>(a, i);
-    if (w.ok) {
-      float A, B;
-      bilinear_grad(g.itilde, a.W, w.xx, w.yy, w.dx, w.dy, A, B);
+  constexpr int U = 4;  // events in flight per thread (latency-bound gathers)
+  // every workgroup walks ONE contiguous slice of the event list (in tile order that keeps its LUT / Itilde reads local)
+  const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+  const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
+  const int stride = 256;
+  for (int i0 = blk_beg + threadIdx.x; i0 < blk_end; i0 += stride * U) {
+    uint32_t e[U];
+    double dt[U], px[U], py[U], pz[U];
+    bool act[U];
 #pragma unroll
-      for (int k = 0; k < 3; k++) acc[k] += (double)w.r0[k] * (double)A + (double)w.r1[k] * (double)B;
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * stride;
+      act[u] = i < blk_end;
+      if (g.sxy) {
+        e[u] = act[u] ? g.sxy[i] : 0u;
+        dt[u] = act[u] ? a.batch_dt[g.sbatch[i]] : 0.0;
+      } else {
+        e[u] = act[u] ? a.xy[i] : 0u;
+        dt[u] = act[u] ? a.batch_dt[i / a.per_batch] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
+      px[u] = l[0]; py[u] = l[1]; pz[u] = l[2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const FeWarp w = fe_warp_math<true>(a, px[u], py[u], pz[u], dt[u]);
+      if (act[u] && w.ok) {
+        float A, B;
+        bilinear_grad(g.itilde, a.W, w.xx, w.yy, w.dx, w.dy, A, B);
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] += (double)w.r0[k] * (double)A + (double)w.r1[k] * (double)B;
+      }
     }
   }
 #pragma unroll

@@ -25,12 +25,10 @@ struct FeWarp {
   float r0[3], r1[3];
 };
 
+// the arithmetic of the front-end warp on an already-loaded bearing vector (lets callers batch the loads)
 template <bool DERIV>
-__device__ __forceinline__ FeWarp fe_warp_core(const FeSplatArgs &a, uint32_t e, double dt) {
+__device__ __forceinline__ FeWarp fe_warp_math(const FeSplatArgs &a, double px, double py, double pz, double dt) {
   FeWarp w;
-  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
-  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
-  const double px = b[0], py = b[1], pz = b[2];
   // p' = p + (omega*dt) x p   (first-order rotation)
   const double drx = a.wx * dt, dry = a.wy * dt, drz = a.wz * dt;
   const double rx = px + (dry * pz - drz * py);
@@ -60,6 +58,13 @@ __device__ __forceinline__ FeWarp fe_warp_core(const FeSplatArgs &a, uint32_t e,
 }
 
 template <bool DERIV>
+__device__ __forceinline__ FeWarp fe_warp_core(const FeSplatArgs &a, uint32_t e, double dt) {
+  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
+  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
+  return fe_warp_math<DERIV>(a, b[0], b[1], b[2], dt);
+}
+
+template <bool DERIV>
 __device__ __forceinline__ FeWarp fe_warp_event(const FeSplatArgs &a, int i) {
   return fe_warp_core<DERIV>(a, a.xy[i], a.batch_dt[i / a.per_batch]);
 }
@@ -73,19 +78,17 @@ struct BeWarp {
   float m[6];
 };
 
+// the arithmetic of the back-end warp on already-loaded operands: bearing (b0,b1,b2) and the batch rotation R[9]
 template <bool DERIV>
-__device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e, int batch) {
+__device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e, int batch, double b0, double b1,
+                                              double b2, const double *R) {
   BeWarp w;
-  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
   w.is_old = (e >> 31) != 0;
   w.batch = batch;
-  const PoseEntry &pe = a.poses[w.batch];
-  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
-  const double b0 = b[0], b1 = b[1], b2 = b[2];
   // e_ray_w = R * bearing
-  const double x = pe.R[0] * b0 + pe.R[1] * b1 + pe.R[2] * b2;
-  const double y = pe.R[3] * b0 + pe.R[4] * b1 + pe.R[5] * b2;
-  const double z = pe.R[6] * b0 + pe.R[7] * b1 + pe.R[8] * b2;
+  const double x = R[0] * b0 + R[1] * b1 + R[2] * b2;
+  const double y = R[3] * b0 + R[4] * b1 + R[5] * b2;
+  const double z = R[6] * b0 + R[7] * b1 + R[8] * b2;
   // equirectangular projection
   const double phi = atan2(x, z);
   const double rho = sqrt(x * x + y * y + z * z);
@@ -116,6 +119,16 @@ __device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e,
     w.m[5] = d10 * (-rby) + d11 * rbx;
   }
   return w;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e, int batch) {
+  const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
+  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = a.poses[batch].R[k];
+  return be_warp_math<DERIV>(a, e, batch, b[0], b[1], b[2], R);
 }
 
 template <bool DERIV>

@@ -92,8 +92,34 @@ class _Evaluator:
     def accum_count(self):
         return int(self._L.cmx_accum_count(self._ctx))
 
+    def set_grad_buffer(self, device_ptr, n_doubles):
+        self._ck(self._L.cmx_set_grad_buffer(self._ctx, C.c_void_p(device_ptr), int(n_doubles)))
+
+    def grad_count(self):
+        return int(self._L.cmx_grad_count(self._ctx))
+
+    def finish_begin(self, want_grad=True):
+        fn = self._L.cmx_frontend_finish_begin if isinstance(self, FrontendEvaluator) else self._L.cmx_backend_finish_begin
+        self._ck(fn(self._ctx, int(bool(want_grad))))
+
+    def finish_end(self, want_grad=True):
+        fe = isinstance(self, FrontendEvaluator)
+        n = 3 if fe else self.num_params
+        c = C.c_double()
+        g = np.zeros(max(n, 1))
+        fn = self._L.cmx_frontend_finish_end if fe else self._L.cmx_backend_finish_end
+        self._ck(fn(self._ctx, C.byref(c), _dp(g) if want_grad else None))
+        return c.value, (g[:n] if want_grad else None)
+
     def timing_enable(self, on=True):
-        self._ck(self._L.cmx_timing_enable(self._ctx, int(bool(on))))
+        """on: True = all kernel classes, False = off, or an iterable of class names (e.g. ["splat"])."""
+        if on is True:
+            mask = 0x1F
+        elif not on:
+            mask = 0
+        else:
+            mask = sum(1 << _lib.T_NAMES.index(n) for n in on)
+        self._ck(self._L.cmx_timing_enable(self._ctx, mask))
 
     def timing_get(self):
         """{'splat': (ms, launches), ...} accumulated since the last call."""

@@ -151,6 +151,17 @@ int cmx_frontend_accumulate(cmx_ctx *ctx, const double omega[3], int want_grad);
 int cmx_frontend_finish(cmx_ctx *ctx, double *contrast, double *grad);
 int cmx_backend_accumulate(cmx_ctx *ctx, const double *drotv, int want_grad);
 int cmx_backend_finish(cmx_ctx *ctx, double *contrast, double *grad);
+/* With CMX_GRAD_ADJOINT the gradient needs a second, tiny exchange (each rank gathers over its own events from the
+ * common Itilde plane).  finish() = finish_begin() + finish_end(); between the two the rank's partial gradient sums
+ * sit in device memory at cmx_grad_ptr(ctx) [cmx_grad_count(ctx) doubles] for an in-place all-reduce(sum); nothing
+ * is synchronised with the host until finish_end().  cmx_set_grad_buffer makes that buffer caller-owned. */
+int cmx_frontend_finish_begin(cmx_ctx *ctx, int want_grad);
+int cmx_frontend_finish_end(cmx_ctx *ctx, double *contrast, double *grad);
+int cmx_backend_finish_begin(cmx_ctx *ctx, int want_grad);
+int cmx_backend_finish_end(cmx_ctx *ctx, double *contrast, double *grad);
+void *cmx_grad_ptr(const cmx_ctx *ctx);
+size_t cmx_grad_count(const cmx_ctx *ctx);
+int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
 
 /* ------------------------------------------------------------------ optimiser driver (host C++) ----------
  * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors
@@ -178,7 +189,8 @@ int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, in
 
 /* ------------------------------------------------------------------ timing hooks ------------------------
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
- * cmx_timing_enable(ctx,1) makes every evaluation record events around its kernels;
+ * cmx_timing_enable(ctx, mask) makes every evaluation record events around the kernel classes whose bit is set
+ * (bit CMX_T_SPLAT, ...; 0x1f = all, 0 = off);
  * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
 enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COUNT = 5 };
 /* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last

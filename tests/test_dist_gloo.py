@@ -44,7 +44,43 @@ class OracleSplitPhase:
         return po.contrast(blurred[0], blurred[1:] if want_grad else None, 0, want_grad)
 
 
-def _worker(rank, world, port, q):
+class OracleSplitPhaseAdjoint(OracleSplitPhase):
+    """Stand-in with the adjoint flavour's contract: only the I plane is exchanged; finish_begin leaves this rank's
+    partial gradient sums  sum_px blur(D_k of MY events) * (B - mu)  in `gsum`; finish_end scales by 2/N."""
+
+    def __init__(self, po, p, sl, accum, gsum):
+        super().__init__(po, p, sl, accum)
+        self.gsum = gsum
+        self.n_g = 0
+
+    def accumulate(self, om, want_grad):
+        import torch
+        self.om = om
+        self.count = self.np_
+        self.accum[:self.count] = torch.from_numpy(self.fe.iwe(om, blur=False).reshape(-1))
+
+    def finish_begin(self, want_grad):
+        import torch
+        po, p = self.po, self.p
+        B = po.gaussian_blur(self.accum[:self.count].numpy().reshape(p.H, p.W).copy(), p.sigma).astype(np.float64)
+        self.B = B
+        self.n_g = 0
+        if want_grad:
+            _, d = self.fe.iwe(self.om, deriv=True, blur=True)  # blurred derivative images of MY events only
+            z = B - B.mean()
+            self.gsum[:3] = torch.from_numpy(np.array([(d[..., k].astype(np.float64) * z).sum() for k in range(3)]))
+            self.n_g = 3
+
+    def grad_count(self):
+        return self.n_g
+
+    def finish_end(self, want_grad):
+        N = self.B.size
+        c = self.B.var()
+        return c, (2.0 * self.gsum[:3].numpy().copy() / N if want_grad else None)
+
+
+def _worker(rank, world, port, q, adjoint=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -55,7 +91,11 @@ def _worker(rank, world, port, q):
     p = synth.frontend_packet(6_050, 96, 72, 80.0, 80.0, 47.5, 35.5, seed=13)
     beg, end = batch_range(len(p.x), p.batch, rank, world)
     accum = torch.zeros(4 * p.W * p.H, dtype=torch.float32)
-    sh = ShardedEvaluator(OracleSplitPhase(po, p, slice(beg, end), accum), accum)
+    if adjoint:
+        gsum = torch.zeros(8, dtype=torch.float64)
+        sh = ShardedEvaluator(OracleSplitPhaseAdjoint(po, p, slice(beg, end), accum, gsum), accum, gsum)
+    else:
+        sh = ShardedEvaluator(OracleSplitPhase(po, p, slice(beg, end), accum), accum)
     om = (0.5, -0.7, 0.3)
     c, g = sh.eval(om, True)
     c_only, _ = sh.eval(om, False)
@@ -65,7 +105,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_eval_equals_single_process(oracle):
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_sharded_eval_equals_single_process(oracle, adjoint):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -73,7 +114,7 @@ def test_sharded_eval_equals_single_process(oracle):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, adjoint)) for r in range(2)]
     for pr in procs:
         pr.start()
     c, g, c_only, beg, end = q.get(timeout=180)
@@ -88,4 +129,4 @@ def test_sharded_eval_equals_single_process(oracle):
     c_ref, g_ref = ref.eval((0.5, -0.7, 0.3))
     # the only difference is fp32 summation order across the two partial images
     assert abs(c - c_ref) < 1e-6 * abs(c_ref) and abs(c_only - c_ref) < 1e-6 * abs(c_ref)
-    assert np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()
+    assert np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()  # adjoint: two exchanges (I plane, 3 doubles)

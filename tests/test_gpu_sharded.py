@@ -1,0 +1,142 @@
+"""-m gpu: the multi-GPU split-phase path on ONE GPU.
+
+(1) two evaluators, each holding half of the event batches, exchange their partial planes (and, in adjoint mode,
+    their partial gradient sums) through plain tensor adds instead of RCCL -- exactly what the all-reduce would
+    deliver -- and must reproduce the single-evaluator result and the oracle;
+(2) the real ShardedEvaluator over a world_size-1 NCCL(=RCCL) process group: torch-owned accumulation planes,
+    torch stream, in-place all_reduce on the evaluator's buffers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cmax_slam_amd import synth
+from cmax_slam_amd.dist import ShardedEvaluator, attach_torch_accum, batch_range
+from util import RTOL, rel_scalar, rel_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _exchange(torch, bufs, n):
+    tot = bufs[0][:n] + bufs[1][:n]
+    for b in bufs:
+        b[:n] = tot
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_frontend_two_shards_on_one_gpu(hip, oracle, fast):
+    import torch
+    p = synth.frontend_packet(50_050, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=41)
+    dev = torch.device("cuda", 0)
+    evs, accs, gss = [], [], []
+    for r in range(2):
+        beg, end = batch_range(len(p.x), p.batch, r, 2)
+        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        if fast:
+            fe.set_fast_path()
+        fe.set_packet(p.x[beg:end], p.y[beg:end], p.t_ns[beg:end], p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+        acc = torch.zeros(fe.accum_capacity(), dtype=torch.float32, device=dev)
+        gs = torch.zeros(8, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        fe.set_accum_buffer(acc.data_ptr(), acc.numel())
+        fe.set_grad_buffer(gs.data_ptr(), gs.numel())
+        evs.append(fe); accs.append(acc); gss.append(gs)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in ((0.3, -0.5, 0.2), (0.6, -0.9, 0.4)):
+        for want in (True, False):
+            for fe in evs:
+                fe.accumulate(om, want)
+            torch.cuda.synchronize()
+            assert evs[0].accum_count() == evs[1].accum_count()
+            _exchange(torch, accs, evs[0].accum_count())
+            torch.cuda.synchronize()
+            for fe in evs:
+                fe.finish_begin(want)
+            torch.cuda.synchronize()
+            n = evs[0].grad_count()
+            assert n == (3 if (fast and want) else 0)
+            if n:
+                _exchange(torch, gss, n)
+                torch.cuda.synchronize()
+            outs = [fe.finish_end(want) for fe in evs]
+            c_ref, g_ref = ref.eval(om, want)
+            for c, g in outs:
+                assert rel_scalar(c, c_ref) < RTOL
+                if want:
+                    assert rel_vec(g, g_ref) < RTOL
+            assert outs[0][0] == outs[1][0]  # both ranks finish on identical planes: bit-identical contrast
+
+
+def test_backend_two_shards_on_one_gpu(hip, oracle):
+    import torch
+    w = synth.backend_window(40_040, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 10, 3, 0.35, seed=42)
+    dev = torch.device("cuda", 0)
+    for fast in (False, True):
+        evs, accs, gss = [], [], []
+        for r in range(2):
+            beg, end = batch_range(len(w.x), w.batch, r, 2)
+            be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+            if fast:
+                be.set_fast_path()
+            be.set_window(w.x[beg:end], w.y[beg:end], w.t_ns[beg:end], w.order, w.knots_init, w.start_ns, w.dt_ns,
+                          w.num_fixed, w.t_next_win_beg_ns)
+            acc = torch.zeros(be.accum_capacity(), dtype=torch.float32, device=dev)
+            gs = torch.zeros(64, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            be.set_accum_buffer(acc.data_ptr(), acc.numel())
+            be.set_grad_buffer(gs.data_ptr(), gs.numel())
+            evs.append(be); accs.append(acc); gss.append(gs)
+        ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order)
+        ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+        d = np.random.default_rng(3).normal(0, 0.01, w.P)
+        for be in evs:
+            be.accumulate(d, True)
+        torch.cuda.synchronize()
+        _exchange(torch, accs, evs[0].accum_count())
+        torch.cuda.synchronize()
+        for be in evs:
+            be.finish_begin(True)
+        torch.cuda.synchronize()
+        n = evs[0].grad_count()
+        assert n == (w.P if fast else 0)
+        if n:
+            _exchange(torch, gss, n)
+            torch.cuda.synchronize()
+        c_ref, g_ref = ref.eval(d)
+        for be in evs:
+            c, g = be.finish_end(True)
+            assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
+
+
+def test_sharded_evaluator_over_nccl_world1(hip, oracle):
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        p = synth.frontend_packet(30_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=43)
+        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        fe.set_fast_path()
+        fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+        accum, gsum, stream = attach_torch_accum(fe, dev)
+        sh = ShardedEvaluator(fe, accum, gsum, force_collectives=True)
+        ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+        ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+        for om in ((0.3, -0.5, 0.2), (0.1, 0.2, 0.3)):
+            with torch.cuda.stream(stream):
+                c, g = sh.eval(om, True)
+                c0, _ = sh.eval(om, False)
+            c_ref, g_ref = ref.eval(om)
+            assert rel_scalar(c, c_ref) < RTOL and rel_scalar(c0, c_ref) < RTOL
+            assert rel_vec(g, g_ref) < RTOL
+    finally:
+        dist.destroy_process_group()
