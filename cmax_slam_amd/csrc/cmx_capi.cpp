@@ -77,6 +77,8 @@ struct cmx_ctx {
   // adjoint-gradient scratch: blurred plane B, Itilde = G^T(B - mu), per-block gradient partials
   float *d_B = nullptr, *d_itilde = nullptr;
   size_t B_cap = 0, itilde_cap = 0;
+  float *d_cx = nullptr, *d_cy = nullptr;  // G^T 1 = cx(x)*cy(y): column sums of the REFLECT_101 blur operator
+  size_t cx_cap = 0, cy_cap = 0;
   double *d_gpartials = nullptr;
   size_t gpartials_cap = 0;
   double *d_gsum = nullptr;   // this rank's partial gradient sums [P] (caller-owned when external: RCCL reduces it in place)
@@ -177,13 +179,44 @@ double time_to_sec(long long t_ns) {  // ros::Time::toSec
   return (double)(t_ns / 1000000000LL) + 1e-9 * (double)(t_ns % 1000000000LL);
 }
 
+// c1d[q] = (G^T 1)_q for one axis of length L: taps that stay inside + the taps the forward pass reflected back
+// (see adjoint_kernel / image_adjoint_kernel).  1 in the interior; only the outer r pixels differ.
+int upload_gt1(cmx_ctx *c) {
+  const int r = c->radius;
+  for (int axis = 0; axis < 2; axis++) {
+    const int L = axis == 0 ? c->imgW : c->imgH;
+    if (L <= 0) continue;
+    std::vector<float> v((size_t)L);
+    for (int q = 0; q < L; q++) {
+      double s = 0;
+      for (int j = -r; j <= r; j++)
+        if (q - j >= 0 && q - j < L) s += (double)c->taps[r + j];
+      if (L > 2 * r + 1) {
+        if (1 <= q && q <= r)
+          for (int m = 0; m <= r - q; m++) s += (double)c->taps[r + q + m];
+        if (L - 1 - r <= q && q <= L - 2) {
+          const int d = L - 1 - q;
+          for (int m = 0; m <= r - d; m++) s += (double)c->taps[r + d + m];
+        }
+      }
+      v[(size_t)q] = (float)s;
+    }
+    float *&dst = axis == 0 ? c->d_cx : c->d_cy;
+    size_t &cap = axis == 0 ? c->cx_cap : c->cy_cap;
+    int rc = ensure(c, dst, cap, (size_t)L);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return CMX_OK;
+}
+
 // cv::GaussianBlur(Size(0,0), sigma) on CV_32F: ksize = cvRound(sigma*8+1)|1; fp64 kernel normalised, cast to fp32
 int setup_blur(cmx_ctx *c, double sigma) {
   c->sigma = sigma;
   if (!(sigma > 0)) {
     c->radius = 0;
     c->taps[0] = 1.f;
-    return CMX_OK;
+    return upload_gt1(c);
   }
   const int n = ((int)lrint(sigma * 4 * 2 + 1)) | 1;
   const int r = n / 2;
@@ -198,7 +231,7 @@ int setup_blur(cmx_ctx *c, double sigma) {
   sum = 1. / sum;
   for (int i = 0; i < n; i++) c->taps[i] = (float)(t[i] * sum);
   c->radius = r;
-  return CMX_OK;
+  return upload_gt1(c);
 }
 
 // ---- timing helpers
@@ -400,17 +433,6 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
   return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
 }
 
-// cost-only evaluation in adjoint mode: keep the blurred plane so that a df at the same point only needs the
-// adjoint blur + gather (GSL's conjugate_fr evaluates f then df at every accepted point)
-float *store_B(cmx_ctx *c, bool with_planes_grad) {
-  c->B_valid = false;
-  if (with_planes_grad || !c->reuse_image || !adjoint_ok(c) || c->accum_external) return nullptr;
-  const size_t np = (size_t)c->imgW * c->imgH;
-  if (ensure(c, c->d_B, c->B_cap, np) != CMX_OK) return nullptr;
-  c->B_valid = true;
-  return c->d_B;
-}
-
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -469,43 +491,42 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
 }
 
 
-// adjoint gradient: image pass (keeps the blurred plane B) -> sums -> Itilde = G^T(B - mu) -> gather over the
-// events -> finalize (contrast from the moments, gradient = (2/N) * sum of the gather partials)
-int run_adjoint(cmx_ctx *c, int P, bool reuse, int phase = 0) {
+// adjoint gradient: fused image pass (B = G*A with its moments, Jt = G^T B^) -> gather over the events (S1, and S2 for
+// the votes next to the border) -> finalize: contrast from the moments, grad = (2/N)(S1 - mu*S2).
+// phase 0 = everything; 1 = up to the per-rank partial sums (d_gsum, 2P doubles); 2 = finalize from d_gsum.
+int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   const int W = c->imgW, H = c->imgH;
   const size_t np = (size_t)W * H;
-  int rc = ensure(c, c->d_B, c->B_cap, np);
+  int rc = ensure(c, c->d_itilde, c->itilde_cap, np);
   if (rc) return rc;
-  rc = ensure(c, c->d_itilde, c->itilde_cap, np);
-  if (rc) return rc;
-  ImgArgs a{};
+  ImgAdjArgs ia{};
+  ImgArgs &a = ia.img;
   a.W = W; a.H = H; a.r = c->radius;
   memcpy(a.taps, c->taps, sizeof(a.taps));
-  if (c->kind == KIND_FE) {
-    a.src_a = c->d_accum;
-  } else {
-    a.src_a = c->d_accum;
+  a.src_a = c->d_accum;
+  if (c->kind == KIND_BE) {
     a.src_b = c->d_accum + np;
     a.igp = c->ig_nonzero ? c->d_IGp : nullptr;
     a.alpha = c->d_alpha;
   }
   a.P = 0;
-  a.out_blur0 = c->d_B;
   a.tiles_x = (W + kTileX - 1) / kTileX;
   a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  ia.jt = c->d_itilde;
   rc = ensure(c, c->d_partials, c->partials_cap, (size_t)2 * a.nblk);
   if (rc) return rc;
   rc = ensure(c, c->d_sums, c->sums_cap, 2);
   if (rc) return rc;
   const int gb = gather_blocks(c->n_packed);
-  rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * (P > 0 ? P : 1));
+  const int P2 = 2 * (P > 0 ? P : 1);
+  rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * P2);
   if (rc) return rc;
-  if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
+  if (2 + (size_t)P > c->result_cap - 2) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
   if (!c->gsum_external) {
-    rc = ensure(c, c->d_gsum, c->gsum_cap, (size_t)(P > 0 ? P : 1));
+    rc = ensure(c, c->d_gsum, c->gsum_cap, (size_t)P2);
     if (rc) return rc;
-  } else if ((size_t)P > c->gsum_cap) {
-    return fail(c, CMX_ERR_INVALID_ARG, "external gradient buffer too small: %zu < %d doubles", c->gsum_cap, P);
+  } else if ((size_t)P2 > c->gsum_cap) {
+    return fail(c, CMX_ERR_INVALID_ARG, "external gradient buffer too small: %zu < %d doubles", c->gsum_cap, P2);
   }
   a.partials = c->d_partials;
   FinalizeArgs f{};
@@ -516,8 +537,9 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse, int phase = 0) {
   f.partials = c->d_partials;
   f.sums = c->d_sums;
   f.result = c->d_result;
-  const bool direct = a.nblk <= 2048;  // few tiles: fold the moment reduction into the adjoint / finalize kernels
+  const bool direct = a.nblk <= 2048;  // few tiles: finalize sums the per-tile moments itself
   f.direct = direct ? 1 : 0;
+  f.mu_free = 1;
   if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
     f.gpartials = c->d_gpartials;
     f.gblocks = gb;
@@ -534,22 +556,8 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse, int phase = 0) {
   }
   {
     Span sp(c, CMX_T_IMAGE);
-    if (!reuse) {
-      launch_image_moments(a, c->stream);
-      if (!direct) launch_reduce_partials(f, c->stream);
-    }
-    c->B_valid = true;
-    AdjointArgs ad{};
-    ad.W = W; ad.H = H; ad.r = c->radius;
-    memcpy(ad.taps, c->taps, sizeof(ad.taps));
-    ad.B = c->d_B;
-    ad.partials = c->d_partials;
-    ad.nblk = a.nblk;
-    ad.tiles_x = a.tiles_x;
-    ad.npix = (double)np;
-    ad.subtract_mean = (c->measure == CMX_MEAN_SQUARE) ? 0 : 1;
-    ad.out = c->d_itilde;
-    launch_adjoint(ad, direct ? nullptr : c->d_sums, c->stream);
+    launch_image_adjoint(ia, c->stream);
+    if (!direct) launch_reduce_partials(f, c->stream);
   }
   {
     Span sp(c, CMX_T_GATHER);
@@ -558,22 +566,24 @@ int run_adjoint(cmx_ctx *c, int P, bool reuse, int phase = 0) {
       g.ev = fe_args(c, c->last_x);
       g.itilde = c->d_itilde;
       g.gpartials = c->d_gpartials;
+      g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
       if (c->splat_mode == 1 && c->bin_valid) {  // tile order: the same sorted arrays the LDS splat consumes
         g.sxy = c->d_sxy;
         g.sbatch = c->d_sbatch;
       }
       if (c->n_packed > 0) launch_fe_gather(g, c->stream);
-      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P * sizeof(double), c->stream));
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     } else {
       BeGatherArgs g{};
       g.ev = be_args(c);
       g.itilde = c->d_itilde;
       g.P = P;
       g.gpartials = c->d_gpartials;
+      g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
       if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->stream);
-      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * (P > 0 ? P : 1) * sizeof(double), c->stream));
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }
-    if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, P, c->d_gsum, c->stream);
+    if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
   }
   if (phase == 1) {
     HIP_TRY(c, hipGetLastError());
@@ -656,6 +666,8 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_fallback);
   hipFree(c->d_B);
   hipFree(c->d_itilde);
+  hipFree(c->d_cx);
+  hipFree(c->d_cy);
   hipFree(c->d_gpartials);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
@@ -861,8 +873,8 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
     return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
   int rc = bind(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, 3, c->B_valid);
-  else rc = run_image_and_finalize(c, grad ? 3 : 0, store_B(c, grad != nullptr), nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
+  else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;
@@ -872,7 +884,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 static bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) {
-  if (!want_grad || !c->reuse_image || !c->have_data || !c->accumulated || !c->x_valid || !c->B_valid) return false;
+  if (!want_grad || !c->reuse_image || !c->have_data || !c->accumulated || !c->x_valid) return false;
   if (!adjoint_ok(c) || c->accum_external) return false;
   return memcmp(x, c->last_x, sizeof(double) * (size_t)n) == 0;
 }
@@ -1119,8 +1131,8 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (rc) return rc;
   rc = be_first_iter(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, P, c->B_valid);
-  else rc = run_image_and_finalize(c, grad ? P : 0, store_B(c, grad != nullptr), nullptr);
+  if (grad && c->last_adjoint) rc = run_adjoint(c, P);
+  else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c);
   if (rc) return rc;
@@ -1153,7 +1165,7 @@ static int finish_begin(cmx_ctx *c, int kind, int want_grad) {
     if (rc) return rc;
   }
   if (want_grad && c->last_adjoint) {
-    rc = run_adjoint(c, P, false, 1);
+    rc = run_adjoint(c, P, 1);
     c->pending_P = P;
   } else {
     if (want_grad && c->last_P != P) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
@@ -1172,7 +1184,7 @@ static int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad) {
   if (rc) return rc;
   const int P = (kind == KIND_FE) ? 3 : 3 * (c->K - c->num_fixed);
   if (c->pending_P >= 0) {
-    rc = run_adjoint(c, c->pending_P, false, 2);
+    rc = run_adjoint(c, c->pending_P, 2);
     if (rc) return rc;
   }
   c->finish_pending = false;
@@ -1187,7 +1199,7 @@ int cmx_frontend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return
 int cmx_backend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_BE, want_grad); }
 int cmx_backend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_BE, contrast, grad); }
 void *cmx_grad_ptr(const cmx_ctx *c) { return c ? c->d_gsum : nullptr; }
-size_t cmx_grad_count(const cmx_ctx *c) { return (c && c->finish_pending && c->pending_P > 0) ? (size_t)c->pending_P : 0; }
+size_t cmx_grad_count(const cmx_ctx *c) { return (c && c->finish_pending && c->pending_P > 0) ? (size_t)(2 * c->pending_P) : 0; }
 int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
   if (!c) return CMX_ERR_INVALID_ARG;
   int rc = bind(c);

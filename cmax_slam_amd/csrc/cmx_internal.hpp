@@ -72,12 +72,25 @@ struct AdjointArgs {
   float *out;              // Itilde
 };
 
+// fused image pass of the adjoint gradient: B = G*A (moments of B), Jt = G^T B^ in ONE kernel.
+// G^T(B - mu) = G^T B - mu*c with c = G^T 1 = cx(x)*cy(y) (1 in the interior, differs only within r of the border), and the
+// bilinear-derivative weights sum to zero, so the mu term only matters for votes next to the border: the gather
+// accumulates it separately (S2) and finalize applies  grad = (2/N) (S1 - mu*S2).
+struct ImgAdjArgs {
+  ImgArgs img;      // composition + taps + partials (rows 0,1) ; P / dplanes / out_blurd unused
+  float *jt;        // out: G^T B^  (W*H)
+};
+size_t image_adjoint_lds_bytes(int r);
+void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s);
+
 struct FeGatherArgs {
   FeSplatArgs ev;          // same event / camera description as the splat
   const float *itilde;
   double *gpartials;       // [nblocks][3]
   const uint32_t *sxy;     // optional: events in destination-tile order (better LUT / Itilde locality) ...
   const uint32_t *sbatch;  // ... with their batch indices; null = time order
+  const float *cx, *cy;    // G^T 1 factors (W and H floats) when itilde holds G^T B (mu-free form); null: itilde = G^T(B-mu)
+  int r;                   // blur radius (defines the border band where cx, cy differ from 1)
 };
 
 struct BeGatherArgs {
@@ -85,7 +98,9 @@ struct BeGatherArgs {
   const float *itilde;
   int P;                   // 3 * (K - num_fixed)
   int chunk;               // events per workgroup iteration (multiple of 256)
-  double *gpartials;       // [nblocks][P]
+  double *gpartials;       // [nblocks][P]  (mu-free form: [nblocks][2P], S1 then S2)
+  const float *cx, *cy;    // as in FeGatherArgs
+  int r;
 };
 
 struct FinalizeArgs {
@@ -99,6 +114,7 @@ struct FinalizeArgs {
   int gblocks, gP;
   unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
   int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
+  int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
 };
 
 struct AlphaArgs {

@@ -178,9 +178,14 @@ size_t image_lds_bytes(int r) {
 // LDS: raw tile with halo -> row-blurred tile -> column pass in registers -> fp64 moments.
 // Row pass:  s = k[0]*S[x-r]; s += k[j]*S[x-r+j]           (generic row filter order)
 // Col pass:  s = k[r]*T[y];   s += k[r+j]*(T[y+j]+T[y-j])  (symmetric column filter order)
+template <int R>  // R >= 0: compile-time radius (loops unroll, taps live in registers, index maths is constant); -1: a.r
 __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int r = a.r, W = a.W, H = a.H;
+  const int r = (R >= 0) ? R : a.r;
+  const int W = a.W, H = a.H;
+  float taps[2 * kMaxRadius + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * kMaxRadius + 1; j++) taps[j] = (R < 0 || j <= 2 * R) ? a.taps[j] : 0.f;
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
   double *red = reinterpret_cast<double *>(smem_raw);
   float *raw = reinterpret_cast<float *>(smem_raw + 4 * sizeof(double));
@@ -221,8 +226,9 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
     for (int idx = tid; idx < kTileX * rawH; idx += kImgThreads) {
       const int ly = idx >> 6, lx = idx & 63;
       const float *S = raw + ly * rawW + lx;
-      float s = a.taps[0] * S[0];
-      for (int j = 1; j <= 2 * r; j++) s += a.taps[j] * S[j];
+      float s = taps[0] * S[0];
+#pragma unroll
+      for (int j = 1; j <= 2 * r; j++) s += taps[j] * S[j];
       rowb[idx] = s;
     }
     __syncthreads();
@@ -231,8 +237,9 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
     for (int j = 0; j < 4; j++) {
       const int ly = tq * 4 + j + r;
       const float *T = rowb + ly * kTileX + tx;
-      float s = a.taps[r] * T[0];
-      for (int t = 1; t <= r; t++) s += a.taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
+      float s = taps[r] * T[0];
+#pragma unroll
+      for (int t = 1; t <= r; t++) s += taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
       if (valid[j]) {
         const size_t o = (size_t)(y0 + tq * 4 + j) * W + (x0 + tx);
         if (k < 0) {
@@ -267,7 +274,8 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
 
 void launch_image_moments(const ImgArgs &a, hipStream_t s) {
   const int groups = a.P > 0 ? (a.P + kPlaneGroup - 1) / kPlaneGroup : 1;
-  hipLaunchKernelGGL(image_moments_kernel, dim3(a.nblk, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
+  if (a.r == 4) hipLaunchKernelGGL(image_moments_kernel<4>, dim3(a.nblk, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
+  else hipLaunchKernelGGL(image_moments_kernel<-1>, dim3(a.nblk, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
 }
 
 // ---------------------------------------------------------------------------------------------- reduce + finalize
@@ -331,11 +339,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     a.result[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
   }
   // adjoint mode: grad_k = (2/N) * sum_events <dW_k, Itilde>: block-parallel sum over the gather kernel's partials
+  const int gstride = a.mu_free ? 2 * a.gP : a.gP;
   for (int k = 0; k < a.gP; k++) {
-    double s = 0;
-    for (int b = t; b < a.gblocks; b += 256) s += a.gpartials[(size_t)b * a.gP + k];
+    double s = 0, s2 = 0;
+    for (int b = t; b < a.gblocks; b += 256) {
+      s += a.gpartials[(size_t)b * gstride + k];
+      if (a.mu_free) s2 += a.gpartials[(size_t)b * gstride + a.gP + k];
+    }
     s = block_sum(s, red);
-    if (t == 0) a.result[2 + k] = 2.0 * s / N;
+    if (a.mu_free) s2 = block_sum(s2, red);
+    if (t == 0) a.result[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
   }
 }
 
@@ -445,6 +458,136 @@ void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s) {
   hipLaunchKernelGGL(adjoint_kernel, dim3(a.nblk), dim3(kImgThreads), image_lds_bytes(a.r), s, a, sums);
 }
 
+// ---------------------------------------------------------------------------------------------- fused image + adjoint
+// One workgroup = one 64x16 tile of Jt = G^T B^.  It needs B on the tile + r halo, hence the raw image on the tile +
+// 2r halo; the moments of B are taken over the tile's own pixels only, so every pixel is counted once.
+size_t image_adjoint_lds_bytes(int r) {
+  const size_t aw = kTileX + 4 * r, ah = kTileY + 4 * r, bw = kTileX + 2 * r, bh = kTileY + 2 * r;
+  return sizeof(double) * 16 + sizeof(float) * (aw * ah + bw * ah + bw * bh + (size_t)kTileX * bh);
+}
+
+constexpr int kAdjThreads = 1024;  // 16 waves per tile: the phases are LDS-latency bound, more waves per SIMD hide it
+
+// block-wide sum for kAdjThreads threads; result valid in every thread.  red: 16 doubles of LDS.
+__device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0;
+  for (int w = 0; w < nwaves; w++) s += red[w];
+  return s;
+}
+
+template <int R>
+__global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const ImgArgs &a = g.img;
+  const int r = (R >= 0) ? R : a.r;
+  const int W = a.W, H = a.H;
+  float taps[2 * kMaxRadius + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * kMaxRadius + 1; j++) taps[j] = (R < 0 || j <= 2 * R) ? a.taps[j] : 0.f;
+  const int aw = kTileX + 4 * r, ah = kTileY + 4 * r, bw = kTileX + 2 * r, bh = kTileY + 2 * r;
+  double *red = reinterpret_cast<double *>(smem_raw);
+  float *bufA = reinterpret_cast<float *>(smem_raw + 16 * sizeof(double));  // raw, aw x ah
+  float *bufR = bufA + aw * ah;                                            // row-blurred raw, bw x ah
+  float *bufB = bufR + bw * ah;                                            // B^ (0 outside the image), bw x bh
+  float *bufT = bufB + bw * bh;                                            // row pass of G^T, kTileX x bh
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
+  const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
+
+  for (int idx = tid; idx < aw * ah; idx += kAdjThreads) {
+    const int ly = idx / aw, lx = idx - ly * aw;
+    const int gx = reflect101(x0 + lx - 2 * r, W), gy = reflect101(y0 + ly - 2 * r, H);
+    const size_t off = (size_t)gy * W + gx;
+    float v = a.src_a[off];
+    if (a.src_b) v = v + a.src_b[off];
+    if (a.igp) v = a.igp[off] * alpha + v;
+    bufA[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < bw * ah; idx += kAdjThreads) {  // forward row pass (same op order as image_moments)
+    const int ly = idx / bw, lx = idx - ly * bw;
+    const float *S = bufA + ly * aw + lx;
+    float s = taps[0] * S[0];
+#pragma unroll
+    for (int j = 1; j <= 2 * r; j++) s += taps[j] * S[j];
+    bufR[idx] = s;
+  }
+  __syncthreads();
+  double sI = 0, sII = 0;
+  for (int idx = tid; idx < bw * bh; idx += kAdjThreads) {  // forward column pass -> B on tile + r halo
+    const int ly = idx / bw, lx = idx - ly * bw;
+    const float *T = bufR + (ly + r) * bw + lx;
+    float s = taps[r] * T[0];
+#pragma unroll
+    for (int t = 1; t <= r; t++) s += taps[r + t] * (T[t * bw] + T[-t * bw]);
+    const int gx = x0 + lx - r, gy = y0 + ly - r;
+    const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+    bufB[idx] = inside ? s : 0.f;
+    if (inside && lx >= r && lx < r + kTileX && ly >= r && ly < r + kTileY) {
+      sI += (double)s;
+      sII += (double)s * (double)s;
+      if (a.out_blur0) a.out_blur0[(size_t)gy * W + gx] = s;
+    }
+  }
+  {
+    const double t0 = block_sum_n(sI, red, kAdjThreads / 64), t1 = block_sum_n(sII, red, kAdjThreads / 64);
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + tile] = t0;
+      a.partials[(size_t)1 * a.nblk + tile] = t1;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kTileX * bh; idx += kAdjThreads) {  // G^T row pass: zero-padded conv + folded reflections
+    const int ly = idx >> 6, lx = idx & 63;
+    const float *S = bufB + ly * bw + lx;
+    float s = taps[0] * S[0];
+#pragma unroll
+    for (int j = 1; j <= 2 * r; j++) s += taps[j] * S[j];
+    const int gx = x0 + lx;
+    const float *Srow = bufB + ly * bw;  // column of global x is (x - x0 + r)
+    if (1 <= gx && gx <= r)
+      for (int m = 0; m <= r - gx; m++) s += taps[r + gx + m] * Srow[m - x0 + r];
+    if (W - 1 - r <= gx && gx <= W - 2) {
+      const int d = W - 1 - gx;
+      for (int m = 0; m <= r - d; m++) s += taps[r + d + m] * Srow[(W - 1 - m) - x0 + r];
+    }
+    bufT[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kTileX * kTileY; idx += kAdjThreads) {
+    const int tx = idx & 63, ty = idx >> 6;
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gx < W && gy < H) {
+      const int ly = ty + r;
+      const float *T = bufT + ly * kTileX + tx;
+      float s = taps[r] * T[0];
+#pragma unroll
+      for (int t = 1; t <= r; t++) s += taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
+      const float *Tcol = bufT + tx;  // row of global y is (y - y0 + r)
+      if (1 <= gy && gy <= r)
+        for (int m = 0; m <= r - gy; m++) s += taps[r + gy + m] * Tcol[(m - y0 + r) * kTileX];
+      if (H - 1 - r <= gy && gy <= H - 2) {
+        const int d = H - 1 - gy;
+        for (int m = 0; m <= r - d; m++) s += taps[r + d + m] * Tcol[((H - 1 - m) - y0 + r) * kTileX];
+      }
+      g.jt[(size_t)gy * W + gx] = s;
+    }
+  }
+}
+
+void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s) {
+  if (a.img.r == 4)
+    hipLaunchKernelGGL(image_adjoint_kernel<4>, dim3(a.img.nblk), dim3(kAdjThreads), image_adjoint_lds_bytes(4), s, a);
+  else
+    hipLaunchKernelGGL(image_adjoint_kernel<-1>, dim3(a.img.nblk), dim3(kAdjThreads), image_adjoint_lds_bytes(a.img.r), s, a);
+}
+
 // ---------------------------------------------------------------------------------------------- gather passes
 // d(contrast)/d(theta_k) = (2/N) sum_events [ r0_k * dItilde/dx(at the event) + r1_k * dItilde/dy ] where the
 // bilinear-interpolation derivatives are exactly the signed-weight sums the reference scatters into its derivative
@@ -456,6 +599,18 @@ __device__ __forceinline__ void bilinear_grad(const float *it, int W, int xx, in
   B = (1.f - dx) * (i10 - i00) + dx * (i11 - i01);
 }
 
+// the same two directional derivatives of the separable plane c(x,y) = cx[x]*cy[y] (= G^T 1); zero away from the border
+__device__ __forceinline__ void border_grad(const float *cx, const float *cy, int W, int H, int r, int xx, int yy, float dx,
+                                            float dy, float &A, float &B) {
+  A = 0.f;
+  B = 0.f;
+  if (xx <= r || xx + 1 >= W - 1 - r || yy <= r || yy + 1 >= H - 1 - r) {
+    const float c00 = cx[xx] * cy[yy], c01 = cx[xx + 1] * cy[yy], c10 = cx[xx] * cy[yy + 1], c11 = cx[xx + 1] * cy[yy + 1];
+    A = (1.f - dy) * (c01 - c00) + dy * (c11 - c10);
+    B = (1.f - dx) * (c10 - c00) + dx * (c11 - c01);
+  }
+}
+
 int gather_blocks(int n) {
   int blocks = (n + 255) / 256;
   const int cap = 768;  // 3 workgroups per CU
@@ -465,7 +620,7 @@ int gather_blocks(int n) {
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   __shared__ double red[4];
   const FeSplatArgs &a = g.ev;
-  double acc[3] = {0, 0, 0};
+  double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
   constexpr int U = 4;  // events in flight per thread (latency-bound gathers)
   // every workgroup walks ONE contiguous slice of the event list (in tile order that keeps its LUT / Itilde reads local)
   const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
@@ -500,13 +655,29 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
         bilinear_grad(g.itilde, a.W, w.xx, w.yy, w.dx, w.dy, A, B);
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[k] += (double)w.r0[k] * (double)A + (double)w.r1[k] * (double)B;
+        if (g.cx) {
+          float Ac, Bc;
+          border_grad(g.cx, g.cy, a.W, a.H, g.r, w.xx, w.yy, w.dx, w.dy, Ac, Bc);
+          if (Ac != 0.f || Bc != 0.f) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc2[k] += (double)w.r0[k] * (double)Ac + (double)w.r1[k] * (double)Bc;
+          }
+        }
       }
     }
   }
+  const int stride_out = g.cx ? 6 : 3;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const double t = block_sum(acc[k], red);
-    if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * 3 + k] = t;
+    if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * stride_out + k] = t;
+  }
+  if (g.cx) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double t = block_sum(acc2[k], red);
+      if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * stride_out + 3 + k] = t;
+    }
   }
 }
 
@@ -526,9 +697,10 @@ template <int N>
 __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
   __shared__ double shV[kMaxSlots * 3];
   __shared__ double shG[kMaxGradLDS];
+  __shared__ double shG2[kMaxGradLDS];  // border (mu) term: only the rare votes within r of the panorama border add to it
   const BeSplatArgs &a = g.ev;
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int j = tid; j < g.P; j += 256) shG[j] = 0;
+  for (int j = tid; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
   for (int j = tid; j < kMaxSlots * 3; j += 256) shV[j] = 0;
   __syncthreads();
   for (int base = blockIdx.x * 256; base < a.n; base += gridDim.x * 256) {
@@ -545,6 +717,22 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
         V0 = (double)A * (double)w.m[0] + (double)B * (double)w.m[3];
         V1 = (double)A * (double)w.m[1] + (double)B * (double)w.m[4];
         V2 = (double)A * (double)w.m[2] + (double)B * (double)w.m[5];
+        if (g.cx) {
+          float Ac, Bc;
+          border_grad(g.cx, g.cy, a.Wp, a.Hp, g.r, w.xx, w.yy, w.dx, w.dy, Ac, Bc);
+          if (Ac != 0.f || Bc != 0.f) {  // rare: straight to the block accumulators, no per-batch staging
+            const PoseEntry &pe = a.poses[w.batch];
+            const double u0 = (double)Ac * (double)w.m[0] + (double)Bc * (double)w.m[3];
+            const double u1 = (double)Ac * (double)w.m[1] + (double)Bc * (double)w.m[4];
+            const double u2 = (double)Ac * (double)w.m[2] + (double)Bc * (double)w.m[5];
+            const int jb = 3 * (pe.idx_cp_beg - a.num_fixed);
+            for (int c = 0; c < 3 * N; c++) {
+              const int j = jb + c;
+              if (j >= 0)
+                atomicAdd(&shG2[j], u0 * (double)pe.Jcp[c] + u1 * (double)pe.Jcp[3 * N + c] + u2 * (double)pe.Jcp[6 * N + c]);
+            }
+          }
+        }
       }
     }
     // segmented reduction over contiguous runs of equal batch id inside the wave
@@ -578,7 +766,11 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
     }
     __syncthreads();
   }
-  for (int j = tid; j < g.P; j += 256) g.gpartials[(size_t)blockIdx.x * g.P + j] = shG[j];
+  const int stride_out = g.cx ? 2 * g.P : g.P;
+  for (int j = tid; j < g.P; j += 256) {
+    g.gpartials[(size_t)blockIdx.x * stride_out + j] = shG[j];
+    if (g.cx) g.gpartials[(size_t)blockIdx.x * stride_out + g.P + j] = shG2[j];
+  }
 }
 
 int launch_be_gather(const BeGatherArgs &a, hipStream_t s) {

@@ -56,7 +56,7 @@ def test_frontend_two_shards_on_one_gpu(hip, oracle, fast):
                 fe.finish_begin(want)
             torch.cuda.synchronize()
             n = evs[0].grad_count()
-            assert n == (3 if (fast and want) else 0)
+            assert n == (6 if (fast and want) else 0)  # S1 and S2 (border term) per parameter
             if n:
                 _exchange(torch, gss, n)
                 torch.cuda.synchronize()
@@ -100,7 +100,7 @@ def test_backend_two_shards_on_one_gpu(hip, oracle):
             be.finish_begin(True)
         torch.cuda.synchronize()
         n = evs[0].grad_count()
-        assert n == (w.P if fast else 0)
+        assert n == (2 * w.P if fast else 0)
         if n:
             _exchange(torch, gss, n)
             torch.cuda.synchronize()
