@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     for (int u = 0; u < U; u++) {
       const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
       b0[u] = l[0]; b1[u] = l[1]; b2[u] = l[2];
-      const double *Rp = a.poses[bi[u]].R;
+      const double *Rp = a.poseR[bi[u]].R;
 #pragma unroll
       for (int k = 0; k < 9; k++) R[u][k] = Rp[k];
     }

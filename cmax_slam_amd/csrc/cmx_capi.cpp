@@ -57,7 +57,8 @@ struct cmx_ctx {
   int Wp = 0, Hp = 0, order = 0, K = 0, num_fixed = 0;
   long long *d_batch_t = nullptr;
   PoseEntry *d_poses = nullptr;
-  size_t batch_t_cap = 0, poses_cap = 0;
+  PoseR *d_poseR = nullptr;
+  size_t batch_t_cap = 0, poses_cap = 0, poseR_cap = 0;
   SplineArgs *d_spline = nullptr, *h_spline = nullptr;  // h_spline: pinned staging
   std::vector<Quat> knots0;
   float *d_IG = nullptr, *d_IGp = nullptr;
@@ -68,6 +69,12 @@ struct cmx_ctx {
   int imgW = 0, imgH = 0;  // W,H (front end) or Wp,Hp (back end)
   float *d_accum = nullptr;
   size_t accum_cap = 0, accum_count = 0;
+  // ping-pong partner of d_accum (fast path, context-owned memory only): the image kernel of evaluation k clears the
+  // buffer evaluation k-1 used, so evaluation k+1 splats into it without a memset launch
+  float *d_accum_alt = nullptr;
+  size_t accum_alt_cap = 0;
+  bool accum_clean = false, alt_clean = false;  // buffer known to be all-zero over the planes the fast path uses
+  int pingpong_planes = 0;                     // planes being ping-ponged by the pending evaluation (0 = off)
   bool accum_external = false;
   float *d_scratch = nullptr;  // blurred-plane readback scratch
   size_t scratch_cap = 0;
@@ -302,6 +309,47 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   return CMX_OK;
 }
 
+int ensure_accum(cmx_ctx *c, size_t need);
+
+// Fast path: swap to the partner buffer if it is known clean, otherwise clear the current one.  After this call
+// c->d_accum is all-zero over `nplanes` planes and c->pingpong_planes tells the image pass to clear the partner.
+int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast) {
+  c->pingpong_planes = 0;
+  const size_t need = (size_t)nplanes * np;
+  if (fast && !c->accum_external) {
+    float *before = c->d_accum;
+    int rc = ensure(c, c->d_accum, c->accum_cap, need);
+    if (rc) return rc;
+    if (c->d_accum != before) c->accum_clean = false;  // fresh allocation: contents undefined
+    if (c->accum_alt_cap < need || !c->d_accum_alt) {
+      rc = ensure(c, c->d_accum_alt, c->accum_alt_cap, c->accum_cap > need ? c->accum_cap : need);
+      if (rc) return rc;
+      c->alt_clean = false;
+    }
+    if (c->alt_clean) {
+      std::swap(c->d_accum, c->d_accum_alt);
+      std::swap(c->accum_cap, c->accum_alt_cap);
+      std::swap(c->accum_clean, c->alt_clean);
+    }
+    if (!c->accum_clean) {
+      Span sp(c, CMX_T_ZERO);
+      HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
+    }
+    c->accum_clean = false;  // about to be written
+    c->alt_clean = false;    // holds the previous evaluation's planes until this evaluation's image pass clears it
+    c->pingpong_planes = nplanes;
+    return CMX_OK;
+  }
+  int rc = ensure_accum(c, need);
+  if (rc) return rc;
+  {
+    Span sp(c, CMX_T_ZERO);
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
+  }
+  c->accum_clean = false;
+  return CMX_OK;
+}
+
 int ensure_accum(cmx_ctx *c, size_t need) {
   if (c->accum_external) {
     if (need > c->accum_cap)
@@ -423,6 +471,7 @@ BeSplatArgs be_args(const cmx_ctx *c) {
   a.order = c->order;
   a.num_fixed = c->num_fixed;
   a.xy = c->d_xy;
+  a.poseR = c->d_poseR;
   a.poses = c->d_poses;
   a.lut = c->d_lut;
   a.planes = c->d_accum;
@@ -458,6 +507,11 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   a.P = P;
   a.out_blur0 = out_blur0;
   a.out_blurd = out_blurd;
+  if (c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+    a.zero_ptr = c->d_accum_alt;
+    a.zero_planes = c->pingpong_planes;
+    c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs
+  }
   a.tiles_x = (W + kTileX - 1) / kTileX;
   a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
   const size_t nq = 2 + 2 * (size_t)P;
@@ -512,6 +566,11 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   a.P = 0;
   a.tiles_x = (W + kTileX - 1) / kTileX;
   a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  if (phase != 2 && c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+    a.zero_ptr = c->d_accum_alt;
+    a.zero_planes = c->pingpong_planes;
+    c->alt_clean = true;
+  }
   ia.jt = c->d_itilde;
   rc = ensure(c, c->d_partials, c->partials_cap, (size_t)2 * a.nblk);
   if (rc) return rc;
@@ -650,12 +709,14 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_batch_dt);
   hipFree(c->d_batch_t);
   hipFree(c->d_poses);
+  hipFree(c->d_poseR);
   hipFree(c->d_spline);
   if (c->h_spline) hipHostFree(c->h_spline);
   hipFree(c->d_IG);
   hipFree(c->d_IGp);
   hipFree(c->d_alpha);
   if (!c->accum_external) hipFree(c->d_accum);
+  hipFree(c->d_accum_alt);
   hipFree(c->d_scratch);
   hipFree(c->d_partials);
   hipFree(c->d_sums);
@@ -826,12 +887,8 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
 
 static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   const size_t np = (size_t)c->W * c->H;
-  int rc = ensure_accum(c, nplanes * np);
+  int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);
   if (rc) return rc;
-  {
-    Span sp(c, CMX_T_ZERO);
-    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, nplanes * np * sizeof(float), c->stream));
-  }
   FeSplatArgs a = fe_args(c, omega);
   for (int k = 0; k < 3; k++) c->last_x[k] = omega[k];
   const bool use_lds = c->splat_mode == 1 && nplanes == 1 && c->n_packed > 0;
@@ -1011,6 +1068,8 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (rc) return rc;
   rc = ensure(c, c->d_poses, c->poses_cap, (size_t)nb);
   if (rc) return rc;
+  rc = ensure(c, c->d_poseR, c->poseR_cap, (size_t)nb);
+  if (rc) return rc;
   if (!xy.empty()) HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
   const size_t np = (size_t)c->Wp * c->Hp;
@@ -1040,8 +1099,7 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   c->last_adjoint = want_grad && adjoint_ok(c);
   const bool deriv = want_grad && !c->last_adjoint;
   const int P = deriv ? 3 * Kopt : 0;
-  int rc = ensure_accum(c, (size_t)(2 + P) * np);
-  if (rc) return rc;
+  int rc = CMX_OK;
   // knot_i <- exp(drot_i) * knot_i for the non-fixed knots (CopyAndIncrementalUpdate, trajectory.cpp:240-263)
   for (int i = 0; i < c->K; i++) {
     Quat q = c->knots0[i];
@@ -1054,13 +1112,11 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   HIP_TRY(c, hipMemcpyAsync(c->d_spline, c->h_spline, sizeof(SplineArgs), hipMemcpyHostToDevice, c->stream));
   {
     Span sp(c, CMX_T_POSE);
-    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poses,
+    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poseR, c->d_poses,
                          c->stream);
   }
-  {
-    Span sp(c, CMX_T_ZERO);
-    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)(2 + P) * np * sizeof(float), c->stream));
-  }
+  rc = begin_accum(c, 2 + P, np, P == 0 && adjoint_ok(c) && c->splat_mode == 1);
+  if (rc) return rc;
   BeSplatArgs a = be_args(c);
   const bool use_lds = c->splat_mode == 1 && !deriv && c->n_packed > 0;
   if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {

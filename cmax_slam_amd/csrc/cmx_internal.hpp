@@ -25,8 +25,11 @@ struct FeSplatArgs {
   float *planes;           // [1 + 3][H][W]: IWE, dI/dwx, dI/dwy, dI/dwz
 };
 
-struct PoseEntry {  // per event batch, written by the pose-table kernel
-  double R[9];      // so3.matrix(), row-major
+// per event batch, written by the pose-table kernel.  The rotation lives in its own dense table (72 B per batch):
+// the tile-ordered splat reads it at random batch indices, and 3.6 MB for 50k batches stays L2-resident where the
+// 216-byte combined record did not (238 MB fetched per 5M-event launch, profiles/r01c_be_fastpath.txt).
+struct PoseR { double R[9]; };  // so3.matrix(), row-major
+struct PoseEntry {
   float Jcp[36];    // ddrot_ddrot_cp, 3 x 3n row-major (n<=4)
   int idx_cp_beg;
   int pad;
@@ -40,6 +43,7 @@ struct BeSplatArgs {
   int order;      // 2 / 4
   int num_fixed;
   const uint32_t *xy;
+  const PoseR *poseR;
   const PoseEntry *poses;
   const double *lut;
   float *planes;  // [2 + P][Hp][Wp]: IL_old, IL_new, derivative planes
@@ -58,6 +62,8 @@ struct ImgArgs {
   double *partials;     // [2 + 2P][nblk]
   int nblk;             // tiles in x*y
   int tiles_x;
+  float *zero_ptr;      // optional: the OTHER accumulation buffer (previous evaluation's planes); every workgroup clears
+  int zero_planes;      // its own tile there, so the next evaluation needs no memset launch (ping-pong accumulation)
 };
 
 // adjoint pass:  Itilde = G^T (B - mu)   with B the blurred image, G the REFLECT_101 separable Gaussian
@@ -158,7 +164,7 @@ void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_
 
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_be_pose_table(const SplineArgs *d_spline, const long long *d_batch_t, int nb, int order, bool want_j,
-                          PoseEntry *out, hipStream_t s);
+                          PoseR *outR, PoseEntry *out, hipStream_t s);
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);

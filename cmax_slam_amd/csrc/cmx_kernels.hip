@@ -62,7 +62,7 @@ void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------- K0
 template <int N, bool WANT_J>
 __global__ __launch_bounds__(64) void be_pose_table_kernel(const SplineArgs *sp, const long long *batch_t, int nb,
-                                                           PoseEntry *out) {
+                                                           PoseR *outR, PoseEntry *out) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nb) return;
   Mat3 R, J[N];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void be_pose_table_kernel(const SplineArgs *sp,
   spline_eval<N, WANT_J>(*sp, batch_t[b], R, J, idx);
   PoseEntry &o = out[b];
 #pragma unroll
-  for (int i = 0; i < 9; i++) o.R[i] = R.m[i];
+  for (int i = 0; i < 9; i++) outR[b].R[i] = R.m[i];
   o.idx_cp_beg = idx;
   if (WANT_J) {
     // 3 x 3N fp32, block k at columns 3k..3k+2  (Trajectory::evaluate copies d_val_d_knot[k] as float)
@@ -84,15 +84,15 @@ __global__ __launch_bounds__(64) void be_pose_table_kernel(const SplineArgs *sp,
 }
 
 void launch_be_pose_table(const SplineArgs *d_spline, const long long *d_batch_t, int nb, int order, bool want_j,
-                          PoseEntry *out, hipStream_t s) {
+                          PoseR *outR, PoseEntry *out, hipStream_t s) {
   if (nb <= 0) return;
   const dim3 g((nb + 63) / 64), b(64);
   if (order == 2) {
-    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<2, true>), g, b, 0, s, d_spline, d_batch_t, nb, out);
-    else hipLaunchKernelGGL((be_pose_table_kernel<2, false>), g, b, 0, s, d_spline, d_batch_t, nb, out);
+    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<2, true>), g, b, 0, s, d_spline, d_batch_t, nb, outR, out);
+    else hipLaunchKernelGGL((be_pose_table_kernel<2, false>), g, b, 0, s, d_spline, d_batch_t, nb, outR, out);
   } else {
-    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<4, true>), g, b, 0, s, d_spline, d_batch_t, nb, out);
-    else hipLaunchKernelGGL((be_pose_table_kernel<4, false>), g, b, 0, s, d_spline, d_batch_t, nb, out);
+    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<4, true>), g, b, 0, s, d_spline, d_batch_t, nb, outR, out);
+    else hipLaunchKernelGGL((be_pose_table_kernel<4, false>), g, b, 0, s, d_spline, d_batch_t, nb, outR, out);
   }
 }
 
@@ -204,6 +204,12 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   bool valid[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) valid[j] = (x0 + tx < W) && (y0 + tq * 4 + j < H);
+  if (a.zero_ptr && g == 0) {  // clear this tile of the other accumulation buffer (nobody reads it during this launch)
+    for (int pl = 0; pl < a.zero_planes; pl++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (valid[j]) a.zero_ptr[(size_t)pl * np + (size_t)(y0 + tq * 4 + j) * W + (x0 + tx)] = 0.f;
+  }
 
   // pass over plane 0 (k == -1) then the group's derivative planes
   for (int k = -1; k < k_end; k = (k < 0 ? k_beg : k + 1)) {
@@ -291,29 +297,35 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(FinalizeArgs a) {
 // contrast / gradient from the moments (fp64):
 //   variance:     contrast = (sqrt(max(E[I^2]-mu^2,0)))^2 ; grad_k = 2*(E[I D_k] - mu*E[D_k])
 //   mean square:  contrast = E[I^2]                        ; grad_k = 2*E[I D_k]
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-  __shared__ double red[4];
-  const int t = threadIdx.x;
+// One workgroup of 16 waves.  Waves 0/1 reduce the image moments; then every wave reduces whole parameters on its
+// own (wave-shuffle sums over coalesced rows of the [column][block] partial tables): no workgroup barriers in the
+// per-parameter loop.
+__global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
+  __shared__ double sh[2];
+  __shared__ double shp[16];
+  __shared__ double outv[2 + 3 * kMaxKnots];  // results are staged here and written to the mapped host buffer by ONE
+                                              // wave, contiguously: scattered lane writes over PCIe cost ~0.5 us each
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const double N = a.npix;
-  double s0, s1;
   if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
-    double p0 = 0, p1 = 0;
-    for (int b = t; b < a.nblk; b += 256) {
-      p0 += a.partials[b];
-      p1 += a.partials[(size_t)a.nblk + b];
+    // this is ONE workgroup reading tables other CUs just wrote (L2-remote): keep many independent loads in flight
+    const int row = wave & 1, part = wave >> 1;  // 8 waves per row
+    double p = 0;
+    const double *src = a.partials + (size_t)row * a.nblk;
+    for (int b = part * 64 + lane; b < a.nblk; b += 8 * 64) p += src[b];
+    p = wave_sum(p);
+    if (lane == 0) shp[wave] = p;
+    __syncthreads();
+    if (t < 2) {
+      double s = 0;
+      for (int w = 0; w < 8; w++) s += shp[2 * w + t];
+      sh[t] = s;
     }
-    s0 = block_sum(p0, red);
-    s1 = block_sum(p1, red);
-    __syncthreads();
-    if (t == 0) { red[0] = s0; red[1] = s1; }
-    __syncthreads();
-    s0 = red[0];
-    s1 = red[1];
-    __syncthreads();
-  } else {
-    s0 = a.sums[0];
-    s1 = a.sums[1];
+  } else if (t < 2) {
+    sh[t] = a.sums[t];
   }
+  __syncthreads();
+  const double s0 = sh[0], s1 = sh[1];
   const double mu = s0 / N;
   if (t == 0) {
     double c;
@@ -325,8 +337,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       const double sd = sqrt(var);
       c = sd * sd;
     }
-    a.result[0] = c;
-    a.result[1] = mu;
+    outv[0] = c;
+    outv[1] = mu;
     if (a.fallback) {
       a.result[4094] = (double)(*a.fallback);
       *a.fallback = 0u;
@@ -334,22 +346,35 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       a.result[4094] = 0.0;
     }
   }
-  for (int k = t; k < a.P; k += blockDim.x) {
+  // derivative-plane mode: moments of the P blurred planes were reduced into sums[] by reduce_partials
+  for (int k = t; k < a.P; k += 1024) {
     const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
-    a.result[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
+    outv[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
   }
-  // adjoint mode: grad_k = (2/N) * sum_events <dW_k, Itilde>: block-parallel sum over the gather kernel's partials
-  const int gstride = a.mu_free ? 2 * a.gP : a.gP;
-  for (int k = 0; k < a.gP; k++) {
+  // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP)
+  for (int k = wave; k < a.gP; k += 16) {
     double s = 0, s2 = 0;
-    for (int b = t; b < a.gblocks; b += 256) {
-      s += a.gpartials[(size_t)b * gstride + k];
-      if (a.mu_free) s2 += a.gpartials[(size_t)b * gstride + a.gP + k];
+    const double *r1 = a.gpartials + (size_t)k * a.gblocks;
+    const double *r2 = a.gpartials + (size_t)(a.gP + k) * a.gblocks;
+    int b = lane;
+    for (; b + 192 < a.gblocks; b += 256) {  // 4 (x2) independent loads per lane in flight
+      const double v0 = r1[b], v1 = r1[b + 64], v2 = r1[b + 128], v3 = r1[b + 192];
+      double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      if (a.mu_free) { w0 = r2[b]; w1 = r2[b + 64]; w2 = r2[b + 128]; w3 = r2[b + 192]; }
+      s += (v0 + v1) + (v2 + v3);
+      s2 += (w0 + w1) + (w2 + w3);
     }
-    s = block_sum(s, red);
-    if (a.mu_free) s2 = block_sum(s2, red);
-    if (t == 0) a.result[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
+    for (; b < a.gblocks; b += 64) {
+      s += r1[b];
+      if (a.mu_free) s2 += r2[b];
+    }
+    s = wave_sum(s);
+    s2 = wave_sum(s2);
+    if (lane == 0) outv[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
   }
+  __syncthreads();
+  const int nout = 2 + (a.P > a.gP ? a.P : a.gP);
+  if (t < nout) a.result[t] = outv[t];
 }
 
 // per-parameter sum of the gather kernel's block partials -> gsum[P] (the buffer ranks all-reduce)
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(256) void reduce_gpartials_kernel(const double *gpa
   __shared__ double red[4];
   const int k = blockIdx.x;
   double s = 0;
-  for (int b = threadIdx.x; b < gblocks; b += 256) s += gpartials[(size_t)b * P + k];
+  for (int b = threadIdx.x; b < gblocks; b += 256) s += gpartials[(size_t)k * gblocks + b];
   s = block_sum(s, red);
   if (threadIdx.x == 0) gsum[k] = s;
 }
@@ -370,7 +395,7 @@ void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 + 2 * a.P), dim3(256), 0, s, a);
 }
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, a);
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
   launch_reduce_partials(a, s);
@@ -499,6 +524,13 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
   const int tile = blockIdx.x;
   const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
+  if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
+    for (int idx = tid; idx < kTileX * kTileY * a.zero_planes; idx += kAdjThreads) {
+      const int pl = idx / (kTileX * kTileY), q = idx - pl * (kTileX * kTileY);
+      const int gx = x0 + (q & 63), gy = y0 + (q >> 6);
+      if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
+    }
+  }
 
   for (int idx = tid; idx < aw * ah; idx += kAdjThreads) {
     const int ly = idx / aw, lx = idx - ly * aw;
@@ -613,7 +645,7 @@ __device__ __forceinline__ void border_grad(const float *cx, const float *cy, in
 
 int gather_blocks(int n) {
   int blocks = (n + 255) / 256;
-  const int cap = 768;  // 3 workgroups per CU
+  const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~130 VGPRs: 3 blocks/CU is its occupancy)
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
@@ -666,17 +698,17 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
       }
     }
   }
-  const int stride_out = g.cx ? 6 : 3;
+  // partial table layout: [column][block], columns = S1 (3) then S2 (3)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const double t = block_sum(acc[k], red);
-    if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * stride_out + k] = t;
+    if (threadIdx.x == 0) g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = t;
   }
   if (g.cx) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const double t = block_sum(acc2[k], red);
-      if (threadIdx.x == 0) g.gpartials[(size_t)blockIdx.x * stride_out + 3 + k] = t;
+      if (threadIdx.x == 0) g.gpartials[(size_t)(3 + k) * gridDim.x + blockIdx.x] = t;
     }
   }
 }
@@ -766,10 +798,9 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
     }
     __syncthreads();
   }
-  const int stride_out = g.cx ? 2 * g.P : g.P;
-  for (int j = tid; j < g.P; j += 256) {
-    g.gpartials[(size_t)blockIdx.x * stride_out + j] = shG[j];
-    if (g.cx) g.gpartials[(size_t)blockIdx.x * stride_out + g.P + j] = shG2[j];
+  for (int j = tid; j < g.P; j += 256) {  // [column][block]
+    g.gpartials[(size_t)j * gridDim.x + blockIdx.x] = shG[j];
+    if (g.cx) g.gpartials[(size_t)(g.P + j) * gridDim.x + blockIdx.x] = shG2[j];
   }
 }
 

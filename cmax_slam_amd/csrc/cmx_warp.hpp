@@ -127,7 +127,7 @@ __device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e,
   const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
   double R[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = a.poses[batch].R[k];
+  for (int k = 0; k < 9; k++) R[k] = a.poseR[batch].R[k];
   return be_warp_math<DERIV>(a, e, batch, b[0], b[1], b[2], R);
 }
 
