@@ -44,6 +44,11 @@ SYMBOLS = {
     "cmx_backend_eval": (C.c_int, [ctx_p, c_dp, c_dp, c_dp]),
     "cmx_backend_get_plane": (C.c_int, [ctx_p, C.c_int, c_fp]),
     "cmx_backend_get_alpha": (C.c_int, [ctx_p, c_dp]),
+    "cmx_backend_update_map": (C.c_int, [ctx_p, C.c_int]),
+    "cmx_backend_mark_visited": (C.c_int, [ctx_p, c_dp, C.c_int]),
+    "cmx_backend_reset_map": (C.c_int, [ctx_p]),
+    "cmx_backend_get_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
+    "cmx_backend_set_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
     "cmx_traj_temp_start_ns": (C.c_int64, [C.c_double, C.c_int, C.c_double]),
     "cmx_accum_capacity": (C.c_size_t, [ctx_p]),
     "cmx_set_accum_buffer": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),

@@ -62,6 +62,7 @@ struct cmx_ctx {
   SplineArgs *d_spline = nullptr, *h_spline = nullptr;  // h_spline: pinned staging
   std::vector<Quat> knots0;
   float *d_IG = nullptr, *d_IGp = nullptr;
+  unsigned char *d_visits = nullptr, *d_mask = nullptr;  // IG_update_times_map_ and the per-pose scratch mask
   bool ig_nonzero = false, first_iter = true;
   double *d_alpha = nullptr;
 
@@ -81,9 +82,9 @@ struct cmx_ctx {
   int last_P = 0;              // derivative planes produced by the last accumulate()
   bool accumulated = false;
 
-  // adjoint-gradient scratch: blurred plane B, Itilde = G^T(B - mu), per-block gradient partials
-  float *d_B = nullptr, *d_itilde = nullptr;
-  size_t B_cap = 0, itilde_cap = 0;
+  // adjoint-gradient scratch: Jt plane, per-block gradient partials
+  float *d_itilde = nullptr;  // Jt = G^T (G I)
+  size_t itilde_cap = 0;
   float *d_cx = nullptr, *d_cy = nullptr;  // G^T 1 = cx(x)*cy(y): column sums of the REFLECT_101 blur operator
   size_t cx_cap = 0, cy_cap = 0;
   double *d_gpartials = nullptr;
@@ -95,7 +96,6 @@ struct cmx_ctx {
   int pending_P = 0;
   bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
-  bool B_valid = false;       // d_B / d_sums hold the blurred image + moments of that accumulation
   int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
   int64_t reuse_hits = 0;
   double last_x[3 * kMaxKnots] = {0};  // parameters of the last accumulate (the gather pass re-warps the events)
@@ -713,6 +713,8 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_spline);
   if (c->h_spline) hipHostFree(c->h_spline);
   hipFree(c->d_IG);
+  hipFree(c->d_visits);
+  hipFree(c->d_mask);
   hipFree(c->d_IGp);
   hipFree(c->d_alpha);
   if (!c->accum_external) hipFree(c->d_accum);
@@ -725,7 +727,6 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tile_start);
   hipFree(c->d_chunks);
   hipFree(c->d_fallback);
-  hipFree(c->d_B);
   hipFree(c->d_itilde);
   hipFree(c->d_cx);
   hipFree(c->d_cy);
@@ -750,7 +751,6 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_REUSE_IMAGE:
       c->reuse_image = value != 0;
-      c->B_valid = false;
       return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
@@ -843,7 +843,6 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   c->have_data = false;
   c->accumulated = false;
   c->x_valid = false;
-  c->B_valid = false;
   if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
   if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
     return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d is not implemented on the GPU (variance / mean-square only)",
@@ -908,7 +907,6 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->last_P = nplanes - 1;
   c->accumulated = true;
   c->x_valid = true;
-  c->B_valid = false;
   return CMX_OK;
 }
 
@@ -999,6 +997,10 @@ int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lu
   HIP_TRY(c, hipMalloc((void **)&c->d_IGp, np * sizeof(float)));
   HIP_TRY(c, hipMemset(c->d_IG, 0, np * sizeof(float)));
   HIP_TRY(c, hipMemset(c->d_IGp, 0, np * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_visits, np));
+  HIP_TRY(c, hipMalloc((void **)&c->d_mask, np));
+  HIP_TRY(c, hipMemset(c->d_visits, 0, np));
+  HIP_TRY(c, hipMemset(c->d_mask, 0, np));
   HIP_TRY(c, hipMalloc((void **)&c->d_alpha, sizeof(double)));
   HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
   HIP_TRY(c, hipMalloc((void **)&c->d_spline, sizeof(SplineArgs)));
@@ -1016,7 +1018,6 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   c->have_data = false;
   c->accumulated = false;
   c->x_valid = false;
-  c->B_valid = false;
   if (order != 2 && order != 4) return fail(c, CMX_ERR_INVALID_ARG, "spline order %d unsupported (2 = linear, 4 = cubic)", order);
   if (K < order || K > kMaxKnots) return fail(c, CMX_ERR_INVALID_ARG, "K=%d outside [%d, %d]", K, order, kMaxKnots);
   if (num_fixed < 0 || num_fixed > K) return fail(c, CMX_ERR_INVALID_ARG, "num_fixed=%d outside [0, K]", num_fixed);
@@ -1073,7 +1074,9 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (!xy.empty()) HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
   const size_t np = (size_t)c->Wp * c->Hp;
-  if (IG) {
+  if (IG == CMX_KEEP_MAP) {
+    c->ig_nonzero = true;  // resident map: contents unknown to the host; the alpha kernel counts the non-zeros itself
+  } else if (IG) {
     HIP_TRY(c, hipMemcpy(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice));
     c->ig_nonzero = false;
     for (size_t i = 0; i < np; i++)
@@ -1135,7 +1138,6 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   c->last_P = P;
   c->accumulated = true;
   c->x_valid = true;
-  c->B_valid = false;
   for (int k = 0; k < 3 * Kopt && k < 3 * kMaxKnots; k++) c->last_x[k] = drotv[k];
   return CMX_OK;
 }
@@ -1265,6 +1267,60 @@ int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
   c->d_gsum = (double *)device_ptr;
   c->gsum_cap = device_ptr ? n_doubles : 0;
   c->gsum_external = device_ptr != nullptr;
+  return CMX_OK;
+}
+
+// ---- global-map upkeep on the device: IG and the visit counts stay resident
+int cmx_backend_update_map(cmx_ctx *c, int max_update_times) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "no evaluation has run in this window (IL_old undefined)");
+  int rc = bind(c);
+  if (rc) return rc;
+  launch_update_map(c->d_IG, c->d_accum, c->d_visits, c->Wp * c->Hp, max_update_times, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CMX_OK;
+}
+int cmx_backend_mark_visited(cmx_ctx *c, const double q[4], int radius) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!q || radius < 0 || radius > 64) return fail(c, CMX_ERR_INVALID_ARG, "bad pose / radius");
+  int rc = bind(c);
+  if (rc) return rc;
+  const Mat3 R = q_to_R(Quat{q[0], q[1], q[2], q[3]});
+  launch_mark_visited(be_args(c), R.m, c->H, radius, c->d_mask, c->d_visits, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return CMX_OK;
+}
+int cmx_backend_reset_map(cmx_ctx *c) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  int rc = bind(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->Wp * c->Hp;
+  HIP_TRY(c, hipMemsetAsync(c->d_IG, 0, np * sizeof(float), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_visits, 0, np, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->ig_nonzero = false;
+  return CMX_OK;
+}
+int cmx_backend_get_map(cmx_ctx *c, float *IG, unsigned char *visits) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  int rc = bind(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->Wp * c->Hp;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (IG) HIP_TRY(c, hipMemcpy(IG, c->d_IG, np * sizeof(float), hipMemcpyDeviceToHost));
+  if (visits) HIP_TRY(c, hipMemcpy(visits, c->d_visits, np, hipMemcpyDeviceToHost));
+  return CMX_OK;
+}
+int cmx_backend_set_map(cmx_ctx *c, const float *IG, const unsigned char *visits) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  int rc = bind(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->Wp * c->Hp;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (IG) HIP_TRY(c, hipMemcpy(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice));
+  if (visits) HIP_TRY(c, hipMemcpy(c->d_visits, visits, np, hipMemcpyHostToDevice));
   return CMX_OK;
 }
 

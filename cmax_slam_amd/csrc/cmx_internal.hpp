@@ -66,18 +66,6 @@ struct ImgArgs {
   int zero_planes;      // its own tile there, so the next evaluation needs no memset launch (ping-pong accumulation)
 };
 
-// adjoint pass:  Itilde = G^T (B - mu)   with B the blurred image, G the REFLECT_101 separable Gaussian
-struct AdjointArgs {
-  int W, H, r;
-  float taps[2 * kMaxRadius + 1];
-  const float *B;          // blurred plane 0 (written by image_moments)
-  const double *partials;  // image_moments' per-tile moments (row 0 = sum B), used when no reduced sums are passed
-  int nblk, tiles_x;
-  double npix;
-  int subtract_mean;       // 1 = variance, 0 = mean square
-  float *out;              // Itilde
-};
-
 // fused image pass of the adjoint gradient: B = G*A (moments of B), Jt = G^T B^ in ONE kernel.
 // G^T(B - mu) = G^T B - mu*c with c = G^T 1 = cx(x)*cy(y) (1 in the interior, differs only within r of the border), and the
 // bilinear-derivative weights sum to zero, so the mu term only matters for votes next to the border: the gather
@@ -169,13 +157,17 @@ void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
-void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the number of blocks (rows of gpartials)
 int launch_be_gather(const BeGatherArgs &a, hipStream_t s);
 int gather_blocks(int n);
+// global-map upkeep (once per window)
+void launch_update_map(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_update_times,
+                       hipStream_t s);
+void launch_mark_visited(const BeSplatArgs &cam, const double R[9], int sensor_h, int radius, unsigned char *mask,
+                         unsigned char *visits, hipStream_t s);
 void launch_interleave3(const float *planes, float *out, int npix, hipStream_t s);
 size_t image_lds_bytes(int r);
 

@@ -8,6 +8,7 @@
 //                                                            (reference event_pano_warper.cpp:199-230,
 //                                                             local_focus_funcs.cpp:9-44, global_focus_funcs.cpp:11-47)
 //   alpha_*         K4  event-density ratio alpha            (reference event_pano_warper.cpp:134-165)
+//   image_adjoint   fused blur + moments + G^T (adjoint gradient), fe/be_gather: gradient by gathering over the events
 //   reduce/finalize     partial moments -> contrast, gradient (fp64)
 //
 // Numerics: geometry in fp64 exactly as the reference, weights/accumulators fp32.  This file is compiled with
@@ -402,87 +403,6 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
   launch_finalize_only(a, s);
 }
 
-// ---------------------------------------------------------------------------------------------- adjoint blur
-// Itilde = G^T (B - mu):  the transpose of the REFLECT_101 separable Gaussian = zero-padded convolution plus the
-// taps that the forward pass reflected across the border, folded back onto the pixels they came from:
-//   (Gx^T b)_q = sum_j g_j b^(q-j)  +  [1<=q<=r] sum_{m=0}^{r-q} g_{q+m} b_m  +  [W-1-r<=q<=W-2] sum_m g_{(W-1-q)+m} b_{W-1-m}
-// (b^ = b inside the image, 0 outside; needs W,H > 2r).
-__global__ __launch_bounds__(kImgThreads) void adjoint_kernel(AdjointArgs a, const double *sums) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int r = a.r, W = a.W, H = a.H;
-  const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
-  float *raw = reinterpret_cast<float *>(smem_raw + 4 * sizeof(double));
-  float *rowb = raw + rawW * rawH;
-  const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
-  float mu = 0.f;
-  if (a.subtract_mean) {
-    if (sums) {
-      mu = (float)(sums[0] / a.npix);
-    } else {  // few tiles: every workgroup sums the per-tile moments itself (saves a launch)
-      double *red = reinterpret_cast<double *>(smem_raw);
-      double p = 0;
-      for (int b = tid; b < a.nblk; b += kImgThreads) p += a.partials[b];
-      const double s = block_sum(p, red);
-      __syncthreads();
-      if (tid == 0) red[0] = s;
-      __syncthreads();
-      mu = (float)(red[0] / a.npix);
-      __syncthreads();
-    }
-  }
-  for (int idx = tid; idx < rawW * rawH; idx += kImgThreads) {
-    const int ly = idx / rawW, lx = idx - ly * rawW;
-    const int gx = x0 + lx - r, gy = y0 + ly - r;
-    float v = 0.f;
-    if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = a.B[(size_t)gy * W + gx] - mu;
-    raw[idx] = v;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < kTileX * rawH; idx += kImgThreads) {
-    const int ly = idx >> 6, lx = idx & 63;
-    const float *S = raw + ly * rawW + lx;
-    float s = a.taps[0] * S[0];
-    for (int j = 1; j <= 2 * r; j++) s += a.taps[j] * S[j];
-    const int gx = x0 + lx;
-    const float *Srow = raw + ly * rawW;  // raw column of global x is (x - x0 + r)
-    if (1 <= gx && gx <= r) {
-      for (int m = 0; m <= r - gx; m++) s += a.taps[r + gx + m] * Srow[m - x0 + r];
-    }
-    if (W - 1 - r <= gx && gx <= W - 2) {
-      const int d = W - 1 - gx;
-      for (int m = 0; m <= r - d; m++) s += a.taps[r + d + m] * Srow[(W - 1 - m) - x0 + r];
-    }
-    rowb[idx] = s;
-  }
-  __syncthreads();
-  const int tx = tid & 63, tq = tid >> 6;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int gy = y0 + tq * 4 + j, gx = x0 + tx;
-    if (gx < W && gy < H) {
-      const int ly = tq * 4 + j + r;
-      const float *T = rowb + ly * kTileX + tx;
-      float s = a.taps[r] * T[0];
-      for (int t = 1; t <= r; t++) s += a.taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
-      const float *Tcol = rowb + tx;  // rowb row of global y is (y - y0 + r)
-      if (1 <= gy && gy <= r) {
-        for (int m = 0; m <= r - gy; m++) s += a.taps[r + gy + m] * Tcol[(m - y0 + r) * kTileX];
-      }
-      if (H - 1 - r <= gy && gy <= H - 2) {
-        const int d = H - 1 - gy;
-        for (int m = 0; m <= r - d; m++) s += a.taps[r + d + m] * Tcol[((H - 1 - m) - y0 + r) * kTileX];
-      }
-      a.out[(size_t)gy * W + gx] = s;
-    }
-  }
-}
-
-void launch_adjoint(const AdjointArgs &a, const double *sums, hipStream_t s) {
-  hipLaunchKernelGGL(adjoint_kernel, dim3(a.nblk), dim3(kImgThreads), image_lds_bytes(a.r), s, a, sums);
-}
-
 // ---------------------------------------------------------------------------------------------- fused image + adjoint
 // One workgroup = one 64x16 tile of Jt = G^T B^.  It needs B on the tile + r halo, hence the raw image on the tile +
 // 2r halo; the moments of B are taken over the tile's own pixels only, so every pixel is counted once.
@@ -848,6 +768,53 @@ __global__ __launch_bounds__(256) void alpha_finalize_kernel(AlphaArgs a) {
 void launch_alpha(const AlphaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(alpha_partials_kernel, dim3(a.nblk), dim3(256), 0, s, a);
   hipLaunchKernelGGL(alpha_finalize_kernel, dim3(1), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------- map upkeep
+// EventWarper::updateIG (event_pano_warper.cpp:109-126): IG += IL_old where the visit count is <= max_update_times
+__global__ void update_map_kernel(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_t) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
+    if ((int)visits[i] <= max_t) IG[i] += IL_old[i];
+}
+void launch_update_map(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_update_times,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(update_map_kernel, dim3(2048), dim3(256), 0, s, IG, IL_old, visits, npix, max_update_times);
+}
+
+// EventWarper::setUpdateTimesIG (event_pano_warper.cpp:81-107): warp every sensor pixel with one pose, mark the
+// (2r+1)^2 neighbourhood of the hit cell (the reference's row test is `0 <= y_mask + j`; rows < 0, which the
+// reference would write out of bounds, are skipped), then visits = saturate_u8(visits + mask).
+struct RotArg { double R[9]; };
+__global__ void mark_mask_kernel(BeSplatArgs a, RotArg rot, int sensor_h, int radius, unsigned char *mask) {
+  const int npx = a.W * sensor_h;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const double *b = a.lut + 3 * (size_t)i;
+    const double x = rot.R[0] * b[0] + rot.R[1] * b[1] + rot.R[2] * b[2];
+    const double y = rot.R[3] * b[0] + rot.R[4] * b[1] + rot.R[5] * b[2];
+    const double z = rot.R[6] * b[0] + rot.R[7] * b[1] + rot.R[8] * b[2];
+    const double phi = atan2(x, z);
+    const double theta = asin(y / sqrt(x * x + y * y + z * z));
+    const int ic = (int)(a.cxp + phi * a.fx), ir = (int)(a.cyp + theta * a.fy);
+    for (int di = -radius; di <= radius; di++)
+      for (int dj = -radius; dj <= radius; dj++) {
+        const int xm = ic + di, ym = ir + dj;
+        if (0 <= ym + dj && ym < a.Hp && 0 <= xm && xm < a.Wp && ym >= 0) mask[(size_t)ym * a.Wp + xm] = 1;
+      }
+  }
+}
+__global__ void add_mask_kernel(unsigned char *visits, unsigned char *mask, int npix) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+    const int v = (int)visits[i] + (int)mask[i];
+    visits[i] = (unsigned char)(v > 255 ? 255 : v);
+    mask[i] = 0;
+  }
+}
+void launch_mark_visited(const BeSplatArgs &cam, const double R[9], int sensor_h, int radius, unsigned char *mask,
+                         unsigned char *visits, hipStream_t s) {
+  RotArg rot;
+  for (int i = 0; i < 9; i++) rot.R[i] = R[i];
+  hipLaunchKernelGGL(mark_mask_kernel, dim3(1024), dim3(256), 0, s, cam, rot, sensor_h, radius, mask);
+  hipLaunchKernelGGL(add_mask_kernel, dim3(2048), dim3(256), 0, s, visits, mask, cam.Wp * cam.Hp);
 }
 
 // planar [3][npix] -> interleaved [npix][3]  (CV_32FC3 layout of the reference's derivative image)

@@ -12,10 +12,6 @@ namespace cmx {
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// LDS fp32 atomic add (ds_add_f32)
-__device__ __forceinline__ void lds_add_f32(float *p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // per-event front-end warp: fp64 first-order rotation + pinhole; fp32 bilinear offsets; optional 2x3 Jacobian rows
 struct FeWarp {

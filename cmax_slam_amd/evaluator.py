@@ -218,7 +218,8 @@ class BackendEvaluator(_Evaluator):
             raise ValueError("x, y, t_ns must have equal length")
         k = _c(knots_xyzw, np.float64).reshape(-1, 4)
         ig = None
-        if IG is not None:
+        keep = isinstance(IG, str) and IG == "resident"  # CMX_KEEP_MAP: use the device-resident global map
+        if IG is not None and not keep:
             ig = _c(IG, np.float32)
             if ig.size != self.Wp * self.Hp:
                 raise ValueError("IG must be Hp x Wp")
@@ -226,7 +227,7 @@ class BackendEvaluator(_Evaluator):
             self._ctx, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p), t.ctypes.data_as(c_i64p),
             int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns),
             int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
-            ig.ctypes.data_as(c_fp) if ig is not None else None))
+            C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
         self.K, self.num_fixed = k.shape[0], int(num_fixed)
 
     def eval(self, drotv, want_grad=True):
@@ -258,6 +259,30 @@ class BackendEvaluator(_Evaluator):
         a = C.c_double()
         self._ck(self._L.cmx_backend_get_alpha(self._ctx, C.byref(a)))
         return a.value
+
+    # --- global-map upkeep (EventWarper::updateIG / setUpdateTimesIG / resetIG), device-resident
+    def updateIG(self, max_update_times):
+        self._ck(self._L.cmx_backend_update_map(self._ctx, int(max_update_times)))
+
+    def setUpdateTimesIG(self, quat_xyzw, radius=3):
+        q = _c(quat_xyzw, np.float64)
+        self._ck(self._L.cmx_backend_mark_visited(self._ctx, _dp(q), int(radius)))
+
+    def resetIG(self):
+        self._ck(self._L.cmx_backend_reset_map(self._ctx))
+
+    def getIG(self, with_visits=False):
+        ig = np.empty((self.Hp, self.Wp), np.float32)
+        v = np.empty((self.Hp, self.Wp), np.uint8) if with_visits else None
+        self._ck(self._L.cmx_backend_get_map(self._ctx, ig.ctypes.data_as(c_fp),
+                                             v.ctypes.data_as(C.POINTER(C.c_uint8)) if with_visits else None))
+        return (ig, v) if with_visits else ig
+
+    def setIG(self, IG=None, visits=None):
+        ig = _c(IG, np.float32) if IG is not None else None
+        v = _c(visits, np.uint8) if visits is not None else None
+        self._ck(self._L.cmx_backend_set_map(self._ctx, ig.ctypes.data_as(c_fp) if ig is not None else None,
+                                             v.ctypes.data_as(C.POINTER(C.c_uint8)) if v is not None else None))
 
     # --- reference-named entry points
     def computeImageOfWarpedEvents(self, drotv, want_deriv=False):

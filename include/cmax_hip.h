@@ -129,6 +129,21 @@ enum { CMX_PLANE_IL_OLD = 0, CMX_PLANE_IL_NEW = 1, CMX_PLANE_IWE = 2, CMX_PLANE_
  * plane j (only after an evaluation with CMX_GRAD_PLANES and grad != NULL). host: Hp*Wp fp32. */
 int cmx_backend_get_plane(cmx_ctx *ctx, int which, float *host);
 int cmx_backend_get_alpha(cmx_ctx *ctx, double *alpha);
+
+/* Global-map upkeep on the device (once per window, after the solve).  Keeps IG_ and
+ * IG_update_times_map_ resident across windows: pass IG = CMX_KEEP_MAP to cmx_backend_set_window instead of
+ * round-tripping a 4..32 MB plane through the host every window.
+ *   cmx_backend_update_map    EventWarper::updateIG          (src/backend/event_pano_warper.cpp:109-126): IG += IL_old of
+ *                             the LAST evaluation wherever the visit count is <= max_update_times
+ *   cmx_backend_mark_visited  EventWarper::setUpdateTimesIG  (:81-107) for one pose (the caller loops over the poses
+ *                             every 0.05 s, src/backend/pose_graph_optimizer.cpp:325-337); counts saturate at 255
+ *   cmx_backend_reset_map     resetIG + zero visit counts;   get/set_map: host copies (either pointer may be NULL) */
+#define CMX_KEEP_MAP ((const float *)(uintptr_t)1)
+int cmx_backend_update_map(cmx_ctx *ctx, int max_update_times);
+int cmx_backend_mark_visited(cmx_ctx *ctx, const double quat_xyzw[4], int radius);
+int cmx_backend_reset_map(cmx_ctx *ctx);
+int cmx_backend_get_map(cmx_ctx *ctx, float *IG, unsigned char *visits);
+int cmx_backend_set_map(cmx_ctx *ctx, const float *IG, const unsigned char *visits);
 /* int64_t(1e9 * (t_beg + idx_traj_beg*dt_knots)) -- the (double)->ns truncation of trajectory.cpp:255-256 */
 int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots);
 

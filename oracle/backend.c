@@ -208,3 +208,48 @@ int orc_be_eval(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t
   free(knots);
   return rc;
 }
+
+/* ---- global-map upkeep (once per window, outside the optimiser loop) ---- */
+
+/* EventWarper::updateIG  event_pano_warper.cpp:109-126:
+ * IG(y,x) += IL_old(y,x) wherever the visit count is <= max_update_times */
+void orc_be_update_ig(float *IG, const float *IL_old, const uint8_t *update_times, int npix, int max_update_times) {
+  for (int i = 0; i < npix; i++)
+    if ((int)update_times[i] <= max_update_times) IG[i] += IL_old[i];
+}
+
+/* EventWarper::setUpdateTimesIG  event_pano_warper.cpp:81-107 (+ warpEventToMap :37-54):
+ * every sensor pixel is warped with `rot` onto the panorama; a (2*radius+1)^2 neighbourhood of the hit cell is
+ * marked in a mask; the mask is added (cv::add on CV_8U: saturating) to the visit-count map.
+ * The reference's row test is `0 <= y_mask + j` (sic) and it then indexes mask.at(y_mask, x_mask) -- for
+ * y_mask < 0 that is an out-of-bounds write; this restatement keeps the published test AND skips y_mask < 0. */
+void orc_be_mark_visited(int W, int H, const double *lut, int Wp, int Hp, const double quat_xyzw[4], int radius,
+                         uint8_t *update_times) {
+  const double qx = quat_xyzw[0], qy = quat_xyzw[1], qz = quat_xyzw[2], qw = quat_xyzw[3];
+  /* rot.matrix(): Eigen toRotationMatrix */
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const double tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
+                       txz - twy, tyz + twx, 1 - (txx + tyy)};
+  uint8_t *mask = (uint8_t *)calloc((size_t)Wp * Hp, 1);
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const double *b = lut + 3 * ((size_t)y * W + x);
+      double e[3], px[2];
+      for (int i = 0; i < 3; i++) e[i] = R[3 * i] * b[0] + R[3 * i + 1] * b[1] + R[3 * i + 2] * b[2];
+      orc_equirect_project(Wp, Hp, e, px, NULL);
+      const int ic = (int)px[0], ir = (int)px[1];
+      for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+          const int x_mask = ic + i, y_mask = ir + j;
+          if (0 <= y_mask + j && y_mask < Hp && 0 <= x_mask && x_mask < Wp && y_mask >= 0)
+            mask[(size_t)y_mask * Wp + x_mask] = 1;
+        }
+    }
+  for (size_t i = 0; i < (size_t)Wp * Hp; i++) {
+    const int v = (int)update_times[i] + (int)mask[i];
+    update_times[i] = (uint8_t)(v > 255 ? 255 : v);
+  }
+  free(mask);
+}

@@ -117,6 +117,10 @@ int orc_be_eval(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t
                 double *contrast, double *grad, float *iwe_out /* optional */);
 /* EventWarper::updateAlpha (event_pano_warper.cpp:134-165) */
 double orc_be_alpha(const float *IGp, const float *IL, int npix);
+/* global-map upkeep, once per window (event_pano_warper.cpp:81-126) */
+void orc_be_update_ig(float *IG, const float *IL_old, const uint8_t *update_times, int npix, int max_update_times);
+void orc_be_mark_visited(int W, int H, const double *lut, int Wp, int Hp, const double quat_xyzw[4], int radius,
+                         uint8_t *update_times);
 /* dvs::EquirectangularCamera::projectToImage (equirectangular_camera.h:18-45) */
 void orc_equirect_project(int Wp, int Hp, const double P[3], double px[2], float jac[6] /* or NULL */);
 

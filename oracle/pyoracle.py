@@ -82,6 +82,9 @@ def lib():
         L.orc_be_alpha.restype = C.c_double
         L.orc_be_alpha.argtypes = [c_fp, c_fp, C.c_int]
         L.orc_equirect_project.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_fp]
+        c_u8p = C.POINTER(C.c_uint8)
+        L.orc_be_update_ig.argtypes = [c_fp, c_fp, c_u8p, C.c_int, C.c_int]
+        L.orc_be_mark_visited.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, c_dp, C.c_int, c_u8p]
         _LIB = L
     return _LIB
 
@@ -260,6 +263,20 @@ class Backend:
     @property
     def alpha(self):
         return self.state.alpha
+
+    # --- global-map upkeep (event_pano_warper.cpp:81-126)
+    def update_ig(self, max_update_times):
+        if not hasattr(self, "update_times"):
+            self.update_times = np.zeros((self.Hp, self.Wp), np.uint8)
+        lib().orc_be_update_ig(_fp(self.IG), _fp(self.IL_old), self.update_times.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               self.IG.size, int(max_update_times))
+
+    def mark_visited(self, quat_xyzw, radius=3):
+        if not hasattr(self, "update_times"):
+            self.update_times = np.zeros((self.Hp, self.Wp), np.uint8)
+        q = _c(quat_xyzw, np.float64)
+        lib().orc_be_mark_visited(self.W, self.H, _dp(self.lut), self.Wp, self.Hp, _dp(q), int(radius),
+                                  self.update_times.ctypes.data_as(C.POINTER(C.c_uint8)))
 
     def _ev(self):
         return (len(self.x), self.x.ctypes.data_as(c_u16p), self.y.ctypes.data_as(c_u16p),

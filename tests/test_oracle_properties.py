@@ -195,3 +195,26 @@ def test_spline_range_error(oracle, win):
     be.set_window(w.x, w.y, w.t_ns, w.knots_init[:5], w.start_ns, w.dt_ns, 3, w.t_next_win_beg_ns)
     with pytest.raises(ValueError):
         be.eval(np.zeros(6))
+
+
+def test_map_upkeep_restatement(oracle, win):
+    """updateIG / setUpdateTimesIG (event_pano_warper.cpp:81-126): visit counts gate the accumulation of IL_old."""
+    w = win
+    be = _be(oracle, w, sigma=0.0)
+    be.iwe(np.zeros(w.P))
+    q = w.knots_true[0]
+    be.mark_visited(q, 3)
+    v1 = be.update_times.copy()
+    # the marked region is the sensor footprint dilated by 3 px: roughly sensor area in panorama pixels
+    fx_p = w.Wp / (2 * np.pi)
+    foot = (2 * np.arctan(w.W / 2 / w.fx) * fx_p) * (2 * np.arctan(w.H / 2 / w.fy) * fx_p)
+    assert 0.6 * foot < v1.sum() < 2.0 * foot and v1.max() == 1
+    be.mark_visited(q, 3)
+    assert be.update_times.max() == 2
+    be.update_ig(1)  # pixels visited twice (count 2 > 1) are frozen
+    assert np.all(be.IG[be.update_times == 2] == 0)
+    np.testing.assert_array_equal(be.IG[be.update_times == 0], be.IL_old[be.update_times == 0])
+    be.update_times[...] = 254
+    be.mark_visited(q, 0)
+    be.mark_visited(q, 0)
+    assert be.update_times.max() == 255  # cv::add on CV_8U saturates
