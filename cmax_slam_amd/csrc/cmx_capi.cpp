@@ -89,6 +89,8 @@ struct cmx_ctx {
   size_t cx_cap = 0, cy_cap = 0;
   double *d_gpartials = nullptr;
   size_t gpartials_cap = 0;
+  double *d_vparts = nullptr;  // back end: per-batch partial V sums of the gather pass
+  size_t vparts_cap = 0;
   double *d_gsum = nullptr;   // this rank's partial gradient sums [P] (caller-owned when external: RCCL reduces it in place)
   size_t gsum_cap = 0;
   bool gsum_external = false;
@@ -576,10 +578,16 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   if (rc) return rc;
   rc = ensure(c, c->d_sums, c->sums_cap, 2);
   if (rc) return rc;
-  const int gb = gather_blocks(c->n_packed);
+  // rows of the gather partial table: front end = gather workgroups; back end = workgroups of the per-batch pass
+  const int gb = (c->kind == KIND_FE) ? gather_blocks(c->n_packed) : be_batch_blocks(c->nb);
   const int P2 = 2 * (P > 0 ? P : 1);
   rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * P2);
   if (rc) return rc;
+  const int parts_per_batch = (c->per_batch + 62) / 64 + 1;
+  if (c->kind == KIND_BE) {
+    rc = ensure(c, c->d_vparts, c->vparts_cap, (size_t)(c->nb > 0 ? c->nb : 1) * parts_per_batch * 6);
+    if (rc) return rc;
+  }
   if (2 + (size_t)P > c->result_cap - 2) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
   if (!c->gsum_external) {
     rc = ensure(c, c->d_gsum, c->gsum_cap, (size_t)P2);
@@ -639,7 +647,9 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
       g.P = P;
       g.gpartials = c->d_gpartials;
       g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
-      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->stream);
+      g.vparts = c->d_vparts;
+      g.parts_per_batch = parts_per_batch;
+      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream);
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }
     if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
@@ -731,6 +741,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_cx);
   hipFree(c->d_cy);
   hipFree(c->d_gpartials);
+  hipFree(c->d_vparts);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);

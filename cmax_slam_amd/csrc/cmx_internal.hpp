@@ -91,10 +91,11 @@ struct BeGatherArgs {
   BeSplatArgs ev;
   const float *itilde;
   int P;                   // 3 * (K - num_fixed)
-  int chunk;               // events per workgroup iteration (multiple of 256)
-  double *gpartials;       // [nblocks][P]  (mu-free form: [nblocks][2P], S1 then S2)
+  double *gpartials;       // [2P][be_batch_blocks(nb)]: S1 columns then S2 columns
   const float *cx, *cy;    // as in FeGatherArgs
   int r;
+  double *vparts;          // [nb][parts_per_batch][6]: per-batch partial sums of V (3) and of the border vector U (3)
+  int parts_per_batch;     // 64-event slices a batch can touch
 };
 
 struct FinalizeArgs {
@@ -161,7 +162,8 @@ void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the number of blocks (rows of gpartials)
-int launch_be_gather(const BeGatherArgs &a, hipStream_t s);
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s);  // returns the rows of gpartials (batch-kernel blocks)
+int be_batch_blocks(int nb);
 int gather_blocks(int n);
 // global-map upkeep (once per window)
 void launch_update_map(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_update_times,

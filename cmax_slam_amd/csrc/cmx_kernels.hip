@@ -642,23 +642,19 @@ int launch_fe_gather(const FeGatherArgs &a, hipStream_t s) {
 // back end: per event V = (dItilde/dx, dItilde/dy) * dpm_ddrot (3-vector); events of one batch share the 3x3N
 // spline Jacobian, so V is summed per batch first (segmented wave reduction over the contiguous batch runs, then
 // LDS), and one small mat-vec per batch maps it onto the 3N knot parameters the batch touches.
-constexpr int kMaxSlots = 260;  // batches a 256-event chunk can touch (per_batch >= 1)
 constexpr int kMaxGradLDS = 3 * kMaxKnots;
 
-template <int N>
+// Pass 1: every WAVE walks its own 64-event slices (time order, so the events of a batch are adjacent lanes): segmented
+// shuffle reduction of V (and of the border-term vector U) over the batch runs inside the wave; the run's head lane
+// stores the partial sums to vparts[batch][part] (part = slice index relative to the batch's first slice: a plain
+// store, no atomics, every slot written exactly once).  No barrier, no LDS.
 __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
-  __shared__ double shV[kMaxSlots * 3];
-  __shared__ double shG[kMaxGradLDS];
-  __shared__ double shG2[kMaxGradLDS];  // border (mu) term: only the rare votes within r of the panorama border add to it
   const BeSplatArgs &a = g.ev;
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int j = tid; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
-  for (int j = tid; j < kMaxSlots * 3; j += 256) shV[j] = 0;
-  __syncthreads();
-  for (int base = blockIdx.x * 256; base < a.n; base += gridDim.x * 256) {
-    const int i = base + tid;
-    const int batch0 = base / a.per_batch;
-    double V0 = 0, V1 = 0, V2 = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  for (int base = (blockIdx.x * 4 + wave) * 64; base < a.n; base += nwaves * 64) {
+    const int i = base + lane;
+    double V0 = 0, V1 = 0, V2 = 0, U0 = 0, U1 = 0, U2 = 0;
     int batch = -1;
     if (i < a.n) {
       const BeWarp w = be_warp_event<true>(a, i);
@@ -669,65 +665,85 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
         V0 = (double)A * (double)w.m[0] + (double)B * (double)w.m[3];
         V1 = (double)A * (double)w.m[1] + (double)B * (double)w.m[4];
         V2 = (double)A * (double)w.m[2] + (double)B * (double)w.m[5];
-        if (g.cx) {
-          float Ac, Bc;
-          border_grad(g.cx, g.cy, a.Wp, a.Hp, g.r, w.xx, w.yy, w.dx, w.dy, Ac, Bc);
-          if (Ac != 0.f || Bc != 0.f) {  // rare: straight to the block accumulators, no per-batch staging
-            const PoseEntry &pe = a.poses[w.batch];
-            const double u0 = (double)Ac * (double)w.m[0] + (double)Bc * (double)w.m[3];
-            const double u1 = (double)Ac * (double)w.m[1] + (double)Bc * (double)w.m[4];
-            const double u2 = (double)Ac * (double)w.m[2] + (double)Bc * (double)w.m[5];
-            const int jb = 3 * (pe.idx_cp_beg - a.num_fixed);
-            for (int c = 0; c < 3 * N; c++) {
-              const int j = jb + c;
-              if (j >= 0)
-                atomicAdd(&shG2[j], u0 * (double)pe.Jcp[c] + u1 * (double)pe.Jcp[3 * N + c] + u2 * (double)pe.Jcp[6 * N + c]);
-            }
-          }
+        float Ac, Bc;
+        border_grad(g.cx, g.cy, a.Wp, a.Hp, g.r, w.xx, w.yy, w.dx, w.dy, Ac, Bc);
+        if (Ac != 0.f || Bc != 0.f) {  // rare: votes within r of the panorama border
+          U0 = (double)Ac * (double)w.m[0] + (double)Bc * (double)w.m[3];
+          U1 = (double)Ac * (double)w.m[1] + (double)Bc * (double)w.m[4];
+          U2 = (double)Ac * (double)w.m[2] + (double)Bc * (double)w.m[5];
         }
       }
     }
-    // segmented reduction over contiguous runs of equal batch id inside the wave
+    const bool any_u = __any(U0 != 0.0 || U1 != 0.0 || U2 != 0.0);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const double t0 = __shfl_down(V0, o, 64), t1 = __shfl_down(V1, o, 64), t2 = __shfl_down(V2, o, 64);
       const int bo = __shfl_down(batch, o, 64);
-      if (lane + o < 64 && bo == batch) { V0 += t0; V1 += t1; V2 += t2; }
+      const bool same = lane + o < 64 && bo == batch;
+      if (same) { V0 += t0; V1 += t1; V2 += t2; }
+      if (any_u) {  // wave-uniform
+        const double u0 = __shfl_down(U0, o, 64), u1 = __shfl_down(U1, o, 64), u2 = __shfl_down(U2, o, 64);
+        if (same) { U0 += u0; U1 += u1; U2 += u2; }
+      }
     }
     const int bprev = __shfl_up(batch, 1, 64);
     if (batch >= 0 && (lane == 0 || bprev != batch)) {
-      double *p = shV + 3 * (batch - batch0);
-      atomicAdd(p, V0);
-      atomicAdd(p + 1, V1);
-      atomicAdd(p + 2, V2);
+      const int part = (base >> 6) - ((batch * a.per_batch) >> 6);
+      double *dst = g.vparts + ((size_t)batch * g.parts_per_batch + part) * 6;
+      dst[0] = V0; dst[1] = V1; dst[2] = V2;
+      dst[3] = U0; dst[4] = U1; dst[5] = U2;
     }
-    __syncthreads();
-    const int last = min(a.n - 1, base + 255);
-    const int nslots = last / a.per_batch - batch0 + 1;
-    if (tid < nslots) {
-      const PoseEntry &pe = a.poses[batch0 + tid];
-      const double v0 = shV[3 * tid], v1 = shV[3 * tid + 1], v2 = shV[3 * tid + 2];
-      shV[3 * tid] = 0; shV[3 * tid + 1] = 0; shV[3 * tid + 2] = 0;
-      const int jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
-#pragma unroll
-      for (int c = 0; c < 3 * N; c++) {
-        const int j = jbase + c;
-        if (j >= 0)
-          atomicAdd(&shG[j], v0 * (double)pe.Jcp[c] + v1 * (double)pe.Jcp[3 * N + c] + v2 * (double)pe.Jcp[6 * N + c]);
-      }
-    }
-    __syncthreads();
-  }
-  for (int j = tid; j < g.P; j += 256) {  // [column][block]
-    g.gpartials[(size_t)j * gridDim.x + blockIdx.x] = shG[j];
-    if (g.cx) g.gpartials[(size_t)(g.P + j) * gridDim.x + blockIdx.x] = shG2[j];
   }
 }
 
-int launch_be_gather(const BeGatherArgs &a, hipStream_t s) {
-  const int blocks = gather_blocks(a.ev.n);
-  if (a.ev.order == 2) hipLaunchKernelGGL(be_gather_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(be_gather_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+// Pass 2: one thread per batch: sum its parts, apply the batch's 3x3N spline Jacobian (events of one batch share it),
+// accumulate S1 / S2 per parameter in LDS, one partial row per workgroup ([column][block]).
+template <int N>
+__global__ __launch_bounds__(256) void be_gather_batch_kernel(BeGatherArgs g, int nb) {
+  __shared__ double shG[kMaxGradLDS], shG2[kMaxGradLDS];
+  const BeSplatArgs &a = g.ev;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
+  __syncthreads();
+  for (int b = blockIdx.x * 256 + tid; b < nb; b += gridDim.x * 256) {
+    const int first = b * a.per_batch, last = min(a.n, first + a.per_batch) - 1;
+    const int nparts = (last >> 6) - (first >> 6) + 1;
+    double V[6] = {0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < nparts; p++) {
+      const double *src = g.vparts + ((size_t)b * g.parts_per_batch + p) * 6;
+#pragma unroll
+      for (int q = 0; q < 6; q++) V[q] += src[q];
+    }
+    const PoseEntry &pe = a.poses[b];
+    const int jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
+    const bool has_u = V[3] != 0.0 || V[4] != 0.0 || V[5] != 0.0;
+#pragma unroll
+    for (int c = 0; c < 3 * N; c++) {
+      const int j = jbase + c;
+      if (j >= 0) {
+        const double j0 = (double)pe.Jcp[c], j1 = (double)pe.Jcp[3 * N + c], j2 = (double)pe.Jcp[6 * N + c];
+        atomicAdd(&shG[j], V[0] * j0 + V[1] * j1 + V[2] * j2);
+        if (has_u) atomicAdd(&shG2[j], V[3] * j0 + V[4] * j1 + V[5] * j2);
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < g.P; j += 256) {  // [column][block]
+    g.gpartials[(size_t)j * gridDim.x + blockIdx.x] = shG[j];
+    g.gpartials[(size_t)(g.P + j) * gridDim.x + blockIdx.x] = shG2[j];
+  }
+}
+
+int be_batch_blocks(int nb) {
+  const int blocks = (nb + 255) / 256;
+  return blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+}
+
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s) {
+  hipLaunchKernelGGL(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, a);
+  const int blocks = be_batch_blocks(nb);
+  if (a.ev.order == 2) hipLaunchKernelGGL(be_gather_batch_kernel<2>, dim3(blocks), dim3(256), 0, s, a, nb);
+  else hipLaunchKernelGGL(be_gather_batch_kernel<4>, dim3(blocks), dim3(256), 0, s, a, nb);
   return blocks;
 }
 

@@ -124,3 +124,26 @@ def test_backend_config3_adjoint(hip, oracle):
     c, g = be.eval(d)
     assert rel_scalar(c, c_ref) < RTOL
     assert rel_vec(g, g_ref) < RTOL
+
+
+@pytest.mark.parametrize("W,H,sigma", [(24, 20, 1.0), (9, 9, 1.0), (40, 12, 3.0), (200, 150, 3.0)])
+def test_small_images_and_wide_kernels(hip, oracle, W, H, sigma):
+    """Images not larger than the blur kernel cannot use the folded G^T (double reflections): the evaluator must fall
+    back to the derivative-plane gradient on its own and stay exact; wide kernels (r = 12) exercise the generic path."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    x = rng.integers(0, W, n).astype(np.uint16)
+    y = rng.integers(0, H, n).astype(np.uint16)
+    t = np.sort(rng.integers(0, 50_000_000, n)) + synth.T0_NS
+    f = 0.8 * W
+    p = synth.FrontendPacket(W, H, f, f, (W - 1) / 2, (H - 1) / 2, x, y, t, synth.T0_NS + 25_000_000, np.zeros(3))
+    fe = hip.FrontendEvaluator(W, H, p.lut)
+    fe.set_fast_path()
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, 100, sigma, 0)
+    ref = oracle.Frontend(W, H, p.lut, p.fx, p.fy, p.cx, p.cy, 100, sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in ((0.5, -0.3, 0.8), (0, 0, 0)):
+        c_ref, g_ref = ref.eval(om)
+        c, g = fe.eval(om)
+        assert abs(c - c_ref) <= RTOL * max(abs(c_ref), 1e-12)
+        assert np.abs(g - g_ref).max() <= RTOL * max(np.abs(g_ref).max(), 1e-12)
