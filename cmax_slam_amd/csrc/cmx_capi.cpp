@@ -481,6 +481,7 @@ BeSplatArgs be_args(const cmx_ctx *c) {
 }
 
 bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: image larger than the kernel
+  if (c->measure == CMX_GRADIENT_MAGNITUDE) return false;  // Sobel contrast: derivative-plane form only
   return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
 }
 
@@ -523,6 +524,37 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   if (rc) return rc;
   if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many derivative planes (%d)", P);
   a.partials = c->d_partials;
+  if (c->measure == CMX_GRADIENT_MAGNITUDE && c->kind == KIND_FE) {
+    // blurred planes -> scratch, then Sobel moments (reference local_focus_funcs.cpp:47-73), then finalize
+    const size_t np = (size_t)W * H;
+    float *blur = out_blur0;
+    if (!blur) {
+      rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
+      if (rc) return rc;
+      blur = c->d_scratch;
+      a.out_blur0 = blur;
+      a.out_blurd = blur + np;
+    }
+    SobelArgs sa{};
+    sa.W = W; sa.H = H; sa.P = P;
+    sa.planes = blur;
+    sa.nblk = sobel_blocks(W, H);
+    rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)(1 + P) * sa.nblk);
+    if (rc) return rc;
+    sa.partials = c->d_gpartials;
+    Span sp(c, CMX_T_IMAGE);
+    launch_image_moments(a, c->stream);
+    launch_sobel_moments(sa, c->stream);
+    FinalizeArgs f{};
+    f.P = 0; f.nblk = a.nblk; f.measure = 2; f.npix = (double)np;
+    f.partials = c->d_partials; f.sums = c->d_sums; f.result = c->d_result;
+    f.direct = 1;
+    f.gpartials = c->d_gpartials; f.gblocks = sa.nblk; f.gP = P;
+    f.fallback = c->d_fallback;
+    launch_finalize_only(f, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
   {
     Span sp(c, CMX_T_IMAGE);
     launch_image_moments(a, c->stream);
@@ -855,9 +887,8 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   c->accumulated = false;
   c->x_valid = false;
   if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
-  if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
-    return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d is not implemented on the GPU (variance / mean-square only)",
-                contrast_measure);
+  // computeContrast's switch (local_focus_funcs.cpp:98-109): 1 = mean square, 2 = gradient magnitude, default = variance
+  if (contrast_measure != CMX_MEAN_SQUARE && contrast_measure != CMX_GRADIENT_MAGNITUDE) contrast_measure = CMX_VARIANCE;
   rc = check_events(c, n, x, y, t_ns);
   if (rc) return rc;
   rc = setup_blur(c, blur_sigma);
@@ -1034,8 +1065,8 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (num_fixed < 0 || num_fixed > K) return fail(c, CMX_ERR_INVALID_ARG, "num_fixed=%d outside [0, K]", num_fixed);
   if (!knots_xyzw || dt_ns <= 0) return fail(c, CMX_ERR_INVALID_ARG, "bad spline description");
   if (event_batch_size <= 0 || event_sample_rate <= 0) return fail(c, CMX_ERR_INVALID_ARG, "batch size / sample rate must be > 0");
-  if (contrast_measure != CMX_VARIANCE && contrast_measure != CMX_MEAN_SQUARE)
-    return fail(c, CMX_ERR_INVALID_ARG, "contrast_measure %d unsupported in the back end", contrast_measure);
+  // the back end's switch (global_focus_funcs.cpp:61-69) knows mean square only; everything else is variance
+  if (contrast_measure != CMX_MEAN_SQUARE) contrast_measure = CMX_VARIANCE;
   rc = check_events(c, n, x, y, t_ns);
   if (rc) return rc;
   rc = setup_blur(c, blur_sigma);

@@ -165,6 +165,16 @@ int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the numb
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s);  // returns the rows of gpartials (batch-kernel blocks)
 int be_batch_blocks(int nb);
 int gather_blocks(int n);
+// contrast_ImageGradientMagnitude (front end, contrast_measure = 2): Sobel moments of the blurred planes
+struct SobelArgs {
+  int W, H, P;
+  const float *planes;   // [1+P][H][W] blurred I, D_0..D_{P-1}
+  double *partials;      // [1+P][nblk]: sum(gx^2+gy^2), sum(gx*dgx_k + gy*dgy_k)
+  int nblk;
+};
+void launch_sobel_moments(const SobelArgs &a, hipStream_t s);
+int sobel_blocks(int W, int H);
+
 // global-map upkeep (once per window)
 void launch_update_map(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_update_times,
                        hipStream_t s);

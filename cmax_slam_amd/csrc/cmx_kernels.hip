@@ -347,6 +347,18 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
       a.result[4094] = 0.0;
     }
   }
+  if (a.measure == 2) {  // gradient magnitude: rows of the Sobel partial table [1+gP][gblocks]
+    for (int k = wave; k < 1 + a.gP; k += 16) {
+      double s = 0;
+      for (int b = lane; b < a.gblocks; b += 64) s += a.gpartials[(size_t)k * a.gblocks + b];
+      s = wave_sum(s);
+      if (lane == 0) outv[k == 0 ? 0 : 1 + k] = (k == 0) ? s / N : 2.0 * s / N;
+    }
+    __syncthreads();
+    const int nout2 = 2 + a.gP;
+    if (t < nout2) a.result[t] = outv[t];
+    return;
+  }
   // derivative-plane mode: moments of the P blurred planes were reduced into sums[] by reduce_partials
   for (int k = t; k < a.P; k += 1024) {
     const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
@@ -784,6 +796,54 @@ __global__ __launch_bounds__(256) void alpha_finalize_kernel(AlphaArgs a) {
 void launch_alpha(const AlphaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(alpha_partials_kernel, dim3(a.nblk), dim3(256), 0, s, a);
   hipLaunchKernelGGL(alpha_finalize_kernel, dim3(1), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------- Sobel moments
+// contrast_ImageGradientMagnitude (reference local_focus_funcs.cpp:47-73): cv::Sobel 3x3 (REFLECT_101) of the
+// blurred IWE and of each blurred derivative channel; contrast = mean(gx^2+gy^2), grad_k = 2 mean(gx*dgx_k + gy*dgy_k).
+// Row filter then column filter in fp32, same order as the CPU path; fp64 sums.
+__device__ __forceinline__ void sobel_at(const float *p, int W, int H, int x, int y, float &gx, float &gy) {
+  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, H), yp = reflect101(y + 1, H);
+  const float *r0 = p + (size_t)ym * W, *r1 = p + (size_t)y * W, *r2 = p + (size_t)yp * W;
+  // dx: row [-1 0 1], column [1 2 1]
+  const float d0 = r0[xp] - r0[xm], d1 = r1[xp] - r1[xm], d2 = r2[xp] - r2[xm];
+  gx = d0 + d1 * 2.f + d2;
+  // dy: row [1 2 1], column [-1 0 1]
+  const float s0 = r0[xm] + r0[x] * 2.f + r0[xp], s2 = r2[xm] + r2[x] * 2.f + r2[xp];
+  gy = s2 - s0;
+}
+
+int sobel_blocks(int W, int H) {
+  const int b = (W * H + 255) / 256;
+  return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+
+__global__ __launch_bounds__(256) void sobel_moments_kernel(SobelArgs a) {
+  __shared__ double red[4];
+  const size_t np = (size_t)a.W * a.H;
+  double acc0 = 0, acc[3] = {0, 0, 0};  // front end: P <= 3
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < (int)np; i += gridDim.x * 256) {
+    const int y = i / a.W, x = i - y * a.W;
+    float gx, gy;
+    sobel_at(a.planes, a.W, a.H, x, y, gx, gy);
+    const float hf = gx * gx + gy * gy;
+    acc0 += (double)hf;
+    for (int k = 0; k < a.P; k++) {
+      float dgx, dgy;
+      sobel_at(a.planes + (size_t)(1 + k) * np, a.W, a.H, x, y, dgx, dgy);
+      const float m = gx * dgx + gy * dgy;
+      acc[k] += (double)m;
+    }
+  }
+  double t = block_sum(acc0, red);
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = t;
+  for (int k = 0; k < a.P; k++) {
+    t = block_sum(acc[k], red);
+    if (threadIdx.x == 0) a.partials[(size_t)(1 + k) * a.nblk + blockIdx.x] = t;
+  }
+}
+void launch_sobel_moments(const SobelArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(sobel_moments_kernel, dim3(a.nblk), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------- map upkeep

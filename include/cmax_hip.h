@@ -41,7 +41,9 @@ enum {
   CMX_ERR_TIME_ORDER = 6    /* a batch spans a negative time interval (reference: CHECK_GE abort) */
 };
 
-/* contrast_measure: include/frontend/local_focus_funcs.h:7-11 (back end: VARIANCE / MEAN_SQUARE only) */
+/* contrast_measure: include/frontend/local_focus_funcs.h:7-11.  As in the reference's switch statements any other
+ * value means VARIANCE, and the back end (global_focus_funcs.cpp:61-69) treats GRADIENT_MAGNITUDE as VARIANCE too.
+ * GRADIENT_MAGNITUDE (Sobel, front end) always uses the derivative-plane gradient. */
 enum { CMX_VARIANCE = 0, CMX_MEAN_SQUARE = 1, CMX_GRADIENT_MAGNITUDE = 2 };
 
 /* how the analytic gradient is formed */

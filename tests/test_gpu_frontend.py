@@ -146,3 +146,26 @@ def test_config2_full_size(hip, oracle):
     raw_ref = ref.iwe(p.omega_true, blur=False)
     assert abs(raw.sum(dtype=np.float64) - raw_ref.sum(dtype=np.float64)) < 1e-5 * len(p.x)
     assert rel_img(raw, raw_ref) < RTOL
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_gradient_magnitude_contrast(hip, oracle, small, fast):
+    """contrast_measure = 2: cv::Sobel-based contrast and its analytic gradient (local_focus_funcs.cpp:47-73)."""
+    fe, ref = _pair(hip, oracle, small, measure=2)
+    if fast:
+        fe.set_fast_path()  # Sobel contrast has no adjoint form here: the evaluator uses derivative planes on its own
+    for om in ((0, 0, 0), (0.3, -0.5, 0.2), (0.6, -0.9, 0.4)):
+        c_ref, g_ref = ref.eval(om)
+        c, g = fe.eval(om)
+        assert rel_scalar(c, c_ref) < RTOL
+        assert rel_vec(g, g_ref) < RTOL
+        assert rel_scalar(fe.eval(om, want_grad=False)[0], c_ref) < RTOL
+
+
+def test_unknown_measure_means_variance(hip, oracle, small):
+    fe, ref = _pair(hip, oracle, small, measure=0)
+    fe7 = hip.FrontendEvaluator(small.W, small.H, small.lut)
+    fe7.set_packet(small.x, small.y, small.t_ns, small.t_ref_ns, small.fx, small.fy, small.cx, small.cy, 100, 1.0, 7)
+    c_ref, g_ref = ref.eval((0.3, -0.5, 0.2))
+    c, g = fe7.eval((0.3, -0.5, 0.2))
+    assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
