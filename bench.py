@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--mode", default="fast", choices=["fast", "faithful"],
                     help="fast = adjoint gradient + LDS-privatised splat (production path); faithful = derivative planes + "
                          "one global atomic per vote (the reference's data flow)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="N>1 exchange: native = RCCL communicator inside the evaluator (all-reduces issued from C++ on the "
+                         "context's stream); torch = torch.distributed.all_reduce on evaluator-owned torch tensors")
     ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -103,12 +106,30 @@ def main():
     # every timed step is a FULL evaluation: the df-after-f image reuse (on by default, used by the solver) is off here
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
 
+    comm_used = "none"
     if world > 1:
-        accum, gsum, stream = attach_torch_accum(ev, device)
-        sh = ShardedEvaluator(ev, accum, gsum)
-        def step():
-            with torch.cuda.stream(stream):
-                return sh.eval(x0, True)
+        if args.comm == "native":
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(ev.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                ev.comm_attach(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                comm_used = "native RCCL communicator inside the evaluator"
+            except Exception as e:  # keep the run alive: fall back to torch.distributed on evaluator-owned tensors
+                comm_used = "torch.distributed (native attach failed: %s)" % e
+                args.comm = "torch"
+        if args.comm == "torch":
+            accum, gsum, stream = attach_torch_accum(ev, device)
+            sh = ShardedEvaluator(ev, accum, gsum)
+            if comm_used == "none":
+                comm_used = "torch.distributed.all_reduce (RCCL) in place on the evaluator's planes"
+            def step():
+                with torch.cuda.stream(stream):
+                    return sh.eval(x0, True)
+        else:
+            def step():
+                return ev.eval(x0, True)
     else:
         def step():
             return ev.eval(x0, True)
@@ -167,8 +188,8 @@ def main():
             "dtype": "f64 warp / f32 accumulate", "data": "synthetic",
             "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)",
                        "mode": args.mode + (" (adjoint gradient, LDS-privatised splat)" if adjoint else
-                                            " (derivative planes, global atomics)"), "parallelism": "events sharded by batch range x%d, all-reduce of partial planes" % world
-                       if world > 1 else "single GPU"},
+                                            " (derivative planes, global atomics)"), "parallelism": ("events sharded by batch range x%d, all-reduce of partial planes + partial gradient sums; %s"
+                                       % (world, comm_used)) if world > 1 else "single GPU"},
             "per_gpu_value": value / world,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -65,6 +65,9 @@ SYMBOLS = {
     "cmx_grad_ptr": (C.c_void_p, [ctx_p]),
     "cmx_grad_count": (C.c_size_t, [ctx_p]),
     "cmx_set_grad_buffer": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),
+    "cmx_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "cmx_comm_attach": (C.c_int, [ctx_p, C.c_char_p, C.c_int, C.c_int]),
+    "cmx_comm_detach": (C.c_int, [ctx_p]),
     "cmx_frontend_solve": (C.c_int, [ctx_p, c_dp, C.c_void_p]),
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,

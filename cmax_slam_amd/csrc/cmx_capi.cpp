@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is dlopen()ed when a communicator is first attached
+
 #include "cmx_internal.hpp"
 
 using namespace cmx;
@@ -124,6 +127,10 @@ struct cmx_ctx {
   size_t partials_cap = 0, sums_cap = 0;
   double *h_result = nullptr, *d_result = nullptr;  // mapped pinned host
   size_t result_cap = 0;
+
+  // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
 
   // timing
   bool timing = false;
@@ -284,6 +291,42 @@ void collect_spans(cmx_ctx *c) {  // call after the stream has been synchronised
     c->event_pool.push_back(s.b);
   }
   c->spans.clear();
+}
+
+// ---- RCCL, loaded lazily so that single-GPU hosts carry no dependency on it
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (!a.handle) return a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+int comm_allreduce(cmx_ctx *c, void *buf, size_t count, ncclDataType_t dt) {
+  if (!c->comm || count == 0) return CMX_OK;
+  const ncclResult_t r = rccl().AllReduce(buf, buf, count, dt, ncclSum, c->comm, c->stream);
+  if (r != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(r));
+  return CMX_OK;
 }
 
 int create_common(cmx_ctx **out, int kind, int device, int W, int H, const double *lut) {
@@ -776,6 +819,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_vparts);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
+  if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -986,14 +1030,35 @@ static bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) 
   return memcmp(x, c->last_x, sizeof(double) * (size_t)n) == 0;
 }
 
+// evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
+static int finish_begin(cmx_ctx *c, int kind, int want_grad);
+static int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
+static int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad) {
+  int rc = CMX_OK;
+  if (exchange_planes) {
+    rc = comm_allreduce(c, c->d_accum, c->accum_count, ncclFloat);  // sum of the ranks' partial planes
+    if (rc) return rc;
+  }
+  rc = finish_begin(c, kind, grad != nullptr);
+  if (rc) return rc;
+  if (c->pending_P > 0) {
+    rc = comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, ncclDouble);  // adjoint mode: S1,S2 partial sums
+    if (rc) return rc;
+  }
+  return finish_end(c, kind, contrast, grad);
+}
+
 int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
+  const bool sharded = c && c->comm;
   if (c && c->kind == KIND_FE && omega && can_reuse(c, omega, 3, grad != nullptr)) {
     c->last_adjoint = true;  // image of this very point is resident: adjoint blur + gather only
     c->reuse_hits++;
+    if (sharded) return finish_sharded(c, KIND_FE, false, contrast, grad);
     return cmx_frontend_finish(c, contrast, grad);
   }
   int rc = cmx_frontend_accumulate(c, omega, grad != nullptr);
   if (rc) return rc;
+  if (sharded) return finish_sharded(c, KIND_FE, true, contrast, grad);
   return cmx_frontend_finish(c, contrast, grad);
 }
 
@@ -1242,14 +1307,54 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
+  const bool sharded = c && c->comm;
   if (c && c->kind == KIND_BE && drotv && can_reuse(c, drotv, 3 * (c->K - c->num_fixed), grad != nullptr)) {
     c->last_adjoint = true;
     c->reuse_hits++;
+    if (sharded) return finish_sharded(c, KIND_BE, false, contrast, grad);
     return cmx_backend_finish(c, contrast, grad);
   }
   int rc = cmx_backend_accumulate(c, drotv, grad != nullptr);
   if (rc) return rc;
+  if (sharded) return finish_sharded(c, KIND_BE, true, contrast, grad);
   return cmx_backend_finish(c, contrast, grad);
+}
+
+// ---- native RCCL communicator (one process per GPU; the launcher distributes the 128-byte id)
+int cmx_comm_unique_id(char id[CMX_COMM_ID_BYTES]) {
+  if (!id) return CMX_ERR_INVALID_ARG;
+  if (!rccl().ok) return CMX_ERR_HIP;
+  static_assert(sizeof(ncclUniqueId) <= CMX_COMM_ID_BYTES, "id buffer too small");
+  ncclUniqueId u;
+  if (rccl().GetUniqueId(&u) != ncclSuccess) return CMX_ERR_HIP;
+  memset(id, 0, CMX_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return CMX_OK;
+}
+int cmx_comm_attach(cmx_ctx *c, const char id[CMX_COMM_ID_BYTES], int rank, int nranks) {
+  if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, CMX_ERR_INVALID_ARG, "bad communicator arguments");
+  if (!rccl().ok) return fail(c, CMX_ERR_HIP, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+  int rc = bind(c);
+  if (rc) return rc;
+  if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return fail(c, CMX_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); }
+  c->comm_rank = rank;
+  c->comm_size = nranks;
+  return CMX_OK;
+}
+int cmx_comm_detach(cmx_ctx *c) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->comm_size = 1;
+  c->comm_rank = 0;
+  return CMX_OK;
 }
 
 // ---- three-phase finish for sharded adjoint evaluations: begin (image, adjoint blur, gather -> partial gradient

@@ -92,6 +92,19 @@ class _Evaluator:
     def accum_count(self):
         return int(self._L.cmx_accum_count(self._ctx))
 
+    # native RCCL exchange inside the evaluator (one process per GPU)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(None, _lib.lib().cmx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_attach(self, unique_id, rank, nranks):
+        self._ck(self._L.cmx_comm_attach(self._ctx, C.c_char_p(unique_id), int(rank), int(nranks)))
+
+    def comm_detach(self):
+        self._ck(self._L.cmx_comm_detach(self._ctx))
+
     def set_grad_buffer(self, device_ptr, n_doubles):
         self._ck(self._L.cmx_set_grad_buffer(self._ctx, C.c_void_p(device_ptr), int(n_doubles)))
 

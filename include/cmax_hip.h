@@ -180,6 +180,17 @@ void *cmx_grad_ptr(const cmx_ctx *ctx);
 size_t cmx_grad_count(const cmx_ctx *ctx);
 int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
 
+/* Native exchange: attach an RCCL communicator to the context (one process per GPU) and every cmx_*_eval / cmx_*_solve
+ * performs the all-reduces itself, in place, on the context's stream -- partial planes after the splat, and the 2P
+ * partial gradient sums after the gather pass (adjoint mode).  All ranks therefore see identical contrast / gradient
+ * and take identical optimiser decisions.  Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher
+ * distributes it by whatever means it has (torch.distributed broadcast in bench.py, MPI, a file).  RCCL is dlopen()ed
+ * at this point only; hosts that never attach a communicator do not need it installed. */
+#define CMX_COMM_ID_BYTES 128
+int cmx_comm_unique_id(char id[CMX_COMM_ID_BYTES]);
+int cmx_comm_attach(cmx_ctx *ctx, const char id[CMX_COMM_ID_BYTES], int rank, int nranks);
+int cmx_comm_detach(cmx_ctx *ctx);
+
 /* ------------------------------------------------------------------ optimiser driver (host C++) ----------
  * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors
  * (src/frontend/local_optim_contrast_gsl.cpp:74-233, src/backend/global_optim_contrast_gsl.cpp:15-145).  These

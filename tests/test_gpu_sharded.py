@@ -140,3 +140,39 @@ def test_sharded_evaluator_over_nccl_world1(hip, oracle):
             assert rel_vec(g, g_ref) < RTOL
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_communicator_world1(hip, oracle):
+    """cmx_comm_attach with a 1-rank RCCL communicator: every evaluation (and the C++ solver) issues its ncclAllReduce
+    calls from inside the evaluator; results must be unchanged."""
+    p = synth.frontend_packet(30_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=43)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for fast in (True, False):
+        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        if fast:
+            fe.set_fast_path()
+        fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+        fe.comm_attach(fe.comm_unique_id(), 0, 1)
+        for om in ((0.3, -0.5, 0.2), (0.1, 0.2, 0.3)):
+            c_ref, g_ref = ref.eval(om)
+            assert rel_scalar(fe.eval(om, want_grad=False)[0], c_ref) < RTOL
+            c, g = fe.eval(om)   # df right after f at the same point: image reuse + gradient-sum exchange
+            assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
+        x, rep = fe.setupProblemAndOptimize(np.zeros(3))
+        assert rep["final_cost"] < rep["initial_cost"]
+        fe.comm_detach()
+        c, g = fe.eval((0.3, -0.5, 0.2))
+        assert rel_scalar(c, ref.eval((0.3, -0.5, 0.2))[0]) < RTOL
+
+    w = synth.backend_window(30_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 256, 128, 4, 10, 3, 0.35, seed=44)
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be.set_fast_path()
+    be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    be.comm_attach(be.comm_unique_id(), 0, 1)
+    rb = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order)
+    rb.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    d = np.full(w.P, 0.002)
+    c, g = be.eval(d)
+    c_ref, g_ref = rb.eval(d)
+    assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
