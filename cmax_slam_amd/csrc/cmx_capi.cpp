@@ -10,7 +10,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -41,6 +44,8 @@ struct cmx_ctx {
   // packed events
   uint32_t *d_xy = nullptr;
   size_t xy_cap = 0;
+  uint32_t *h_xy = nullptr;  // pinned staging for the packed events (host packing runs on several threads)
+  size_t h_xy_cap = 0;
   int n_packed = 0, per_batch = 1, nb = 0;
   bool have_data = false;
 
@@ -746,12 +751,53 @@ int sync_and_collect(cmx_ctx *c) {
   return CMX_OK;
 }
 
+// split [0, n) over a few host threads (the AoS->SoA packing of millions of events is memory-bound on one core)
+template <typename F>
+void parallel_ranges(int64_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = (int)(hw ? (hw > 8 ? 8 : hw) : 1);
+  if (n < 262144) T = 1;
+  if (T <= 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t per = (n + T - 1) / T;
+  for (int t = 0; t < T; t++) {
+    const int64_t a = (int64_t)t * per, b = (a + per < n) ? a + per : n;
+    if (a >= b) break;
+    th.emplace_back([=] { fn(a, b); });
+  }
+  for (auto &x : th) x.join();
+}
+
 int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
   if (n < 0 || n > 0x7fffffffLL) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
   if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
-  for (int64_t i = 0; i < n; i++)
-    if (x[i] >= c->W || y[i] >= c->H)
-      return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, x[i], y[i], c->W, c->H);
+  const int W = c->W, H = c->H;
+  std::atomic<int64_t> bad(-1);
+  parallel_ranges(n, [&](int64_t a, int64_t b) {
+    unsigned acc = 0;
+    for (int64_t i = a; i < b; i++) acc |= (unsigned)(x[i] >= W) | (unsigned)(y[i] >= H);
+    if (acc)
+      for (int64_t i = a; i < b; i++)
+        if (x[i] >= W || y[i] >= H) {
+          int64_t cur = bad.load();
+          while ((cur < 0 || i < cur) && !bad.compare_exchange_weak(cur, i)) {}
+          break;
+        }
+  });
+  const int64_t i = bad.load();
+  if (i >= 0)
+    return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, x[i], y[i], W, H);
+  return CMX_OK;
+}
+
+int ensure_pinned_xy(cmx_ctx *c, size_t n) {
+  if (n <= c->h_xy_cap && c->h_xy) return CMX_OK;
+  if (c->h_xy) HIP_TRY(c, hipHostFree(c->h_xy));
+  c->h_xy = nullptr;
+  c->h_xy_cap = 0;
+  const size_t cap = n + n / 4 + 1024;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_xy, cap * sizeof(uint32_t), hipHostMallocDefault));
+  c->h_xy_cap = cap;
   return CMX_OK;
 }
 
@@ -791,6 +837,7 @@ void cmx_destroy(cmx_ctx *c) {
   for (auto e : c->event_pool) hipEventDestroy(e);
   hipFree(c->d_lut);
   hipFree(c->d_xy);
+  if (c->h_xy) hipHostFree(c->h_xy);
   hipFree(c->d_batch_dt);
   hipFree(c->d_batch_t);
   hipFree(c->d_poses);
@@ -943,8 +990,13 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
 
   // SoA packing + per-batch dt = time_batch.toSec() - time_ref.toSec()  (local_image_warped_events.cpp:68-75)
   const int nb = (int)((n + event_batch_size - 1) / event_batch_size);
-  std::vector<uint32_t> xy((size_t)n);
-  for (int64_t i = 0; i < n; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging buffer may still feed the previous upload
+  rc = ensure_pinned_xy(c, (size_t)n);
+  if (rc) return rc;
+  uint32_t *xy = c->h_xy;
+  parallel_ranges(n, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+  });
   std::vector<double> dts((size_t)nb);
   const double tref = time_to_sec(t_ref_ns);
   for (int b = 0; b < nb; b++) {
@@ -959,8 +1011,9 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   rc = ensure(c, c->d_batch_dt, c->batch_cap, (size_t)nb);
   if (rc) return rc;
   if (n) {
-    HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpy(c->d_batch_dt, dts.data(), (size_t)nb * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   c->n_packed = (int)n;
   c->per_batch = event_batch_size;
@@ -1120,6 +1173,9 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
                            int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
                            double blur_sigma, int contrast_measure, const float *IG) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  const bool trace = getenv("CMX_TRACE_SETUP") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_0 = now();
   int rc = bind(c);
   if (rc) return rc;
   c->have_data = false;
@@ -1142,22 +1198,53 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   // with stride event_sample_rate restarting at the batch start (:262).
   const int B = event_batch_size, rate = event_sample_rate;
   const int per_batch = (B + rate - 1) / rate;
-  std::vector<uint32_t> xy;
-  std::vector<long long> bt;
-  xy.reserve((size_t)(n / rate + B));
-  for (int64_t beg = 0; beg < n - 1; beg += B) {
-    const int64_t end = (n - beg > B) ? beg + B : n;
-    if (t_ns[end - 1] < t_ns[beg]) return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", (long long)beg);
-    const long long tb = time_batch_ns(t_ns[beg], t_ns[end - 1]);
-    const long long st = tb - start_ns;
-    if (st < 0 || st / dt_ns + order > K)
-      return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", tb, K,
-                  (long long)start_ns, (long long)dt_ns);
-    bt.push_back(tb);
-    for (int64_t e = beg; e < end; e += rate)
-      xy.push_back((uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u));
+  const int64_t nb64 = (n > 1) ? (n - 1 + B - 1) / B : 0;
+  if (nb64 > 0x7fffffffLL) return fail(c, CMX_ERR_INVALID_ARG, "too many batches");
+  const int nbatches = (int)nb64;
+  int64_t n_packed_total = 0;
+  if (nbatches > 0) {
+    const int64_t last_beg = (int64_t)(nbatches - 1) * B;
+    const int64_t last_len = (n - last_beg > B) ? B : (n - last_beg);  // a trailing single event is never in a batch
+    n_packed_total = (int64_t)(nbatches - 1) * per_batch + (last_len + rate - 1) / rate;
   }
-  const int nb = (int)bt.size();
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging buffer may still feed the previous upload
+  rc = ensure_pinned_xy(c, (size_t)n_packed_total);
+  if (rc) return rc;
+  uint32_t *xy = c->h_xy;
+  const double t_1 = now();
+  std::vector<long long> bt((size_t)nbatches);
+  std::atomic<int> err_kind(0);
+  std::atomic<long long> err_at(-1);
+  parallel_ranges(nbatches, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t beg = b * B;
+      const int64_t end = (n - beg > B) ? beg + B : n;
+      if (t_ns[end - 1] < t_ns[beg]) { err_kind = CMX_ERR_TIME_ORDER; err_at = beg; return; }
+      const long long tb = time_batch_ns(t_ns[beg], t_ns[end - 1]);
+      const long long st = tb - start_ns;
+      if (st < 0 || st / dt_ns + order > K) { err_kind = CMX_ERR_SPLINE_RANGE; err_at = tb; return; }
+      bt[(size_t)b] = tb;
+      if (rate == 1) continue;  // packed below by a flat, vectorisable loop (packed index == event index)
+      uint32_t *dst = xy + b * per_batch;
+      for (int64_t e = beg; e < end; e += rate)
+        *dst++ = (uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u);
+    }
+  });
+  if (rate == 1)
+    parallel_ranges(n_packed_total, [&](int64_t a0, int64_t a1) {
+      const uint16_t *__restrict xs = x, *__restrict ys = y;
+      const int64_t *__restrict ts = t_ns;
+      uint32_t *__restrict out = xy;
+      for (int64_t e = a0; e < a1; e++)
+        out[e] = (uint32_t)xs[e] | ((uint32_t)ys[e] << 16) | ((uint32_t)(ts[e] < t_next_win_beg_ns) << 31);
+    });
+  if (err_kind.load() == CMX_ERR_TIME_ORDER)
+    return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", err_at.load());
+  if (err_kind.load() == CMX_ERR_SPLINE_RANGE)
+    return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", err_at.load(), K,
+                (long long)start_ns, (long long)dt_ns);
+  const int nb = nbatches;
+  const double t_2 = now();
   c->order = order; c->K = K; c->num_fixed = num_fixed;
   c->batch = B; c->sample_rate = rate; c->measure = contrast_measure;
   c->knots0.resize((size_t)K);
@@ -1169,8 +1256,7 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   c->h_spline->dt_ns = dt_ns;
   blending_matrix(order, c->h_spline->blend);
 
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  rc = ensure(c, c->d_xy, c->xy_cap, xy.size());
+  rc = ensure(c, c->d_xy, c->xy_cap, (size_t)n_packed_total);
   if (rc) return rc;
   rc = ensure(c, c->d_batch_t, c->batch_t_cap, (size_t)nb);
   if (rc) return rc;
@@ -1178,16 +1264,20 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (rc) return rc;
   rc = ensure(c, c->d_poseR, c->poseR_cap, (size_t)nb);
   if (rc) return rc;
-  if (!xy.empty()) HIP_TRY(c, hipMemcpy(c->d_xy, xy.data(), xy.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (n_packed_total > 0)
+    HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n_packed_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
   const size_t np = (size_t)c->Wp * c->Hp;
   if (IG == CMX_KEEP_MAP) {
     c->ig_nonzero = true;  // resident map: contents unknown to the host; the alpha kernel counts the non-zeros itself
   } else if (IG) {
     HIP_TRY(c, hipMemcpy(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice));
-    c->ig_nonzero = false;
-    for (size_t i = 0; i < np; i++)
-      if (IG[i] != 0.f) { c->ig_nonzero = true; break; }
+    std::atomic<bool> nz(false);
+    parallel_ranges((int64_t)np, [&](int64_t a0, int64_t a1) {
+      for (int64_t i = a0; i < a1 && !nz.load(std::memory_order_relaxed); i++)
+        if (IG[i] != 0.f) nz = true;
+    });
+    c->ig_nonzero = nz.load();
   } else {
     HIP_TRY(c, hipMemset(c->d_IG, 0, np * sizeof(float)));
     c->ig_nonzero = false;
@@ -1195,7 +1285,9 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
   c->h_result[4095] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
-  c->n_packed = (int)xy.size();
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (trace) fprintf(stderr, "[cmx] set_window: validate+setup %.3f ms, pack %.3f ms, upload+map %.3f ms\n", t_1 - t_0, t_2 - t_1, now() - t_2);
+  c->n_packed = (int)n_packed_total;
   c->per_batch = per_batch;
   c->nb = nb;
   c->have_data = true;
