@@ -49,6 +49,17 @@ SYMBOLS = {
     "cmx_backend_reset_map": (C.c_int, [ctx_p]),
     "cmx_backend_get_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
     "cmx_backend_set_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
+    "cmx_events_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_size_t]),
+    "cmx_events_destroy": (None, [C.c_void_p]),
+    "cmx_events_last_error": (C.c_char_p, [C.c_void_p]),
+    "cmx_events_push": (C.c_int, [C.c_void_p, C.c_int64, c_u16p, c_u16p, c_i64p]),
+    "cmx_events_drop_before": (C.c_int, [C.c_void_p, C.c_int64]),
+    "cmx_events_begin": (C.c_int64, [C.c_void_p]),
+    "cmx_events_end": (C.c_int64, [C.c_void_p]),
+    "cmx_frontend_set_packet_from": (C.c_int, [ctx_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                               C.c_double, C.c_double, C.c_int, C.c_double, C.c_int]),
+    "cmx_backend_set_window_from": (C.c_int, [ctx_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_dp, C.c_int64,
+                                              C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, c_fp]),
     "cmx_traj_temp_start_ns": (C.c_int64, [C.c_double, C.c_int, C.c_double]),
     "cmx_accum_capacity": (C.c_size_t, [ctx_p]),
     "cmx_set_accum_buffer": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),

@@ -146,6 +146,20 @@ struct cmx_ctx {
   int64_t t_n[CMX_T_COUNT] = {0};
 };
 
+// device-resident event store: the stream is uploaded once; packets and windows are
+// cut from it on the device
+struct cmx_events {
+  int device = 0, W = 0, H = 0;
+  size_t capacity = 0;
+  int64_t first_index = 0;   // global sequence number of slot 0
+  size_t size = 0;           // events held
+  uint32_t *d_xy[2] = {nullptr, nullptr};  // x | y << 16 ; two buffers: drop_before compacts into the other one
+  int64_t *d_t[2] = {nullptr, nullptr};
+  int cur = 0;
+  std::vector<int64_t> h_t;  // host mirror of the timestamps (per-batch pose times are formed on the host)
+  std::string err;
+};
+
 namespace {
 
 int fail(cmx_ctx *c, int code, const char *fmt, ...) {
@@ -968,9 +982,11 @@ int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *l
   return CMX_OK;
 }
 
-int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
-                            int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
-                            double blur_sigma, int contrast_measure) {
+// d_raw != nullptr: the events are already on the device (event store), x / y are unused and t_ns is the store's
+// host mirror of the timestamps
+static int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                              const uint32_t *d_raw, int64_t t_ref_ns, double fx, double fy, double cx, double cy,
+                              int event_batch_size, double blur_sigma, int contrast_measure) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   int rc = bind(c);
   if (rc) return rc;
@@ -980,8 +996,12 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
   // computeContrast's switch (local_focus_funcs.cpp:98-109): 1 = mean square, 2 = gradient magnitude, default = variance
   if (contrast_measure != CMX_MEAN_SQUARE && contrast_measure != CMX_GRADIENT_MAGNITUDE) contrast_measure = CMX_VARIANCE;
-  rc = check_events(c, n, x, y, t_ns);
-  if (rc) return rc;
+  if (!d_raw) {
+    rc = check_events(c, n, x, y, t_ns);
+    if (rc) return rc;
+  } else if (n < 0 || n > 0x7fffffffLL) {
+    return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
+  }
   rc = setup_blur(c, blur_sigma);
   if (rc) return rc;
   c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy;
@@ -991,12 +1011,15 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   // SoA packing + per-batch dt = time_batch.toSec() - time_ref.toSec()  (local_image_warped_events.cpp:68-75)
   const int nb = (int)((n + event_batch_size - 1) / event_batch_size);
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging buffer may still feed the previous upload
-  rc = ensure_pinned_xy(c, (size_t)n);
-  if (rc) return rc;
-  uint32_t *xy = c->h_xy;
-  parallel_ranges(n, [&](int64_t a, int64_t b) {
-    for (int64_t i = a; i < b; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
-  });
+  uint32_t *xy = nullptr;
+  if (!d_raw) {
+    rc = ensure_pinned_xy(c, (size_t)n);
+    if (rc) return rc;
+    xy = c->h_xy;
+    parallel_ranges(n, [&](int64_t a, int64_t b) {
+      for (int64_t i = a; i < b; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+    });
+  }
   std::vector<double> dts((size_t)nb);
   const double tref = time_to_sec(t_ref_ns);
   for (int b = 0; b < nb; b++) {
@@ -1011,7 +1034,8 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   rc = ensure(c, c->d_batch_dt, c->batch_cap, (size_t)nb);
   if (rc) return rc;
   if (n) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (d_raw) HIP_TRY(c, hipMemcpyAsync(c->d_xy, d_raw, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpy(c->d_batch_dt, dts.data(), (size_t)nb * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
@@ -1021,6 +1045,12 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   c->have_data = true;
   c->bin_valid = false;
   return CMX_OK;
+}
+
+int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                            int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
+                            double blur_sigma, int contrast_measure) {
+  return fe_set_packet_impl(c, n, x, y, t_ns, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma, contrast_measure);
 }
 
 static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
@@ -1168,10 +1198,11 @@ int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lu
   return CMX_OK;
 }
 
-int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
-                           int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
-                           int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
-                           double blur_sigma, int contrast_measure, const float *IG) {
+static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                              const uint32_t *d_raw, const int64_t *d_t, int order, int K, const double *knots_xyzw,
+                              int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                              int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure,
+                              const float *IG) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   const bool trace = getenv("CMX_TRACE_SETUP") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1188,8 +1219,12 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (event_batch_size <= 0 || event_sample_rate <= 0) return fail(c, CMX_ERR_INVALID_ARG, "batch size / sample rate must be > 0");
   // the back end's switch (global_focus_funcs.cpp:61-69) knows mean square only; everything else is variance
   if (contrast_measure != CMX_MEAN_SQUARE) contrast_measure = CMX_VARIANCE;
-  rc = check_events(c, n, x, y, t_ns);
-  if (rc) return rc;
+  if (!d_raw) {
+    rc = check_events(c, n, x, y, t_ns);
+    if (rc) return rc;
+  } else if (n < 0 || n > 0x7fffffffLL) {
+    return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
+  }
   rc = setup_blur(c, blur_sigma);
   if (rc) return rc;
 
@@ -1208,9 +1243,12 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
     n_packed_total = (int64_t)(nbatches - 1) * per_batch + (last_len + rate - 1) / rate;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging buffer may still feed the previous upload
-  rc = ensure_pinned_xy(c, (size_t)n_packed_total);
-  if (rc) return rc;
-  uint32_t *xy = c->h_xy;
+  uint32_t *xy = nullptr;
+  if (!d_raw) {
+    rc = ensure_pinned_xy(c, (size_t)n_packed_total);
+    if (rc) return rc;
+    xy = c->h_xy;
+  }
   const double t_1 = now();
   std::vector<long long> bt((size_t)nbatches);
   std::atomic<int> err_kind(0);
@@ -1224,13 +1262,13 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
       const long long st = tb - start_ns;
       if (st < 0 || st / dt_ns + order > K) { err_kind = CMX_ERR_SPLINE_RANGE; err_at = tb; return; }
       bt[(size_t)b] = tb;
-      if (rate == 1) continue;  // packed below by a flat, vectorisable loop (packed index == event index)
+      if (rate == 1 || d_raw) continue;  // packed below by a flat, vectorisable loop (packed index == event index) / on the device
       uint32_t *dst = xy + b * per_batch;
       for (int64_t e = beg; e < end; e += rate)
         *dst++ = (uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u);
     }
   });
-  if (rate == 1)
+  if (rate == 1 && !d_raw)
     parallel_ranges(n_packed_total, [&](int64_t a0, int64_t a1) {
       const uint16_t *__restrict xs = x, *__restrict ys = y;
       const int64_t *__restrict ts = t_ns;
@@ -1264,8 +1302,13 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   if (rc) return rc;
   rc = ensure(c, c->d_poseR, c->poseR_cap, (size_t)nb);
   if (rc) return rc;
-  if (n_packed_total > 0)
-    HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n_packed_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  if (n_packed_total > 0) {
+    if (d_raw)
+      launch_be_pack_from_store(d_raw, reinterpret_cast<const long long *>(d_t), (long long)n, B, rate, per_batch,
+                                (int)n_packed_total, (long long)t_next_win_beg_ns, c->d_xy, c->stream);
+    else
+      HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n_packed_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
   if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
   const size_t np = (size_t)c->Wp * c->Hp;
   if (IG == CMX_KEEP_MAP) {
@@ -1293,6 +1336,122 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
   c->have_data = true;
   c->bin_valid = false;
   return CMX_OK;
+}
+
+int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                           int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
+                           int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
+                           double blur_sigma, int contrast_measure, const float *IG) {
+  return be_set_window_impl(c, n, x, y, t_ns, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed,
+                            t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
+}
+
+// ---- device-resident event store -------------------------------------------------------------------------------
+static int efail(cmx_events *e, int code, const char *msg) {
+  if (e) e->err = msg;
+  return code;
+}
+int cmx_events_create(cmx_events **out, int device, int W, int H, size_t capacity) {
+  if (!out) return CMX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || capacity == 0 || capacity > 0x7fffffffULL) return CMX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CMX_ERR_HIP;
+  if (device < 0 || device >= ndev) return CMX_ERR_INVALID_ARG;
+  cmx_events *e = new cmx_events();
+  e->device = device; e->W = W; e->H = H; e->capacity = capacity;
+  *out = e;
+  if (hipSetDevice(device) != hipSuccess) return efail(e, CMX_ERR_HIP, "hipSetDevice failed");
+  for (int k = 0; k < 2; k++) {
+    if (hipMalloc((void **)&e->d_xy[k], capacity * sizeof(uint32_t)) != hipSuccess) return efail(e, CMX_ERR_HIP, "hipMalloc failed");
+    if (hipMalloc((void **)&e->d_t[k], capacity * sizeof(int64_t)) != hipSuccess) return efail(e, CMX_ERR_HIP, "hipMalloc failed");
+  }
+  e->h_t.reserve(capacity);
+  return CMX_OK;
+}
+void cmx_events_destroy(cmx_events *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  for (int k = 0; k < 2; k++) { hipFree(e->d_xy[k]); hipFree(e->d_t[k]); }
+  delete e;
+}
+const char *cmx_events_last_error(const cmx_events *e) { return e ? e->err.c_str() : "null event store"; }
+int64_t cmx_events_begin(const cmx_events *e) { return e ? e->first_index : 0; }
+int64_t cmx_events_end(const cmx_events *e) { return e ? e->first_index + (int64_t)e->size : 0; }
+
+// append a chunk of the (time-ordered) stream: AngVelEstimator::pushEvent's events_.push_back (ang_vel_estimator.cpp:68-78)
+int cmx_events_push(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns) {
+  if (!e || n < 0 || (n > 0 && (!x || !y || !t_ns))) return efail(e, CMX_ERR_INVALID_ARG, "bad arguments");
+  if (e->size + (size_t)n > e->capacity) return efail(e, CMX_ERR_INVALID_ARG, "event store full: drop old events first");
+  if (hipSetDevice(e->device) != hipSuccess) return efail(e, CMX_ERR_HIP, "hipSetDevice failed");
+  std::vector<uint32_t> xy((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    if (x[i] >= e->W || y[i] >= e->H) return efail(e, CMX_ERR_EVENT_RANGE, "event coordinates outside the sensor");
+    xy[(size_t)i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+  }
+  if (n) {
+    if (hipMemcpy(e->d_xy[e->cur] + e->size, xy.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_t[e->cur] + e->size, t_ns, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
+      return efail(e, CMX_ERR_HIP, "upload failed");
+    e->h_t.insert(e->h_t.end(), t_ns, t_ns + n);
+    e->size += (size_t)n;
+  }
+  return CMX_OK;
+}
+
+// AngVelEstimator::deleteOldEvents (ang_vel_estimator.cpp:149-173): forget everything before a global index
+int cmx_events_drop_before(cmx_events *e, int64_t global_index) {
+  if (!e) return CMX_ERR_INVALID_ARG;
+  if (global_index <= e->first_index) return CMX_OK;
+  if (global_index > e->first_index + (int64_t)e->size) return efail(e, CMX_ERR_INVALID_ARG, "index beyond the stored events");
+  if (hipSetDevice(e->device) != hipSuccess) return efail(e, CMX_ERR_HIP, "hipSetDevice failed");
+  const size_t k = (size_t)(global_index - e->first_index), keep = e->size - k;
+  const int other = 1 - e->cur;
+  if (keep) {
+    if (hipMemcpy(e->d_xy[other], e->d_xy[e->cur] + k, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(e->d_t[other], e->d_t[e->cur] + k, keep * sizeof(int64_t), hipMemcpyDeviceToDevice) != hipSuccess)
+      return efail(e, CMX_ERR_HIP, "compaction failed");
+  }
+  e->h_t.erase(e->h_t.begin(), e->h_t.begin() + (ptrdiff_t)k);
+  e->cur = other;
+  e->size = keep;
+  e->first_index = global_index;
+  return CMX_OK;
+}
+
+static int store_range(cmx_ctx *c, const cmx_events *e, int64_t first, int64_t count, size_t *off) {
+  if (!e) return fail(c, CMX_ERR_INVALID_ARG, "null event store");
+  if (!c) return CMX_ERR_INVALID_ARG;
+  if (e->device != c->device || e->W != c->W || e->H != c->H)
+    return fail(c, CMX_ERR_INVALID_ARG, "event store belongs to another device / sensor");
+  if (count < 0 || first < e->first_index || first + count > e->first_index + (int64_t)e->size)
+    return fail(c, CMX_ERR_INVALID_ARG, "range [%lld, %lld) is not held by the event store [%lld, %lld)", (long long)first,
+                (long long)(first + count), (long long)e->first_index, (long long)(e->first_index + (int64_t)e->size));
+  *off = (size_t)(first - e->first_index);
+  return CMX_OK;
+}
+
+// packets / windows cut from the store: events_[first, first+count), exactly what getEventSubset copies
+// (ang_vel_estimator.cpp:137-147, pose_graph_optimizer.cpp:131-165), without leaving the device
+int cmx_frontend_set_packet_from(cmx_ctx *c, const cmx_events *e, int64_t first, int64_t count, int64_t t_ref_ns, double fx,
+                                 double fy, double cx, double cy, int event_batch_size, double blur_sigma,
+                                 int contrast_measure) {
+  size_t off = 0;
+  int rc = store_range(c, e, first, count, &off);
+  if (rc) return rc;
+  return fe_set_packet_impl(c, count, nullptr, nullptr, e->h_t.data() + off, e->d_xy[e->cur] + off, t_ref_ns, fx, fy, cx, cy,
+                            event_batch_size, blur_sigma, contrast_measure);
+}
+int cmx_backend_set_window_from(cmx_ctx *c, const cmx_events *e, int64_t first, int64_t count, int order, int K,
+                                const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed,
+                                int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate, double blur_sigma,
+                                int contrast_measure, const float *IG) {
+  size_t off = 0;
+  int rc = store_range(c, e, first, count, &off);
+  if (rc) return rc;
+  return be_set_window_impl(c, count, nullptr, nullptr, e->h_t.data() + off, e->d_xy[e->cur] + off, e->d_t[e->cur] + off, order,
+                            K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
+                            event_sample_rate, blur_sigma, contrast_measure, IG);
 }
 
 static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {

@@ -175,6 +175,10 @@ struct SobelArgs {
 void launch_sobel_moments(const SobelArgs &a, hipStream_t s);
 int sobel_blocks(int W, int H);
 
+// back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
+void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,
+                               int n_packed, long long t_next, uint32_t *out, hipStream_t s);
+
 // global-map upkeep (once per window)
 void launch_update_map(float *IG, const float *IL_old, const unsigned char *visits, int npix, int max_update_times,
                        hipStream_t s);

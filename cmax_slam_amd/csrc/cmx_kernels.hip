@@ -798,6 +798,21 @@ void launch_alpha(const AlphaArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(alpha_finalize_kernel, dim3(1), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------- event store
+// packed slot j = batch b (= j / per_batch), k-th sample of the batch: raw event b*B + k*rate  (event_pano_warper.cpp:188-196,262)
+__global__ void be_pack_from_store_kernel(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,
+                                          int n_packed, long long t_next, uint32_t *out) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_packed; j += gridDim.x * blockDim.x) {
+    const int b = j / per_batch, k = j - b * per_batch;
+    const long long e = (long long)b * B + (long long)k * rate;
+    out[j] = raw[e] | ((t[e] < t_next) ? 0x80000000u : 0u);
+  }
+}
+void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,
+                               int n_packed, long long t_next, uint32_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(be_pack_from_store_kernel, dim3(2048), dim3(256), 0, s, raw, t, n, B, rate, per_batch, n_packed, t_next, out);
+}
+
 // ---------------------------------------------------------------------------------------------- Sobel moments
 // contrast_ImageGradientMagnitude (reference local_focus_funcs.cpp:47-73): cv::Sobel 3x3 (REFLECT_101) of the
 // blurred IWE and of each blurred derivative channel; contrast = mean(gx^2+gy^2), grad_k = 2 mean(gx*dgx_k + gy*dgy_k).

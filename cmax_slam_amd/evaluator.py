@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import (GRAD_ADJOINT, GRAD_PLANES, MEAN_SQUARE, VARIANCE, CmaxHipError, c_dp, c_fp, c_i64p, c_u16p,
                    check)
 
-__all__ = ["FrontendEvaluator", "BackendEvaluator", "CmaxHipError", "VARIANCE", "MEAN_SQUARE", "GRAD_PLANES",
+__all__ = ["FrontendEvaluator", "BackendEvaluator", "EventStore", "CmaxHipError", "VARIANCE", "MEAN_SQUARE", "GRAD_PLANES",
            "GRAD_ADJOINT"]
 
 
@@ -142,6 +142,48 @@ class _Evaluator:
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.T_NAMES)}
 
 
+class EventStore:
+    """Device-resident copy of the event stream (the reference's AngVelEstimator::events_): push chunks as they
+    arrive, cut packets / windows from it by global event index, drop the prefix like deleteOldEvents."""
+
+    def __init__(self, W, H, capacity, device=0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        check(None, self._L.cmx_events_create(C.byref(self._h), int(device), int(W), int(H), int(capacity)))
+
+    def _ck(self, status):
+        if status != _lib.OK:
+            raise CmaxHipError(status, self._L.cmx_status_string(status).decode() + ": " +
+                               self._L.cmx_events_last_error(self._h).decode())
+
+    def push(self, x, y, t_ns):
+        x, y, t = _c(x, np.uint16), _c(y, np.uint16), _c(t_ns, np.int64)
+        self._ck(self._L.cmx_events_push(self._h, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p),
+                                         t.ctypes.data_as(c_i64p)))
+
+    def drop_before(self, global_index):
+        self._ck(self._L.cmx_events_drop_before(self._h, int(global_index)))
+
+    @property
+    def begin(self):
+        return int(self._L.cmx_events_begin(self._h))
+
+    @property
+    def end(self):
+        return int(self._L.cmx_events_end(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cmx_events_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrontendEvaluator(_Evaluator):
     def __init__(self, W, H, lut, device=0):
         super().__init__()
@@ -162,6 +204,14 @@ class FrontendEvaluator(_Evaluator):
             int(t_ref_ns), float(fx), float(fy), float(cx), float(cy), int(event_batch_size), float(blur_sigma),
             int(contrast_measure)))
         self.n_events = len(x)
+
+    def set_packet_from(self, store, first, count, t_ref_ns, fx, fy, cx, cy, event_batch_size=100, blur_sigma=1.0,
+                        contrast_measure=VARIANCE):
+        """The packet events_[first, first+count) cut from a device-resident EventStore (no host copy)."""
+        self._ck(self._L.cmx_frontend_set_packet_from(self._ctx, store._h, int(first), int(count), int(t_ref_ns), float(fx),
+                                                      float(fy), float(cx), float(cy), int(event_batch_size),
+                                                      float(blur_sigma), int(contrast_measure)))
+        self.n_events = int(count)
 
     def eval(self, ang_vel, want_grad=True):
         """(contrast, gradient[3] | None) -- what computeContrast returns."""
@@ -240,6 +290,19 @@ class BackendEvaluator(_Evaluator):
             self._ctx, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p), t.ctypes.data_as(c_i64p),
             int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns),
             int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
+            C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
+        self.K, self.num_fixed = k.shape[0], int(num_fixed)
+
+    def set_window_from(self, store, first, count, order, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns,
+                        event_batch_size=100, event_sample_rate=1, blur_sigma=1.0, contrast_measure=VARIANCE, IG=None):
+        """The window events_[first, first+count) cut from a device-resident EventStore."""
+        k = _c(knots_xyzw, np.float64).reshape(-1, 4)
+        keep = isinstance(IG, str) and IG == "resident"
+        ig = _c(IG, np.float32) if (IG is not None and not keep) else None
+        self._ck(self._L.cmx_backend_set_window_from(
+            self._ctx, store._h, int(first), int(count), int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns),
+            int(num_fixed), int(t_next_win_beg_ns), int(event_batch_size), int(event_sample_rate), float(blur_sigma),
+            int(contrast_measure),
             C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
         self.K, self.num_fixed = k.shape[0], int(num_fixed)
 

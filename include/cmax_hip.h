@@ -149,6 +149,31 @@ int cmx_backend_set_map(cmx_ctx *ctx, const float *IG, const unsigned char *visi
 /* int64_t(1e9 * (t_beg + idx_traj_beg*dt_knots)) -- the (double)->ns truncation of trajectory.cpp:255-256 */
 int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots);
 
+/* ------------------------------------------------------------------ device-resident event store -----------
+ * SURVEY.md section 8f rank 3.  The reference keeps the stream in AngVelEstimator::events_ and copies a packet
+ * (src/frontend/ang_vel_estimator.cpp:137-147) or a window (src/backend/pose_graph_optimizer.cpp:131-165) out of it for
+ * every solve; consecutive packets and windows overlap heavily.  With a store the stream is uploaded ONCE
+ * (cmx_events_push as events arrive), packets / windows are cut from it on the device by global event index, and
+ * cmx_events_drop_before is deleteOldEvents (ang_vel_estimator.cpp:149-173).  Results are identical to
+ * cmx_frontend_set_packet / cmx_backend_set_window on the same events.  One store per GPU, shared by the front-end and
+ * back-end contexts of that GPU; not thread-safe (serialise push/drop against set_*_from, as the reference does with
+ * mutex_events). */
+typedef struct cmx_events cmx_events;
+int cmx_events_create(cmx_events **out, int device, int W, int H, size_t capacity);
+void cmx_events_destroy(cmx_events *ev);
+const char *cmx_events_last_error(const cmx_events *ev);
+int cmx_events_push(cmx_events *ev, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns);
+int cmx_events_drop_before(cmx_events *ev, int64_t global_index);
+int64_t cmx_events_begin(const cmx_events *ev); /* global index of the oldest event held */
+int64_t cmx_events_end(const cmx_events *ev);   /* one past the newest */
+int cmx_frontend_set_packet_from(cmx_ctx *ctx, const cmx_events *ev, int64_t first, int64_t count, int64_t t_ref_ns,
+                                 double fx, double fy, double cx, double cy, int event_batch_size, double blur_sigma,
+                                 int contrast_measure);
+int cmx_backend_set_window_from(cmx_ctx *ctx, const cmx_events *ev, int64_t first, int64_t count, int order, int K,
+                                const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed,
+                                int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
+                                double blur_sigma, int contrast_measure, const float *IG);
+
 /* ------------------------------------------------------------------ split-phase (multi-GPU) ------------
  * The IWE is a sum over events, the contrast a non-linear function of the SUMMED image, so ranks exchange
  * between splat and blur/reduce.  Each rank loads its contiguous range of event
