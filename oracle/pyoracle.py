@@ -190,6 +190,7 @@ class Frontend:
         return c.value, (g if want_grad else None)
 
 
+
 # ----------------------------------------------------------------------------- spline
 def spline_eval(order, knots_xyzw, start_ns, dt_ns, t_ns, jac=True, use_ref=False):
     k = _c(knots_xyzw, np.float64).reshape(-1, 4)
