@@ -660,8 +660,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
     a.alpha = c->d_alpha;
   }
   a.P = 0;
-  a.tiles_x = (W + kTileX - 1) / kTileX;
-  a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  a.tiles_x = image_adjoint_tiles_x(W);
+  a.nblk = image_adjoint_tiles(W, H);
   if (phase != 2 && c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
     a.zero_ptr = c->d_accum_alt;
     a.zero_planes = c->pingpong_planes;

@@ -75,6 +75,8 @@ struct ImgAdjArgs {
   float *jt;        // out: G^T B^  (W*H)
 };
 size_t image_adjoint_lds_bytes(int r);
+int image_adjoint_tiles_x(int W);
+int image_adjoint_tiles(int W, int H);
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s);
 
 struct FeGatherArgs {

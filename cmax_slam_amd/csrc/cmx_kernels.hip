@@ -416,16 +416,19 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------- fused image + adjoint
-// One workgroup = one 64x16 tile of Jt = G^T B^.  It needs B on the tile + r halo, hence the raw image on the tile +
+// One workgroup = one TX x TY tile of Jt = G^T B^.  It needs B on the tile + r halo, hence the raw image on the tile +
 // 2r halo; the moments of B are taken over the tile's own pixels only, so every pixel is counted once.
+// Tile shape / workgroup size are template parameters (tuned on MI355X: tools/ablate notes in DESIGN.md section 6).
+constexpr int kAdjTX = 64, kAdjTY = 16, kAdjThreads = 1024;
+
 size_t image_adjoint_lds_bytes(int r) {
-  const size_t aw = kTileX + 4 * r, ah = kTileY + 4 * r, bw = kTileX + 2 * r, bh = kTileY + 2 * r;
-  return sizeof(double) * 16 + sizeof(float) * (aw * ah + bw * ah + bw * bh + (size_t)kTileX * bh);
+  const size_t aw = kAdjTX + 4 * r, ah = kAdjTY + 4 * r, bw = kAdjTX + 2 * r, bh = kAdjTY + 2 * r;
+  return sizeof(double) * 16 + sizeof(float) * (aw * ah + bw * ah + bw * bh + (size_t)kAdjTX * bh);
 }
+int image_adjoint_tiles_x(int W) { return (W + kAdjTX - 1) / kAdjTX; }
+int image_adjoint_tiles(int W, int H) { return image_adjoint_tiles_x(W) * ((H + kAdjTY - 1) / kAdjTY); }
 
-constexpr int kAdjThreads = 1024;  // 16 waves per tile: the phases are LDS-latency bound, more waves per SIMD hide it
-
-// block-wide sum for kAdjThreads threads; result valid in every thread.  red: 16 doubles of LDS.
+// block-wide sum for NT threads; result valid in every thread.  red: 16 doubles of LDS.
 __device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves) {
   v = wave_sum(v);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -437,8 +440,8 @@ __device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves)
   return s;
 }
 
-template <int R>
-__global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g) {
+template <int R, int TX, int TY, int NT>
+__global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const ImgArgs &a = g.img;
   const int r = (R >= 0) ? R : a.r;
@@ -446,25 +449,25 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
   float taps[2 * kMaxRadius + 1];
 #pragma unroll
   for (int j = 0; j < 2 * kMaxRadius + 1; j++) taps[j] = (R < 0 || j <= 2 * R) ? a.taps[j] : 0.f;
-  const int aw = kTileX + 4 * r, ah = kTileY + 4 * r, bw = kTileX + 2 * r, bh = kTileY + 2 * r;
+  const int aw = TX + 4 * r, ah = TY + 4 * r, bw = TX + 2 * r, bh = TY + 2 * r;
   double *red = reinterpret_cast<double *>(smem_raw);
   float *bufA = reinterpret_cast<float *>(smem_raw + 16 * sizeof(double));  // raw, aw x ah
-  float *bufR = bufA + aw * ah;                                            // row-blurred raw, bw x ah
-  float *bufB = bufR + bw * ah;                                            // B^ (0 outside the image), bw x bh
-  float *bufT = bufB + bw * bh;                                            // row pass of G^T, kTileX x bh
+  float *bufR = bufA + aw * ah;                                             // row-blurred raw, bw x ah
+  float *bufB = bufR + bw * ah;                                             // B^ (0 outside the image), bw x bh
+  float *bufT = bufB + bw * bh;                                             // row pass of G^T, TX x bh
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
-  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
+  const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
   if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
-    for (int idx = tid; idx < kTileX * kTileY * a.zero_planes; idx += kAdjThreads) {
-      const int pl = idx / (kTileX * kTileY), q = idx - pl * (kTileX * kTileY);
-      const int gx = x0 + (q & 63), gy = y0 + (q >> 6);
+    for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
+      const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
+      const int gx = x0 + (q % TX), gy = y0 + (q / TX);
       if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
     }
   }
 
-  for (int idx = tid; idx < aw * ah; idx += kAdjThreads) {
+  for (int idx = tid; idx < aw * ah; idx += NT) {
     const int ly = idx / aw, lx = idx - ly * aw;
     const int gx = reflect101(x0 + lx - 2 * r, W), gy = reflect101(y0 + ly - 2 * r, H);
     const size_t off = (size_t)gy * W + gx;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
     bufA[idx] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < bw * ah; idx += kAdjThreads) {  // forward row pass (same op order as image_moments)
+  for (int idx = tid; idx < bw * ah; idx += NT) {  // forward row pass (same op order as image_moments)
     const int ly = idx / bw, lx = idx - ly * bw;
     const float *S = bufA + ly * aw + lx;
     float s = taps[0] * S[0];
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
   }
   __syncthreads();
   double sI = 0, sII = 0;
-  for (int idx = tid; idx < bw * bh; idx += kAdjThreads) {  // forward column pass -> B on tile + r halo
+  for (int idx = tid; idx < bw * bh; idx += NT) {  // forward column pass -> B on tile + r halo
     const int ly = idx / bw, lx = idx - ly * bw;
     const float *T = bufR + (ly + r) * bw + lx;
     float s = taps[r] * T[0];
@@ -493,22 +496,22 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
     const int gx = x0 + lx - r, gy = y0 + ly - r;
     const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
     bufB[idx] = inside ? s : 0.f;
-    if (inside && lx >= r && lx < r + kTileX && ly >= r && ly < r + kTileY) {
+    if (inside && lx >= r && lx < r + TX && ly >= r && ly < r + TY) {
       sI += (double)s;
       sII += (double)s * (double)s;
       if (a.out_blur0) a.out_blur0[(size_t)gy * W + gx] = s;
     }
   }
   {
-    const double t0 = block_sum_n(sI, red, kAdjThreads / 64), t1 = block_sum_n(sII, red, kAdjThreads / 64);
+    const double t0 = block_sum_n(sI, red, NT / 64), t1 = block_sum_n(sII, red, NT / 64);
     if (tid == 0) {
       a.partials[(size_t)0 * a.nblk + tile] = t0;
       a.partials[(size_t)1 * a.nblk + tile] = t1;
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < kTileX * bh; idx += kAdjThreads) {  // G^T row pass: zero-padded conv + folded reflections
-    const int ly = idx >> 6, lx = idx & 63;
+  for (int idx = tid; idx < TX * bh; idx += NT) {  // G^T row pass: zero-padded conv + folded reflections
+    const int ly = idx / TX, lx = idx - ly * TX;
     const float *S = bufB + ly * bw + lx;
     float s = taps[0] * S[0];
 #pragma unroll
@@ -524,21 +527,21 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
     bufT[idx] = s;
   }
   __syncthreads();
-  for (int idx = tid; idx < kTileX * kTileY; idx += kAdjThreads) {
-    const int tx = idx & 63, ty = idx >> 6;
+  for (int idx = tid; idx < TX * TY; idx += NT) {
+    const int ty = idx / TX, tx = idx - ty * TX;
     const int gy = y0 + ty, gx = x0 + tx;
     if (gx < W && gy < H) {
       const int ly = ty + r;
-      const float *T = bufT + ly * kTileX + tx;
+      const float *T = bufT + ly * TX + tx;
       float s = taps[r] * T[0];
 #pragma unroll
-      for (int t = 1; t <= r; t++) s += taps[r + t] * (T[t * kTileX] + T[-t * kTileX]);
+      for (int t = 1; t <= r; t++) s += taps[r + t] * (T[t * TX] + T[-t * TX]);
       const float *Tcol = bufT + tx;  // row of global y is (y - y0 + r)
       if (1 <= gy && gy <= r)
-        for (int m = 0; m <= r - gy; m++) s += taps[r + gy + m] * Tcol[(m - y0 + r) * kTileX];
+        for (int m = 0; m <= r - gy; m++) s += taps[r + gy + m] * Tcol[(m - y0 + r) * TX];
       if (H - 1 - r <= gy && gy <= H - 2) {
         const int d = H - 1 - gy;
-        for (int m = 0; m <= r - d; m++) s += taps[r + d + m] * Tcol[((H - 1 - m) - y0 + r) * kTileX];
+        for (int m = 0; m <= r - d; m++) s += taps[r + d + m] * Tcol[((H - 1 - m) - y0 + r) * TX];
       }
       g.jt[(size_t)gy * W + gx] = s;
     }
@@ -547,13 +550,15 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint_kernel(ImgAdjArgs g
 
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s) {
   if (a.img.r == 4)
-    hipLaunchKernelGGL(image_adjoint_kernel<4>, dim3(a.img.nblk), dim3(kAdjThreads), image_adjoint_lds_bytes(4), s, a);
+    hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads>), dim3(a.img.nblk), dim3(kAdjThreads),
+                       image_adjoint_lds_bytes(4), s, a);
   else
-    hipLaunchKernelGGL(image_adjoint_kernel<-1>, dim3(a.img.nblk), dim3(kAdjThreads), image_adjoint_lds_bytes(a.img.r), s, a);
+    hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads>), dim3(a.img.nblk), dim3(kAdjThreads),
+                       image_adjoint_lds_bytes(a.img.r), s, a);
 }
 
 // ---------------------------------------------------------------------------------------------- gather passes
-// d(contrast)/d(theta_k) = (2/N) sum_events [ r0_k * dItilde/dx(at the event) + r1_k * dItilde/dy ] where the
+// d(contrast)/d(theta_k) = (2/N) sum_events [ r0_k * dJt/dx(at the event) + r1_k * dJt/dy ] where the
 // bilinear-interpolation derivatives are exactly the signed-weight sums the reference scatters into its derivative
 // images (local_image_warped_events.cpp:163-166, event_pano_warper.cpp:327-330).
 __device__ __forceinline__ void bilinear_grad(const float *it, int W, int xx, int yy, float dx, float dy, float &A, float &B) {
