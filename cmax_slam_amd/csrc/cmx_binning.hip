@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
-  if (has_win && !(b.variant & 4)) {
+  if (has_win) {
     for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
     __syncthreads();
   }
@@ -140,8 +140,7 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
       const FeWarp w = fe_warp_math<false>(a, px[u], py[u], pz[u], dt[u]);
-      if ((b.variant & 1) && act[u] && w.ok && w.xx == -12345) nfall++;
-      if (act[u] && w.ok && !(b.variant & 1)) {
+      if (act[u] && w.ok) {
         const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
           vote4_lds(win, lx, ly, w.dx, w.dy);
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
     }
   }
   if (nfall) atomicAdd(b.fallback, nfall);
-  if (has_win && !(b.variant & 2)) {
+  if (has_win) {
     __syncthreads();
     for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
       const int ly = p / kBinWindow, lx = p - ly * kBinWindow;

@@ -11,7 +11,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -503,8 +502,6 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.chunks = c->d_chunks;
   b.nchunks = c->nchunks;
   b.fallback = c->d_fallback;
-  static const int variant = getenv("CMX_DEBUG_VARIANT") ? atoi(getenv("CMX_DEBUG_VARIANT")) : 0;
-  b.variant = variant;
   return b;
 }
 
@@ -1204,9 +1201,6 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
                               int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure,
                               const float *IG) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
-  const bool trace = getenv("CMX_TRACE_SETUP") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_0 = now();
   int rc = bind(c);
   if (rc) return rc;
   c->have_data = false;
@@ -1249,7 +1243,6 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     if (rc) return rc;
     xy = c->h_xy;
   }
-  const double t_1 = now();
   std::vector<long long> bt((size_t)nbatches);
   std::atomic<int> err_kind(0);
   std::atomic<long long> err_at(-1);
@@ -1282,7 +1275,6 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", err_at.load(), K,
                 (long long)start_ns, (long long)dt_ns);
   const int nb = nbatches;
-  const double t_2 = now();
   c->order = order; c->K = K; c->num_fixed = num_fixed;
   c->batch = B; c->sample_rate = rate; c->measure = contrast_measure;
   c->knots0.resize((size_t)K);
@@ -1329,7 +1321,6 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   c->h_result[4095] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (trace) fprintf(stderr, "[cmx] set_window: validate+setup %.3f ms, pack %.3f ms, upload+map %.3f ms\n", t_1 - t_0, t_2 - t_1, now() - t_2);
   c->n_packed = (int)n_packed_total;
   c->per_batch = per_batch;
   c->nb = nb;

@@ -139,7 +139,6 @@ struct BinnedEvents {
   const Chunk *chunks;
   int nchunks;
   unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
-  int variant;             // debug/ablation bits (CMX_DEBUG_VARIANT): 1 = no votes, 2 = no flush, 4 = no zeroing
 };
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")

@@ -1,4 +1,4 @@
-"""First-contact script for the GPU box (not a pytest file): quick timing + parity printout."""
+"""First-contact script for the GPU box: quick timing + parity printout of every mode (not a test)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -12,4 +12,4 @@ for _ in range(5): fe.eval(om, True)
 fe.timing_enable(True); fe.timing_get()
 for _ in range(30): fe.eval(om, True)
 t = fe.timing_get()
-print("variant", os.environ.get("CMX_DEBUG_VARIANT", "0"), {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items()}, fe.stats())
+print("kernel us:", {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items()}, fe.stats())
