@@ -25,6 +25,7 @@ using namespace cmx;
 namespace {
 
 enum { KIND_FE = 1, KIND_BE = 2 };
+constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
 
 struct TimedSpan { int cls; hipEvent_t a, b; };
 
@@ -780,7 +781,7 @@ void parallel_ranges(int64_t n, F fn) {
 }
 
 int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
-  if (n < 0 || n > 0x7fffffffLL) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
+  if (n < 0 || n > kMaxEvents) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld (limit %lld)", (long long)n, (long long)kMaxEvents);
   if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
   const int W = c->W, H = c->H;
   std::atomic<int64_t> bad(-1);
@@ -996,7 +997,7 @@ static int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   if (!d_raw) {
     rc = check_events(c, n, x, y, t_ns);
     if (rc) return rc;
-  } else if (n < 0 || n > 0x7fffffffLL) {
+  } else if (n < 0 || n > kMaxEvents) {
     return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
   }
   rc = setup_blur(c, blur_sigma);
@@ -1216,7 +1217,7 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   if (!d_raw) {
     rc = check_events(c, n, x, y, t_ns);
     if (rc) return rc;
-  } else if (n < 0 || n > 0x7fffffffLL) {
+  } else if (n < 0 || n > kMaxEvents) {
     return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
   }
   rc = setup_blur(c, blur_sigma);
@@ -1345,7 +1346,7 @@ static int efail(cmx_events *e, int code, const char *msg) {
 int cmx_events_create(cmx_events **out, int device, int W, int H, size_t capacity) {
   if (!out) return CMX_ERR_INVALID_ARG;
   *out = nullptr;
-  if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || capacity == 0 || capacity > 0x7fffffffULL) return CMX_ERR_INVALID_ARG;
+  if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || capacity == 0 || capacity > (size_t)kMaxEvents) return CMX_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CMX_ERR_HIP;
   if (device < 0 || device >= ndev) return CMX_ERR_INVALID_ARG;
