@@ -83,6 +83,13 @@ SYMBOLS = {
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "cmx_integrate_ang_vel": (C.c_int, [C.c_int, c_i64p, c_dp, C.c_int64, c_dp, c_i64p, c_dp, C.c_int, c_i64p, c_dp,
+                                        C.POINTER(C.c_int)]),
+    "cmx_num_ctrl_poses": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_double]),
+    "cmx_fit_ctrl_poses": (C.c_int, [C.c_int, C.c_int, c_i64p, c_dp, C.c_double, C.c_double, C.c_int, c_dp]),
+    "cmx_traj_incremental_update": (C.c_int, [C.c_int, c_dp, C.c_int, C.c_int, c_dp]),
+    "cmx_traj_evaluate": (C.c_int, [C.c_int, C.c_int, c_dp, C.c_int64, C.c_int64, C.c_int64, c_dp]),
+    "cmx_bearing_lut": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "cmx_get_stats": (C.c_int, [ctx_p, c_dp]),
     "cmx_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "cmx_timing_get": (C.c_int, [ctx_p, c_dp, c_i64p]),

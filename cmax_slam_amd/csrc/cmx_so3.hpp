@@ -149,7 +149,8 @@ struct SplineArgs {
 
 // value R (row-major) and, if WANT_J, the `order` 3x3 blocks d_val_d_knot[i] (row-major, fp64)
 template <int N, bool WANT_J>
-CMX_HD void spline_eval(const SplineArgs &sp, long long t_ns, Mat3 &R, Mat3 *Jblocks, int &start_idx) {
+CMX_HD void spline_eval(const SplineArgs &sp, long long t_ns, Mat3 &R, Mat3 *Jblocks, int &start_idx,
+                        Quat *q_out = nullptr) {
   const long long st = t_ns - sp.start_ns;
   const long long s = st / sp.dt_ns;
   const double u = (double)(st % sp.dt_ns) / (double)sp.dt_ns;
@@ -195,6 +196,7 @@ CMX_HD void spline_eval(const SplineArgs &sp, long long t_ns, Mat3 &R, Mat3 *Jbl
   }
   if (WANT_J) Jblocks[N - 1] = Jh;
   R = q_to_R(res);
+  if (q_out) *q_out = res;
 }
 
 // cumulative blending matrix of a uniform B-spline of order N (host only; tiny)

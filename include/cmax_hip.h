@@ -240,6 +240,39 @@ typedef void (*cmx_fdf_fn)(const double *x, void *params, double *f, double *g);
 int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, int n, double *x, double step_size,
                       double tol, double epsabs_grad, double tolfun, int max_iterations, cmx_solve_report *report);
 
+/* ------------------------------------------------------------------ control-pose initialisation (host C++) ---
+ * what the back-end thread does between two window solves to turn the front end's
+ * angular velocities into the control poses the next window starts from, and the once-per-camera bearing table.
+ * Pure host fp64 (tens of poses x a handful of control poses); no context, no device work.  Quaternions are
+ * (x,y,z,w); stamps are int64 ns; sequences must be strictly increasing in time (the reference keeps them in
+ * std::map keyed by stamp). */
+/* PoseGraphOptimizer::integrateAngVel (src/backend/pose_graph_optimizer.cpp:191-222): trapezoidal integration of the
+ * n stamped angular velocities onto (pose_t_ns, pose_quat), post-multiplied.  prev_*: ang_vel_prev_ (in/out).
+ * out_*: room for n poses; *n_out = number written (stale stamps are skipped unless first_time_window). */
+int cmx_integrate_ang_vel(int n, const int64_t *t_ns, const double *ang_vel /* 3n */, int64_t pose_t_ns,
+                          const double pose_quat[4], int64_t *prev_t_ns, double prev_ang_vel[3], int first_time_window,
+                          int64_t *out_t_ns, double *out_quat /* 4n */, int *n_out);
+/* {Linear,Cubic}Trajectory::generateCtrlPoses' count (src/backend/trajectory.cpp:205-214 / :480-489):
+ * round((t_end - t_beg).toSec() / dt_knots) + 1 (order 2) or + 3 (order 4); -1 on bad arguments */
+int cmx_num_ctrl_poses(int order, int64_t t_beg_ns, int64_t t_end_ns, double dt_knots);
+/* {Linear,Cubic}Trajectory::fitCtrlPoses (src/backend/trajectory.cpp:112-192 / :357-464): least-squares B-spline
+ * fit in the tangent space at the first pose, solved like Eigen's fullPivHouseholderQr().solve (zero free variables
+ * when rank-deficient).  CMX_ERR_INVALID_ARG where the reference's CHECK_GE / Eigen index assertion would abort. */
+int cmx_fit_ctrl_poses(int order, int n_poses, const int64_t *t_ns, const double *quat /* 4 n_poses */,
+                       double t_beg_sec, double dt_knots, int num_cps, double *out_quat /* 4 num_cps */);
+/* {Linear,Cubic}Trajectory::incrementalUpdate (src/backend/trajectory.cpp:221-238 / :491-499):
+ * knot_i <- exp(drotv_{i-idx_beg}) * knot_i for i >= idx_beg; n_params = 3*(K-idx_beg) (what cmx_backend_solve returns) */
+int cmx_traj_incremental_update(int K, double *knots /* 4K, in/out */, int idx_beg, int n_params, const double *drotv);
+/* {Linear,Cubic}Trajectory::evaluate without the Jacobian (src/backend/trajectory.cpp:86-110 / :329-355) */
+int cmx_traj_evaluate(int order, int K, const double *knots, int64_t start_ns, int64_t dt_ns, int64_t t_ns,
+                      double quat_out[4]);
+/* CMaxSLAM::precomputeBearingVectors (src/cmax_slam.cpp:106-120): lut[(y*W+x)*3..] = projectPixelTo3dRay(
+ * rectifyPoint(x,y)) of image_geometry's pinhole model, plumb_bob D = k1 k2 p1 p2 k3.  K 3x3, R 3x3, P 3x4
+ * row-major; D, R, P may be NULL (no distortion, identity, [K|0]).  image_geometry / cv::undistortPoints are not
+ * vendored by the reference: restated from their documented behaviour, parity unpinned. */
+int cmx_bearing_lut(int W, int H, const double K[9], const double D[5], const double R[9], const double P[12],
+                    double *lut /* W*H*3 */);
+
 /* ------------------------------------------------------------------ timing hooks ------------------------
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
  * cmx_timing_enable(ctx, mask) makes every evaluation record events around the kernel classes whose bit is set

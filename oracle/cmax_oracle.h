@@ -79,6 +79,7 @@ int orc_so3_spline_eval(int order, int K, const double *knots_xyzw, int64_t star
 void orc_so3_left_update(double *knot_xyzw, const double drot[3]);
 void orc_so3_exp(const double w[3], double q_xyzw[4]);
 void orc_so3_log(const double q_xyzw[4], double w[3]);
+void orc_so3_mul(const double a_xyzw[4], const double b_xyzw[4], double out_xyzw[4]);
 /* (double)->ns truncation of CopyAndIncrementalUpdate (trajectory.cpp:255-256, :58-67) */
 int64_t orc_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots);
 
@@ -123,6 +124,23 @@ void orc_be_mark_visited(int W, int H, const double *lut, int Wp, int Hp, const 
                          uint8_t *update_times);
 /* dvs::EquirectangularCamera::projectToImage (equirectangular_camera.h:18-45) */
 void orc_equirect_project(int Wp, int Hp, const double P[3], double px[2], float jac[6] /* or NULL */);
+
+/* ---- control-pose initialisation + bearing LUT (traj_init.c) ---- */
+/* PoseGraphOptimizer::integrateAngVel (pose_graph_optimizer.cpp:191-222): n stamped angular velocities (sorted),
+ * the latest pose, the previous angular velocity (in/out).  Returns the number of poses written. */
+int orc_integrate_ang_vel(int n, const int64_t *t_ns, const double *ang_vel, int64_t pose_t_ns,
+                          const double pose_quat[4], int64_t *prev_t_ns, double prev_ang_vel[3],
+                          int first_time_window, int64_t *out_t_ns, double *out_quat);
+/* generateCtrlPoses' count (trajectory.cpp:205-214 / :480-489) */
+int orc_num_ctrl_poses(int order, int64_t t_beg_ns, int64_t t_end_ns, double dt_knots);
+/* Linear/CubicTrajectory::fitCtrlPoses (trajectory.cpp:112-192 / :357-464) */
+int orc_fit_ctrl_poses(int order, int n_poses, const int64_t *t_ns, const double *quat, double t_beg, double dt_knots,
+                       int num_cps, double *out_quat);
+/* Eigen's A.fullPivHouseholderQr().solve(b) restated; returns the rank */
+int orc_fullpiv_qr_solve(int rows, int cols, const double *A_rowmajor, const double *b, double *x);
+/* CMaxSLAM::precomputeBearingVectors (cmax_slam.cpp:106-120) over image_geometry + cv::undistortPoints */
+void orc_bearing_lut(int W, int H, const double K[9], const double D[5], const double R[9], const double P[12],
+                     double *lut);
 
 #ifdef __cplusplus
 }

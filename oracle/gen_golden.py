@@ -5,6 +5,10 @@
                        left-multiplicative knot update.  These PIN oracle/so3_spline.c.
   frontend_small.npz   seeded inputs + the oracle's own outputs (regression vectors; the reference has no
   backend_small.npz    fixtures for the IWE path and cannot be built here: parity unpinned at the OpenCV/ROS boundary)
+  trajinit.npz         least-squares systems of the shape fitCtrlPoses builds, solved by the REFERENCE's vendored
+                       Eigen (fullPivHouseholderQr().solve, incl. rank-deficient ones) + SO3 products by its Sophus:
+                       these PIN oracle/traj_init.c's solver.  Plus the oracle's own integrateAngVel / fitCtrlPoses /
+                       bearing-LUT outputs on seeded inputs (regression vectors).
 
 usage: python oracle/gen_golden.py
 """
@@ -129,7 +133,79 @@ def gen_backend():
     print("backend_small.npz written")
 
 
+def smooth_poses(rng, n, t0_ns, step_ns, rate):
+    """n stamped poses of a smooth rotation (angular velocity random-walk), (t_ns[n], quat[n,4])."""
+    q = po.so3_exp(rng.normal(0, 0.3, 3))
+    w = rng.normal(0, rate, 3)
+    ts, qs = [], []
+    t = t0_ns
+    for _ in range(n):
+        ts.append(t)
+        qs.append(q.copy())
+        w = w + rng.normal(0, 0.2 * rate, 3)
+        q = po.so3_mul(q, po.so3_exp(w * step_ns * 1e-9))
+        t += step_ns + int(rng.integers(-step_ns // 10, step_ns // 10))
+    return np.array(ts, np.int64), np.array(qs)
+
+
+def gen_trajinit():
+    po.build()
+    assert po.ref_lib() is not None, "needs the compiled reference (make -C oracle ref)"
+    rng = np.random.default_rng(20240314 + 7)
+    out = {}
+    # (1) solver cases from the vendored Eigen: padded to 24 x 8
+    A_all, b_all, x_all, shape, rank = [], [], [], [], []
+    for trial in range(80):
+        order = 2 if trial % 2 == 0 else 4
+        cols = order + int(rng.integers(0, 5))
+        rows = cols + int(rng.integers(0, 16))
+        A = np.zeros((rows, cols))
+        basis2 = np.array([[1.0, 0.0], [-1.0, 1.0]])
+        basis4 = np.array([[1 / 6, 2 / 3, 1 / 6, 0], [-0.5, 0, 0.5, 0], [0.5, -1, 0.5, 0], [-1 / 6, 0.5, -0.5, 1 / 6]])
+        M = basis2 if order == 2 else basis4
+        for r in range(rows):
+            seg = int(rng.integers(0, cols - order + 1))
+            if trial % 5 == 4:
+                seg = min(seg, max(cols - order - 1, 0))  # leaves the last control pose unsupported: rank-deficient
+            u = rng.random()
+            A[r, seg:seg + order] = (u ** np.arange(order)) @ M
+        b = rng.normal(0, 0.3, rows)
+        x, rk = po.fullpiv_qr_solve(A, b, use_ref=True)
+        Ap = np.zeros((24, 8)); Ap[:rows, :cols] = A
+        bp = np.zeros(24); bp[:rows] = b
+        xp = np.zeros(8); xp[:cols] = x
+        A_all.append(Ap); b_all.append(bp); x_all.append(xp); shape.append((rows, cols)); rank.append(rk)
+    out["qr_A"], out["qr_b"], out["qr_x"] = np.array(A_all), np.array(b_all), np.array(x_all)
+    out["qr_shape"], out["qr_rank"] = np.array(shape), np.array(rank)
+    # SO3 products from the vendored Sophus
+    qa = np.array([po.so3_exp(rng.normal(0, 1.0, 3), use_ref=True) for _ in range(40)])
+    qb = np.array([po.so3_exp(rng.normal(0, 2.0, 3), use_ref=True) for _ in range(40)])
+    out["mul_a"], out["mul_b"] = qa, qb
+    out["mul_ab"] = np.array([po.so3_mul(a, b, use_ref=True) for a, b in zip(qa, qb)])
+    # (2) regression vectors from the oracle
+    t0 = 1_000_000_000
+    for order, tag in ((2, "lin"), (4, "cub")):
+        ts, qs = smooth_poses(rng, 20, t0 + 3_000_000, 10_000_000, 1.5)
+        n = po.num_ctrl_poses(order, t0, t0 + 200_000_000, 0.05)
+        out[tag + "_pose_t"], out[tag + "_pose_q"] = ts, qs
+        out[tag + "_num_cps"] = np.array(n)
+        out[tag + "_cps"] = po.fit_ctrl_poses(order, ts, qs, po.lib().orc_time_to_sec(t0), 0.05, n)
+    wt = t0 + 5_000_000 + 10_000_000 * np.arange(20, dtype=np.int64)
+    wv = np.cumsum(rng.normal(0, 0.2, (20, 3)), axis=0) + np.array([0.6, -0.9, 0.4])
+    pt, pq, prev_t, prev_w = po.integrate_ang_vel(wt, wv, t0, po.so3_exp([0, np.pi / 2, 0]), t0, wv[0], True)
+    out["iav_t"], out["iav_w"], out["iav_pose_t"], out["iav_pose_q"] = wt, wv, pt, pq
+    K = np.array([[588.10, 0, 339.83], [0, 593.99, 242.43], [0, 0, 1.0]])
+    D = np.array([-0.35, 0.15, 1e-3, -5e-4, -0.03])
+    lut = po.bearing_lut(64, 48, K * np.array([[0.1], [0.1], [1.0]]), D)
+    out["lut_K"], out["lut_D"], out["lut_64x48"] = K * np.array([[0.1], [0.1], [1.0]]), D, lut
+    np.savez_compressed(os.path.join(OUT, "trajinit.npz"), **out)
+    print("trajinit.npz written; ranks:", sorted(set(zip(*[map(int, rank), [c for _, c in shape]]))))
+
+
 if __name__ == "__main__":
+    gen_trajinit()
+    if "--only-trajinit" in sys.argv:
+        sys.exit(0)
     gen_spline()
     gen_frontend()
     gen_backend()

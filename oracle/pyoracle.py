@@ -85,6 +85,17 @@ def lib():
         c_u8p = C.POINTER(C.c_uint8)
         L.orc_be_update_ig.argtypes = [c_fp, c_fp, c_u8p, C.c_int, C.c_int]
         L.orc_be_mark_visited.argtypes = [C.c_int, C.c_int, c_dp, C.c_int, C.c_int, c_dp, C.c_int, c_u8p]
+        L.orc_so3_mul.argtypes = [c_dp, c_dp, c_dp]
+        L.orc_integrate_ang_vel.restype = C.c_int
+        L.orc_integrate_ang_vel.argtypes = [C.c_int, c_i64p, c_dp, C.c_int64, c_dp, C.POINTER(C.c_int64), c_dp, C.c_int,
+                                            c_i64p, c_dp]
+        L.orc_num_ctrl_poses.restype = C.c_int
+        L.orc_num_ctrl_poses.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_double]
+        L.orc_fit_ctrl_poses.restype = C.c_int
+        L.orc_fit_ctrl_poses.argtypes = [C.c_int, C.c_int, c_i64p, c_dp, C.c_double, C.c_double, C.c_int, c_dp]
+        L.orc_fullpiv_qr_solve.restype = C.c_int
+        L.orc_fullpiv_qr_solve.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp]
+        L.orc_bearing_lut.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
         _LIB = L
     return _LIB
 
@@ -102,6 +113,9 @@ def ref_lib():
         R.ref_so3_exp.argtypes = [c_dp, c_dp]
         R.ref_so3_log.argtypes = [c_dp, c_dp]
         R.ref_so3_left_update.argtypes = [c_dp, c_dp]
+        R.ref_so3_mul.argtypes = [c_dp, c_dp, c_dp]
+        R.ref_fullpiv_qr_solve.restype = C.c_int
+        R.ref_fullpiv_qr_solve.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp]
         _REF = R
     return _REF
 
@@ -227,6 +241,65 @@ def left_update(knots_xyzw, drotv, num_fixed, use_ref=False):
     for i in range(num_fixed, k.shape[0]):
         fn(_dp(k[i]), _dp(d[i - num_fixed]))
     return k
+
+
+def so3_mul(a, b, use_ref=False):
+    a, b = _c(a, np.float64), _c(b, np.float64)
+    out = np.zeros(4)
+    (ref_lib().ref_so3_mul if use_ref else lib().orc_so3_mul)(_dp(a), _dp(b), _dp(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- control-pose initialisation
+def fullpiv_qr_solve(A, b, use_ref=False):
+    """x = A.fullPivHouseholderQr().solve(b) and Eigen's rank (restated, or the vendored Eigen itself)."""
+    A = _c(A, np.float64)
+    b = _c(b, np.float64)
+    x = np.zeros(A.shape[1])
+    fn = ref_lib().ref_fullpiv_qr_solve if use_ref else lib().orc_fullpiv_qr_solve
+    rank = fn(A.shape[0], A.shape[1], _dp(A), _dp(b), _dp(x))
+    return x, rank
+
+
+def integrate_ang_vel(t_ns, ang_vel, pose_t_ns, pose_quat, prev_t_ns, prev_ang_vel, first_time_window):
+    """Returns (pose_t_ns[m], pose_quat[m,4], prev_t_ns', prev_ang_vel')."""
+    t = _c(t_ns, np.int64)
+    w = _c(ang_vel, np.float64).reshape(-1, 3)
+    pq = _c(pose_quat, np.float64)
+    pt = C.c_int64(int(prev_t_ns))
+    pw = np.array(prev_ang_vel, dtype=np.float64, copy=True)
+    ot = np.zeros(max(len(t), 1), np.int64)
+    oq = np.zeros((max(len(t), 1), 4))
+    m = lib().orc_integrate_ang_vel(len(t), t.ctypes.data_as(c_i64p), _dp(w), int(pose_t_ns), _dp(pq), C.byref(pt), _dp(pw),
+                                    int(bool(first_time_window)), ot.ctypes.data_as(c_i64p), _dp(oq))
+    return ot[:m].copy(), oq[:m].copy(), pt.value, pw
+
+
+def num_ctrl_poses(order, t_beg_ns, t_end_ns, dt_knots):
+    return int(lib().orc_num_ctrl_poses(int(order), int(t_beg_ns), int(t_end_ns), float(dt_knots)))
+
+
+def fit_ctrl_poses(order, t_ns, quats, t_beg, dt_knots, num_cps):
+    t = _c(t_ns, np.int64)
+    q = _c(quats, np.float64).reshape(-1, 4)
+    out = np.zeros((num_cps, 4))
+    rc = lib().orc_fit_ctrl_poses(int(order), len(t), t.ctypes.data_as(c_i64p), _dp(q), float(t_beg), float(dt_knots),
+                                  int(num_cps), _dp(out))
+    if rc:
+        raise ValueError("fitCtrlPoses: the reference's CHECK / Eigen index assertion would fire")
+    return out
+
+
+def bearing_lut(W, H, K, D, R=None, P=None):
+    K = _c(K, np.float64).reshape(9)
+    D = _c(D, np.float64).reshape(5)
+    R = _c(np.eye(3) if R is None else R, np.float64).reshape(9)
+    if P is None:
+        P = np.concatenate([K.reshape(3, 3), np.zeros((3, 1))], axis=1)
+    P = _c(P, np.float64).reshape(12)
+    lut = np.zeros((H, W, 3))
+    lib().orc_bearing_lut(int(W), int(H), _dp(K), _dp(D), _dp(R), _dp(P), _dp(lut))
+    return lut
 
 
 def traj_temp_start_ns(t_beg, idx_traj_beg, dt_knots):

@@ -11,6 +11,7 @@
  *   src/backend/trajectory.cpp:58-71   (ctor: dt_ns, start_ns, knotsPushBack)
  *   src/backend/trajectory.cpp:86-110 / :329-355 (evaluate + Jacobian blocks)
  *   src/backend/trajectory.cpp:236 / :497 (left-multiplicative update)
+ *   src/backend/trajectory.cpp:176-178 / :448-450 (N.fullPivHouseholderQr().solve on the vendored Eigen)
  */
 #include <cstdint>
 #include <basalt/spline/so3_spline.h>
@@ -68,6 +69,26 @@ void ref_so3_log(const double* q, double* w) {
   r.setQuaternion(Eigen::Quaterniond(q[3], q[0], q[1], q[2]));
   Eigen::Vector3d v = r.log();
   w[0] = v[0]; w[1] = v[1]; w[2] = v[2];
+}
+void ref_so3_mul(const double* a, const double* b, double* out) {
+  Sophus::SO3d ra, rb;
+  ra.setQuaternion(Eigen::Quaterniond(a[3], a[0], a[1], a[2]));
+  rb.setQuaternion(Eigen::Quaterniond(b[3], b[0], b[1], b[2]));
+  const Sophus::SO3d r = ra * rb;
+  const Eigen::Quaterniond& q = r.unit_quaternion();
+  out[0] = q.x(); out[1] = q.y(); out[2] = q.z(); out[3] = q.w();
+}
+/* the solver call of src/backend/trajectory.cpp:176-178 / :448-450 on the vendored Eigen */
+int ref_fullpiv_qr_solve(int rows, int cols, const double* A_rowmajor, const double* b, double* x) {
+  Eigen::MatrixXd N(rows, cols);
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) N(i, j) = A_rowmajor[(size_t)i * cols + j];
+  Eigen::VectorXd D(rows);
+  for (int i = 0; i < rows; i++) D(i) = b[i];
+  auto qr = N.fullPivHouseholderQr();
+  Eigen::VectorXd P = qr.solve(D);
+  for (int j = 0; j < cols; j++) x[j] = P(j);
+  return (int)qr.rank();
 }
 void ref_so3_left_update(double* k, const double* drot) {
   Sophus::SO3d r;

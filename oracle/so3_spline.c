@@ -162,6 +162,13 @@ static void blending_matrix(int N, double *m) {
 void orc_so3_exp(const double w[3], double q[4]) { quat r = so3_exp(w); q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w; }
 void orc_so3_log(const double q[4], double w[3]) { quat r = {q[0], q[1], q[2], q[3]}; so3_log(r, w); }
 
+/* SO3 * SO3 (re-normalised), so3.hpp:325-339 */
+void orc_so3_mul(const double a[4], const double b[4], double out[4]) {
+  quat qa = {a[0], a[1], a[2], a[3]}, qb = {b[0], b[1], b[2], b[3]};
+  quat r = q_mul(qa, qb);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
 /* spline_.getKnot(i) = SO3::exp(drot) * spline_.getKnot(i)   trajectory.cpp:236 / :497 */
 void orc_so3_left_update(double *k, const double drot[3]) {
   quat q = {k[0], k[1], k[2], k[3]};
