@@ -249,3 +249,81 @@ def config5(N=20_000_000, seed=SEED0 + 5, Wp=4096, Hp=2048):
     """1280x720 sensor, linear K=5, 0 fixed (P=15), 4096x2048 map."""
     return backend_window(N, 1280, 720, 1000.0, 1000.0, 639.5, 359.5, Wp=Wp, Hp=Hp, order=2, K=5, num_fixed=0,
                           T=0.2, seed=seed)
+
+
+# ------------------------------------------------------------------ a continuous stream (end-to-end example)
+@dataclass
+class EventStream:
+    W: int
+    H: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    x: np.ndarray
+    y: np.ndarray
+    t_ns: np.ndarray
+    grid_ns: int             # ground-truth sampling step
+    grid_quat: np.ndarray    # world<-camera orientation (x,y,z,w) at T0_NS + k*grid_ns
+    grid_omega: np.ndarray   # body-frame angular velocity at the same stamps [rad/s]
+
+    @property
+    def lut(self):
+        return pinhole_lut(self.W, self.H, self.fx, self.fy, self.cx, self.cy)
+
+    def quat_at(self, t_ns):
+        k = np.clip((np.asarray(t_ns, np.int64) - T0_NS + self.grid_ns // 2) // self.grid_ns, 0, len(self.grid_quat) - 1)
+        return self.grid_quat[k]
+
+    def omega_at(self, t_ns):
+        k = np.clip((np.asarray(t_ns, np.int64) - T0_NS + self.grid_ns // 2) // self.grid_ns, 0, len(self.grid_quat) - 1)
+        return self.grid_omega[k]
+
+
+def event_stream(rate, T, W, H, fx, fy, cx, cy, seed=SEED0, noise=0.10, n_arcs=400, omega_mean=(0.1, 0.9, 0.15),
+                 omega_amp=(0.5, 0.4, 0.5), omega_hz=(1.3, 0.7, 1.9), yaw0_deg=0.0):
+    """rate*T events over [t0, t0+T) seen by a camera whose body-frame angular velocity is
+    omega_mean + omega_amp*sin(2 pi f t + phase): R(t+h) = R(t) exp(omega h) (the post-multiplied integration the
+    back end itself uses, pose_graph_optimizer.cpp:205-210), world<-camera, R(t0) = rotation by yaw0 about Y
+    (pose_graph_optimizer.cpp:88-93).  Scene = great-circle arcs spread over the band the camera sweeps."""
+    rng = np.random.default_rng(seed)
+    grid_ns = 10_000
+    n_grid = int(T * 1e9) // grid_ns + 2
+    tg = np.arange(n_grid) * grid_ns * 1e-9
+    phase = rng.uniform(0, 2 * np.pi, 3)
+    omega = np.asarray(omega_mean) + np.asarray(omega_amp) * np.sin(2 * np.pi * np.asarray(omega_hz) * tg[:, None] + phase)
+    th = np.deg2rad(yaw0_deg)
+    R = Rot.from_matrix(np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]))
+    # cumulative product of the per-step increments (midpoint rule)
+    inc = Rot.from_rotvec(0.5 * (omega[:-1] + omega[1:]) * (grid_ns * 1e-9)).as_matrix()
+    grid_R = np.empty((n_grid, 3, 3))
+    grid_R[0] = R.as_matrix()
+    for i in range(n_grid - 1):
+        grid_R[i + 1] = grid_R[i] @ inc[i]
+    quats = Rot.from_matrix(grid_R).as_quat()
+    grid_R = Rot.from_quat(quats).as_matrix()  # re-orthonormalised
+    axes = grid_R[:: max(n_grid // 24, 1), :, 2]
+    cone = 1.25 * np.arctan(np.hypot(W / 2 / fx, H / 2 / fy))
+    scene = _Scene(rng, n_arcs, axes, cone)
+    N = int(round(rate * T))
+    n_sig = int(round(N * (1 - noise)))
+    xs, ys, ts = [], [], []
+    need = n_sig
+    while need > 0:
+        m = min(int(need * 2.5) + 1024, 4_000_000)
+        pts = scene.sample(rng, m)
+        tn = T0_NS + np.floor(rng.random(m) * T * 1e9).astype(np.int64)
+        Rt = grid_R[(tn - T0_NS + grid_ns // 2) // grid_ns]
+        p_cam = np.einsum("nji,nj->ni", Rt, pts)
+        xi, yi, ok = _project_pinhole(p_cam, fx, fy, cx, cy, W, H)
+        xs.append(xi[ok]); ys.append(yi[ok]); ts.append(tn[ok])
+        need -= int(ok.sum())
+    x = np.concatenate(xs)[:n_sig]
+    y = np.concatenate(ys)[:n_sig]
+    tn = np.concatenate(ts)[:n_sig]
+    n_noise = N - len(x)
+    x = np.concatenate([x, rng.integers(0, W, n_noise)])
+    y = np.concatenate([y, rng.integers(0, H, n_noise)])
+    tn = np.concatenate([tn, T0_NS + np.floor(rng.random(n_noise) * T * 1e9).astype(np.int64)])
+    o = np.argsort(tn, kind="stable")
+    return EventStream(W, H, fx, fy, cx, cy, x[o].astype(np.uint16), y[o].astype(np.uint16), tn[o], grid_ns, quats, omega)
