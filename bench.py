@@ -119,6 +119,13 @@ def main():
             except Exception as e:  # keep the run alive: fall back to torch.distributed on evaluator-owned tensors
                 comm_used = "torch.distributed (native attach failed: %s)" % e
                 args.comm = "torch"
+            # all ranks must take the same exchange path: one failed attach moves everybody to the torch path
+            ok = torch.tensor([1 if args.comm == "native" else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and args.comm == "native":
+                ev.comm_detach()
+                comm_used = "torch.distributed (native attach failed on another rank)"
+                args.comm = "torch"
         if args.comm == "torch":
             accum, gsum, stream = attach_torch_accum(ev, device)
             sh = ShardedEvaluator(ev, accum, gsum)

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void fe_bin_keys_kernel(FeSplatArgs a, int til
 __global__ __launch_bounds__(256) void be_bin_keys_kernel(BeSplatArgs a, int tiles_x, int ntiles, uint32_t *keys,
                                                           uint32_t *idx) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const BeWarp w = be_warp_event<false>(a, i);
+    const BeWarp w = be_warp_event<0>(a, i);
     // the IL_old / IL_new split is a property of the event (its timestamp), so it can be part of the sort key:
     // every chunk then votes into ONE plane and needs one LDS window
     keys[i] = w.ok ? (uint32_t)(2 * ((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) + (w.is_old ? 0 : 1)) : (uint32_t)(2 * ntiles);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const BeWarp w = be_warp_math<false>(a, e[u], (int)bi[u], b0[u], b1[u], b2[u], R[u]);
+      const BeWarp w = be_warp_math<0>(a, e[u], (int)bi[u], b0[u], b1[u], b2[u], R[u]);
       if (act[u] && w.ok) {
         const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void be_splat_kernel(BeSplatArgs a) {
   const int Wp = a.Wp;
   const size_t np = (size_t)Wp * a.Hp;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    const BeWarp w = be_warp_event<DERIV>(a, i);
+    const BeWarp w = be_warp_event<DERIV ? 1 : 0>(a, i);
     if (w.ok) {
       const float dx = w.dx, dy = w.dy;
       const size_t off = (size_t)w.yy * Wp + w.xx;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
     double V0 = 0, V1 = 0, V2 = 0, U0 = 0, U1 = 0, U2 = 0;
     int batch = -1;
     if (i < a.n) {
-      const BeWarp w = be_warp_event<true>(a, i);
+      const BeWarp w = be_warp_event<2>(a, i);
       batch = w.batch;
       if (w.ok) {
         float A, B;

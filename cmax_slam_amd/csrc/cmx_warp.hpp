@@ -74,8 +74,13 @@ struct BeWarp {
   float m[6];
 };
 
-// the arithmetic of the back-end warp on already-loaded operands: bearing (b0,b1,b2) and the batch rotation R[9]
-template <bool DERIV>
+// the arithmetic of the back-end warp on already-loaded operands: bearing (b0,b1,b2) and the batch rotation R[9].
+// DERIV = 1: d(pixel)/d(rotation) with the projection Jacobian evaluated in fp64 and cast to fp32 entry by entry,
+//            exactly the reference's Matx23f (equirectangular_camera.h:33-44) -- the derivative-plane (faithful) mode.
+// DERIV = 2: the same five entries evaluated in fp32 from the fp64 ray (the reference multiplies them in fp32 anyway,
+//            event_pano_warper.cpp:281-285); relative difference ~1e-7 per entry, saves five fp64 divisions and a
+//            square root per event in the ALU-bound gather pass of the adjoint mode.
+template <int DERIV>
 __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e, int batch, double b0, double b1,
                                               double b2, const double *R) {
   BeWarp w;
@@ -96,7 +101,23 @@ __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e,
   w.ok = (1 <= w.xx && w.xx < a.Wp - 2 && 1 <= w.yy && w.yy < a.Hp - 2);
   w.dx = (float)(pxm - w.xx);
   w.dy = (float)(pym - w.yy);
-  if (DERIV) {
+  if (DERIV == 2) {
+    const float xf = (float)x, yf = (float)y, zf = (float)z, rhof = (float)rho;
+    const float fxf = (float)a.fx, fyf = (float)a.fy;
+    const float inv_rho = 1.f / rhof, inv_z = 1.f / zf;
+    const float Ydivrho = yf * inv_rho, XdivZ = xf * inv_z;
+    const float tmp1 = fxf * inv_z / (1.f + XdivZ * XdivZ);
+    const float tmp2 = -fyf / sqrtf(1.f - Ydivrho * Ydivrho);
+    const float tmp3 = Ydivrho * inv_rho * inv_rho;
+    const float d00 = tmp1, d02 = -tmp1 * XdivZ;
+    const float d10 = tmp2 * tmp3 * xf, d11 = tmp2 * (tmp3 * yf - inv_rho), d12 = tmp2 * tmp3 * zf;
+    w.m[0] = d02 * yf;
+    w.m[1] = d00 * zf + d02 * (-xf);
+    w.m[2] = d00 * (-yf);
+    w.m[3] = d11 * (-zf) + d12 * yf;
+    w.m[4] = d10 * zf + d12 * (-xf);
+    w.m[5] = d10 * (-yf) + d11 * xf;
+  } else if (DERIV == 1) {
     const double Ydivrho = y / rho;
     const double XdivZ = x / z;
     const double tmp1 = a.fx / ((1 + XdivZ * XdivZ) * z);
@@ -117,7 +138,7 @@ __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e,
   return w;
 }
 
-template <bool DERIV>
+template <int DERIV>
 __device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e, int batch) {
   const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
   const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
@@ -127,7 +148,7 @@ __device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e,
   return be_warp_math<DERIV>(a, e, batch, b[0], b[1], b[2], R);
 }
 
-template <bool DERIV>
+template <int DERIV>
 __device__ __forceinline__ BeWarp be_warp_event(const BeSplatArgs &a, int i) {
   return be_warp_core<DERIV>(a, a.xy[i], i / a.per_batch);
 }
