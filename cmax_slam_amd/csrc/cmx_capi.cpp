@@ -671,7 +671,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   rc = ensure(c, c->d_sums, c->sums_cap, 2);
   if (rc) return rc;
   // rows of the gather partial table: front end = gather workgroups; back end = workgroups of the per-batch pass
-  const int gb = (c->kind == KIND_FE) ? gather_blocks(c->n_packed) : be_batch_blocks(c->nb);
+  const int gb = (c->kind == KIND_FE) ? fe_gather_blocks(c->n_packed) : be_batch_blocks(c->nb);
   const int P2 = 2 * (P > 0 ? P : 1);
   rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * P2);
   if (rc) return rc;

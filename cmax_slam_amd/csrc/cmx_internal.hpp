@@ -166,6 +166,7 @@ int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the numb
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s);  // returns the rows of gpartials (batch-kernel blocks)
 int be_batch_blocks(int nb);
 int gather_blocks(int n);
+int fe_gather_blocks(int n);
 // contrast_ImageGradientMagnitude (front end, contrast_measure = 2): Sobel moments of the blurred planes
 struct SobelArgs {
   int W, H, P;

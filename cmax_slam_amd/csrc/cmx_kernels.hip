@@ -585,6 +585,13 @@ int gather_blocks(int n) {
   const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~130 VGPRs: 3 blocks/CU is its occupancy)
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
+// front end: one workgroup per kFeGatherPerBlock events up to the cap (tools/sweep_fe_gather.sh: 1024 -> 16.9 us,
+// 1536 -> 18.3 us, 512 -> 18.0 us per 1M events)
+constexpr int kFeGatherPerBlock = 1024, kFeGatherCap = 2048;
+int fe_gather_blocks(int n) {
+  int blocks = (n + kFeGatherPerBlock - 1) / kFeGatherPerBlock;
+  return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
+}
 
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   __shared__ double red[4];
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
 }
 
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s) {
-  const int blocks = gather_blocks(a.ev.n);
+  const int blocks = fe_gather_blocks(a.ev.n);
   hipLaunchKernelGGL(fe_gather_kernel, dim3(blocks), dim3(256), 0, s, a);
   return blocks;
 }
