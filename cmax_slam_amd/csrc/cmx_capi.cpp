@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -131,6 +132,8 @@ struct cmx_ctx {
   double *d_partials = nullptr, *d_sums = nullptr;
   size_t partials_cap = 0, sums_cap = 0;
   double *h_result = nullptr, *d_result = nullptr;  // mapped pinned host
+  unsigned long long ticket_issued = 0;  // ticket of the last finalize launch (see sync_and_collect)
+  bool ticket_wait = true;
   size_t result_cap = 0;
 
   // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
@@ -370,6 +373,7 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   c->result_cap = 4096;
   HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
+  memset(c->h_result, 0, c->result_cap * sizeof(double));
   return CMX_OK;
 }
 
@@ -545,6 +549,13 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
   return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
 }
 
+// every evaluation ends in exactly one finalize launch; it carries the ticket sync_and_collect() waits for
+void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
+  f.ticket = ++c->ticket_issued;
+  if (with_reduce) launch_finalize(f, c->stream);
+  else launch_finalize_only(f, c->stream);
+}
+
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -611,7 +622,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     f.direct = 1;
     f.gpartials = c->d_gpartials; f.gblocks = sa.nblk; f.gP = P;
     f.fallback = c->d_fallback;
-    launch_finalize_only(f, c->stream);
+    issue_finalize(c, f, false);
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
@@ -629,9 +640,9 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     f.fallback = c->d_fallback;
     if (P == 0 && a.nblk <= 2048) {
       f.direct = 1;
-      launch_finalize_only(f, c->stream);
+      issue_finalize(c, f, false);
     } else {
-      launch_finalize(f, c->stream);
+      issue_finalize(c, f, true);
     }
   }
   HIP_TRY(c, hipGetLastError());
@@ -709,7 +720,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   f.gP = P;
   f.fallback = c->d_fallback;
   if (phase == 2) {
-    launch_finalize_only(f, c->stream);
+    issue_finalize(c, f, false);
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
@@ -750,16 +761,37 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
-  launch_finalize_only(f, c->stream);
+  issue_finalize(c, f, false);
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }
 
-int sync_and_collect(cmx_ctx *c) {
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false) {
+  // ends_in_finalize: the last thing queued on the stream is an evaluation's finalize kernel.  Wait for it through
+  // its completion ticket in mapped host memory (a few microseconds earlier than the runtime reports the stream idle);
+  // anything slower than the spin budget, and every caller that queued copies or other kernels after the finalize,
+  // takes the ordinary stream synchronisation.
+  bool done = false;
+  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) {
+    const volatile unsigned long long *slot = reinterpret_cast<const volatile unsigned long long *>(c->h_result + kTicketSlot);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      if (*slot == c->ticket_issued) { done = true; break; }
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+        break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[4094] / (double)c->n_packed;
   c->fallback_pending = false;
-  if (c->timing) collect_spans(c);
+  // timing spans are resolved lazily (cmx_timing_get) so that timed evaluations wait exactly like untimed ones
+  if (c->spans.size() > 4096) {
+    if (done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
+  }
   return CMX_OK;
 }
 
@@ -898,6 +930,9 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_REUSE_IMAGE:
       c->reuse_image = value != 0;
       return CMX_OK;
+    case CMX_OPT_SPIN_WAIT:
+      c->ticket_wait = value != 0;
+      return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
 }
@@ -936,6 +971,12 @@ int cmx_timing_enable(cmx_ctx *c, int on) {
 }
 int cmx_timing_get(cmx_ctx *c, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  if (!c->spans.empty()) {
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
+  }
   for (int i = 0; i < CMX_T_COUNT; i++) {
     if (ms) ms[i] = c->t_ms[i];
     if (launches) launches[i] = c->t_n[i];
@@ -1098,7 +1139,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
   else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
   if (rc) return rc;
-  rc = sync_and_collect(c);
+  rc = sync_and_collect(c, true);
   if (rc) return rc;
   *contrast = c->h_result[0];
   if (grad) for (int k = 0; k < 3; k++) grad[k] = c->h_result[2 + k];
@@ -1542,7 +1583,7 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (grad && c->last_adjoint) rc = run_adjoint(c, P);
   else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
   if (rc) return rc;
-  rc = sync_and_collect(c);
+  rc = sync_and_collect(c, true);
   if (rc) return rc;
   *contrast = c->h_result[0];
   if (grad) for (int k = 0; k < P; k++) grad[k] = c->h_result[2 + k];
@@ -1636,7 +1677,7 @@ static int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad) {
     if (rc) return rc;
   }
   c->finish_pending = false;
-  rc = sync_and_collect(c);
+  rc = sync_and_collect(c, true);
   if (rc) return rc;
   *contrast = c->h_result[0];
   if (grad) for (int k = 0; k < P; k++) grad[k] = c->h_result[2 + k];

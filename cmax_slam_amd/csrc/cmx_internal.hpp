@@ -112,7 +112,9 @@ struct FinalizeArgs {
   unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
   int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
   int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
+  unsigned long long ticket;  // written (system scope, after the results) to result[kTicketSlot]: the host polls it
 };
+constexpr int kTicketSlot = 4093;  // h_result[4093] holds the ticket of the last finished evaluation (as a u64)
 
 struct AlphaArgs {
   const float *igp, *il_old, *il_new;

@@ -388,6 +388,13 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __syncthreads();
   const int nout = 2 + (a.P > a.gP ? a.P : a.gP);
   if (t < nout) a.result[t] = outv[t];
+  // completion ticket: results first, then (system-scope release) the ticket the host spins on -- the kernel's end
+  // reaches the host through the runtime's completion signal several microseconds later than this store does
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.result + kTicketSlot), a.ticket, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // per-parameter sum of the gather kernel's block partials -> gsum[P] (the buffer ranks all-reduce)

@@ -61,9 +61,13 @@ enum {
                                  tile of their vote, workgroups accumulate in LDS and flush touched pixels; votes that
                                  leave a window (parameters drifted) take the global path, so results stay exact;
                                  applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */
-  CMX_OPT_REUSE_IMAGE = 3 /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
+  CMX_OPT_REUSE_IMAGE = 3, /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
                              the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
                              df at every accepted point; the reference recomputes everything, :58-70) */
+  CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
+                             that kernel writes to mapped host memory after the results (a few microseconds sooner
+                             than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
+                             evaluation).  0: plain hipStreamSynchronize */
 };
 
 const char *cmx_version(void);
