@@ -133,6 +133,7 @@ struct cmx_ctx {
   size_t partials_cap = 0, sums_cap = 0;
   double *h_result = nullptr, *d_result = nullptr;  // mapped pinned host
   unsigned long long ticket_issued = 0;  // ticket of the last finalize launch (see sync_and_collect)
+  int ticket_nout = 0;                   // result words that launch writes
   bool ticket_wait = true;
   size_t result_cap = 0;
 
@@ -552,6 +553,7 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
 // every evaluation ends in exactly one finalize launch; it carries the ticket sync_and_collect() waits for
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
   f.ticket = ++c->ticket_issued;
+  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
   if (with_reduce) launch_finalize(f, c->stream);
   else launch_finalize_only(f, c->stream);
 }
@@ -773,10 +775,15 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false) {
   // takes the ordinary stream synchronisation.
   bool done = false;
   if (ends_in_finalize && c->ticket_wait && c->ticket_issued) {
-    const volatile unsigned long long *slot = reinterpret_cast<const volatile unsigned long long *>(c->h_result + kTicketSlot);
+    const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result);
+    const unsigned long long want = c->ticket_issued;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
-      if (*slot == c->ticket_issued) { done = true; break; }
+      if (w[kTicketSlot] == want) {  // ticket seen: accept only a consistent snapshot of the results
+        unsigned long long x = w[kFallbackSlot];
+        for (int k = 0; k < c->ticket_nout; k++) x ^= w[k];
+        if ((x ^ (want * kTicketMix)) == w[kChecksumSlot]) { done = true; break; }
+      }
       __builtin_ia32_pause();
       if ((spins & 1023u) == 1023u &&
           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
@@ -785,7 +792,7 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false) {
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[4094] / (double)c->n_packed;
+  if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[kFallbackSlot] / (double)c->n_packed;
   c->fallback_pending = false;
   // timing spans are resolved lazily (cmx_timing_get) so that timed evaluations wait exactly like untimed ones
   if (c->spans.size() > 4096) {
@@ -1360,7 +1367,7 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     c->ig_nonzero = false;
   }
   HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
-  c->h_result[4095] = 0.0;  // alpha mirror
+  c->h_result[kAlphaSlot] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->n_packed = (int)n_packed_total;
@@ -1558,12 +1565,12 @@ static int be_first_iter(cmx_ctx *c) {
     if (rc) return rc;
     a.partials = c->d_partials;
     a.alpha = c->d_alpha;
-    a.result_alpha = c->d_result + 4095;
+    a.result_alpha = c->d_result + kAlphaSlot;
     launch_alpha(a, c->stream);
     HIP_TRY(c, hipGetLastError());
   } else {
     HIP_TRY(c, hipMemsetAsync(c->d_alpha, 0, sizeof(double), c->stream));  // countNonZero(IGp) < 1 => alpha = 0
-    c->h_result[4095] = 0.0;
+    c->h_result[kAlphaSlot] = 0.0;
   }
   c->first_iter = false;
   return CMX_OK;
@@ -1786,7 +1793,7 @@ int cmx_backend_get_alpha(cmx_ctx *c, double *alpha) {
   int rc = bind(c);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  *alpha = c->h_result[4095];
+  *alpha = c->h_result[kAlphaSlot];
   return CMX_OK;
 }
 

@@ -112,9 +112,14 @@ struct FinalizeArgs {
   unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
   int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
   int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
-  unsigned long long ticket;  // written (system scope, after the results) to result[kTicketSlot]: the host polls it
+  unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
 };
-constexpr int kTicketSlot = 4093;  // h_result[4093] holds the ticket of the last finished evaluation (as a u64)
+// tail of the mapped result buffer (doubles / u64 bit patterns)
+constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nout) and result[kFallbackSlot], ^ ticket*kTicketMix
+constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
+constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
+constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
+constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
 struct AlphaArgs {
   const float *igp, *il_old, *il_new;

@@ -306,7 +306,10 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double shp[16];
   __shared__ double outv[2 + 3 * kMaxKnots];  // results are staged here and written to the mapped host buffer by ONE
                                               // wave, contiguously: scattered lane writes over PCIe cost ~0.5 us each
+  __shared__ double shfall;
+  __shared__ unsigned long long shchk;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  if (t == 0) shchk = 0ull;
   const double N = a.npix;
   if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
     // this is ONE workgroup reading tables other CUs just wrote (L2-remote): keep many independent loads in flight
@@ -341,10 +344,10 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     outv[0] = c;
     outv[1] = mu;
     if (a.fallback) {
-      a.result[4094] = (double)(*a.fallback);
+      shfall = (double)(*a.fallback);
       *a.fallback = 0u;
     } else {
-      a.result[4094] = 0.0;
+      shfall = 0.0;
     }
   }
   if (a.measure == 2) {  // gradient magnitude: rows of the Sobel partial table [1+gP][gblocks]
@@ -387,14 +390,27 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   }
   __syncthreads();
   const int nout = 2 + (a.P > a.gP ? a.P : a.gP);
-  if (t < nout) a.result[t] = outv[t];
-  // completion ticket: results first, then (system-scope release) the ticket the host spins on -- the kernel's end
-  // reaches the host through the runtime's completion signal several microseconds later than this store does
-  __threadfence_system();
+  // Results, then a checksum and the completion ticket the host spins on (sync_and_collect): the host accepts the
+  // results once the ticket matches AND the checksum over what it read matches, so no system-scope fence (an L2
+  // write-back, ~3 us here) is needed to order these stores over PCIe -- a torn read simply fails the check and is
+  // repeated.  The kernel's end reaches the host through the runtime's completion signal several microseconds later.
+  unsigned long long bits = 0ull;
+  if (t < nout) {
+    const double v = outv[t];
+    a.result[t] = v;
+    bits = (unsigned long long)__double_as_longlong(v);
+  } else if (t == nout) {
+    const double v = shfall;
+    a.result[kFallbackSlot] = v;
+    bits = (unsigned long long)__double_as_longlong(v);
+  }
+  if (t <= nout) atomicXor(&shchk, bits);
   __syncthreads();
-  if (t == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.result + kTicketSlot), a.ticket, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) {
+    volatile unsigned long long *slots = reinterpret_cast<volatile unsigned long long *>(a.result);
+    slots[kChecksumSlot] = shchk ^ (a.ticket * kTicketMix);
+    slots[kTicketSlot] = a.ticket;
+  }
 }
 
 // per-parameter sum of the gather kernel's block partials -> gsum[P] (the buffer ranks all-reduce)

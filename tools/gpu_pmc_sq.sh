@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): instruction-mix / stall PMC passes of the bench command (one counter group per pass).
 # Usage: tools/gpu_pmc_sq.sh <tag> [bench args...]
+# (a counter group the hardware cannot collect in one pass makes rocprofv3 abort and then hang: every pass is under timeout)
 set -u
 TAG=${1:-sq}; shift || true
 REPO=$(pwd)
@@ -13,10 +14,9 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum"; do
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $OUT/p$i -o pmc -- $BENCH > $OUT/p$i.log 2>&1
+  timeout 180 rocprofv3 --pmc $grp -d $OUT/p$i -o pmc -- $BENCH > $OUT/p$i.log 2>&1
 done
 cd $REPO
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1

@@ -8,10 +8,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o pmc -- $BENCH > $OUT/pmc_tcc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o pmc -- $BENCH > $OUT/pmc_tcc.log 2>&1
 cd $REPO
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
