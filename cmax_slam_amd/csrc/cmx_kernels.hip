@@ -351,42 +351,40 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     }
   }
   if (a.measure == 2) {  // gradient magnitude: rows of the Sobel partial table [1+gP][gblocks]
+    __syncthreads();     // row 0 overwrites the contrast thread 0 staged above
     for (int k = wave; k < 1 + a.gP; k += 16) {
       double s = 0;
       for (int b = lane; b < a.gblocks; b += 64) s += a.gpartials[(size_t)k * a.gblocks + b];
       s = wave_sum(s);
       if (lane == 0) outv[k == 0 ? 0 : 1 + k] = (k == 0) ? s / N : 2.0 * s / N;
     }
-    __syncthreads();
-    const int nout2 = 2 + a.gP;
-    if (t < nout2) a.result[t] = outv[t];
-    return;
-  }
-  // derivative-plane mode: moments of the P blurred planes were reduced into sums[] by reduce_partials
-  for (int k = t; k < a.P; k += 1024) {
-    const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
-    outv[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
-  }
-  // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP)
-  for (int k = wave; k < a.gP; k += 16) {
-    double s = 0, s2 = 0;
-    const double *r1 = a.gpartials + (size_t)k * a.gblocks;
-    const double *r2 = a.gpartials + (size_t)(a.gP + k) * a.gblocks;
-    int b = lane;
-    for (; b + 192 < a.gblocks; b += 256) {  // 4 (x2) independent loads per lane in flight
-      const double v0 = r1[b], v1 = r1[b + 64], v2 = r1[b + 128], v3 = r1[b + 192];
-      double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-      if (a.mu_free) { w0 = r2[b]; w1 = r2[b + 64]; w2 = r2[b + 128]; w3 = r2[b + 192]; }
-      s += (v0 + v1) + (v2 + v3);
-      s2 += (w0 + w1) + (w2 + w3);
+  } else {
+    // derivative-plane mode: moments of the P blurred planes were reduced into sums[] by reduce_partials
+    for (int k = t; k < a.P; k += 1024) {
+      const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
+      outv[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
     }
-    for (; b < a.gblocks; b += 64) {
-      s += r1[b];
-      if (a.mu_free) s2 += r2[b];
+    // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP)
+    for (int k = wave; k < a.gP; k += 16) {
+      double s = 0, s2 = 0;
+      const double *r1 = a.gpartials + (size_t)k * a.gblocks;
+      const double *r2 = a.gpartials + (size_t)(a.gP + k) * a.gblocks;
+      int b = lane;
+      for (; b + 192 < a.gblocks; b += 256) {  // 4 (x2) independent loads per lane in flight
+        const double v0 = r1[b], v1 = r1[b + 64], v2 = r1[b + 128], v3 = r1[b + 192];
+        double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (a.mu_free) { w0 = r2[b]; w1 = r2[b + 64]; w2 = r2[b + 128]; w3 = r2[b + 192]; }
+        s += (v0 + v1) + (v2 + v3);
+        s2 += (w0 + w1) + (w2 + w3);
+      }
+      for (; b < a.gblocks; b += 64) {
+        s += r1[b];
+        if (a.mu_free) s2 += r2[b];
+      }
+      s = wave_sum(s);
+      s2 = wave_sum(s2);
+      if (lane == 0) outv[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
     }
-    s = wave_sum(s);
-    s2 = wave_sum(s2);
-    if (lane == 0) outv[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
   }
   __syncthreads();
   const int nout = 2 + (a.P > a.gP ? a.P : a.gP);
