@@ -68,7 +68,7 @@ struct cmx_ctx {
   PoseEntry *d_poses = nullptr;
   PoseR *d_poseR = nullptr;
   size_t batch_t_cap = 0, poses_cap = 0, poseR_cap = 0;
-  SplineArgs *d_spline = nullptr, *h_spline = nullptr;  // h_spline: pinned staging
+  SplineArgs *h_spline = nullptr;  // temp-trajectory description, passed to the pose-table kernel by value
   std::vector<Quat> knots0;
   float *d_IG = nullptr, *d_IGp = nullptr;
   unsigned char *d_visits = nullptr, *d_mask = nullptr;  // IG_update_times_map_ and the per-pose scratch mask
@@ -893,7 +893,6 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_batch_t);
   hipFree(c->d_poses);
   hipFree(c->d_poseR);
-  hipFree(c->d_spline);
   if (c->h_spline) hipHostFree(c->h_spline);
   hipFree(c->d_IG);
   hipFree(c->d_visits);
@@ -1239,7 +1238,6 @@ int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lu
   HIP_TRY(c, hipMemset(c->d_mask, 0, np));
   HIP_TRY(c, hipMalloc((void **)&c->d_alpha, sizeof(double)));
   HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
-  HIP_TRY(c, hipMalloc((void **)&c->d_spline, sizeof(SplineArgs)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_spline, sizeof(SplineArgs), hipHostMallocDefault));
   return CMX_OK;
 }
@@ -1510,10 +1508,9 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     }
     c->h_spline->knots[i] = q;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_spline, c->h_spline, sizeof(SplineArgs), hipMemcpyHostToDevice, c->stream));
   {
     Span sp(c, CMX_T_POSE);
-    launch_be_pose_table(c->d_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poseR, c->d_poses,
+    launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poseR, c->d_poses,
                          c->stream);
   }
   rc = begin_accum(c, 2 + P, np, P == 0 && adjoint_ok(c) && c->splat_mode == 1);

@@ -160,7 +160,7 @@ void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_
 void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s);
 
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s);
-void launch_be_pose_table(const SplineArgs *d_spline, const long long *d_batch_t, int nb, int order, bool want_j,
+void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,
                           PoseR *outR, PoseEntry *out, hipStream_t s);
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
