@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
           vote4_lds(win, lx, ly, w.dx, w.dy);
         } else {
           vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
+          if (b.tflags) {  // the four corners can straddle up to four image tiles
+            b.tflags[(w.yy / kTileY) * b.tflags_tiles_x + w.xx / kTileX] = 1;
+            b.tflags[(w.yy / kTileY) * b.tflags_tiles_x + (w.xx + 1) / kTileX] = 1;
+            b.tflags[((w.yy + 1) / kTileY) * b.tflags_tiles_x + w.xx / kTileX] = 1;
+            b.tflags[((w.yy + 1) / kTileY) * b.tflags_tiles_x + (w.xx + 1) / kTileX] = 1;
+          }
           nfall++;
         }
       }
@@ -218,7 +224,10 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
       const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
       const fix_t v = win[ly * kBinStride + lx];
-      if (v != 0ull) atomic_add_f32(dst + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), (float)((double)v * kFixInv));
+      if (v != 0ull) {
+        atomic_add_f32(dst + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), (float)((double)v * kFixInv));
+        if (b.tflags) b.tflags[((c.wy0 + ly) / kTileY) * b.tflags_tiles_x + (c.wx0 + lx) / kTileX] = 1;
+      }
     }
   }
 }

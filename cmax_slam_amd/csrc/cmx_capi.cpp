@@ -106,6 +106,12 @@ struct cmx_ctx {
   bool finish_pending = false; // finish_begin ran, finish_end has not
   int pending_P = 0;
   bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
+  // back end: image-tile occupancy of the two ping-pong accumulation buffers and of IGp (see ImgArgs::flags_*)
+  unsigned char *d_tflags = nullptr, *d_tflags_alt = nullptr, *d_igp_flags = nullptr;
+  size_t tflags_cap = 0;          // tiles
+  bool accum_flagged = false;     // every non-zero pixel of d_accum lies in a tile flagged in d_tflags
+  bool alt_flagged = false;       // the same for d_accum_alt / d_tflags_alt
+  bool igp_flags_valid = false;
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
   int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
   int64_t reuse_hits = 0;
@@ -394,16 +400,21 @@ int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast) {
       rc = ensure(c, c->d_accum_alt, c->accum_alt_cap, c->accum_cap > need ? c->accum_cap : need);
       if (rc) return rc;
       c->alt_clean = false;
+      c->alt_flagged = false;  // contents unknown: the next image pass clears every tile
     }
     if (c->alt_clean) {
       std::swap(c->d_accum, c->d_accum_alt);
       std::swap(c->accum_cap, c->accum_alt_cap);
       std::swap(c->accum_clean, c->alt_clean);
+      std::swap(c->d_tflags, c->d_tflags_alt);
+      std::swap(c->accum_flagged, c->alt_flagged);
     }
     if (!c->accum_clean) {
       Span sp(c, CMX_T_ZERO);
       HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
+      if (c->d_tflags) HIP_TRY(c, hipMemsetAsync(c->d_tflags, 0, c->tflags_cap, c->stream));
     }
+    c->accum_flagged = false;  // set by the caller once a flag-marking splat has been launched into the clean buffer
     c->accum_clean = false;  // about to be written
     c->alt_clean = false;    // holds the previous evaluation's planes until this evaluation's image pass clears it
     c->pingpong_planes = nplanes;
@@ -416,6 +427,7 @@ int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast) {
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
   }
   c->accum_clean = false;
+  c->accum_flagged = false;
   return CMX_OK;
 }
 
@@ -558,6 +570,24 @@ void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
   else launch_finalize_only(f, c->stream);
 }
 
+// ping-pong partner clearing + tile-occupancy flags of an image pass (see ImgArgs)
+int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip) {
+  a.tiles_y = (a.H + kTileY - 1) / kTileY;
+  if (a.zero_ptr) {
+    if (c->alt_flagged && c->d_tflags_alt) {
+      a.flags_other = c->d_tflags_alt;  // clear the dirty tiles only
+    } else if (c->d_tflags_alt) {
+      HIP_TRY(c, hipMemsetAsync(c->d_tflags_alt, 0, c->tflags_cap, c->stream));  // everything is cleared: no flag survives
+    }
+    c->alt_flagged = true;  // clean buffer, no flags: trivially consistent
+  }
+  if (may_skip && c->accum_flagged && c->d_tflags && (!a.igp || c->igp_flags_valid)) {
+    a.flags_cur = c->d_tflags;
+    a.flags_igp = a.igp ? c->d_igp_flags : nullptr;
+  }
+  return CMX_OK;
+}
+
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -591,7 +621,9 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   a.tiles_x = (W + kTileX - 1) / kTileX;
   a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
   const size_t nq = 2 + 2 * (size_t)P;
-  int rc = ensure(c, c->d_partials, c->partials_cap, nq * a.nblk);
+  int rc = attach_tiles(c, a, /*may_skip=*/P == 0 && !out_blur0 && !out_blurd);
+  if (rc) return rc;
+  rc = ensure(c, c->d_partials, c->partials_cap, nq * a.nblk);
   if (rc) return rc;
   rc = ensure(c, c->d_sums, c->sums_cap, nq);
   if (rc) return rc;
@@ -658,8 +690,11 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
 int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   const int W = c->imgW, H = c->imgH;
   const size_t np = (size_t)W * H;
+  float *jt_before = c->d_itilde;
   int rc = ensure(c, c->d_itilde, c->itilde_cap, np);
   if (rc) return rc;
+  if (c->d_itilde != jt_before)  // tiles the image pass skips keep whatever they held: make that finite from the start
+    HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
   ImgAdjArgs ia{};
   ImgArgs &a = ia.img;
   a.W = W; a.H = H; a.r = c->radius;
@@ -678,6 +713,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
     a.zero_planes = c->pingpong_planes;
     c->alt_clean = true;
   }
+  rc = attach_tiles(c, a, /*may_skip=*/true);
+  if (rc) return rc;
   ia.jt = c->d_itilde;
   rc = ensure(c, c->d_partials, c->partials_cap, (size_t)2 * a.nblk);
   if (rc) return rc;
@@ -913,6 +950,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_cx);
   hipFree(c->d_cy);
   hipFree(c->d_gpartials);
+  hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
   hipFree(c->d_vparts);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
@@ -1521,13 +1559,37 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     rc = do_binning(c, nullptr, &a);
     if (rc) return rc;
   }
+  // tile occupancy: only for the LDS splat into this context's own ping-pong buffers (planes that are all-reduced
+  // across ranks or owned by the caller would need the flags exchanged as well)
+  const bool use_flags = use_lds && c->pingpong_planes > 0 && !c->comm && !c->accum_external;
+  if (use_flags) {
+    const size_t tiles = (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY);
+    if (tiles > c->tflags_cap || !c->d_tflags || !c->d_tflags_alt || !c->d_igp_flags) {
+      unsigned char **ptrs[3] = {&c->d_tflags, &c->d_tflags_alt, &c->d_igp_flags};
+      for (auto p : ptrs) {
+        if (*p) HIP_TRY(c, hipFree(*p));
+        *p = nullptr;
+        HIP_TRY(c, hipMalloc((void **)p, tiles));
+        HIP_TRY(c, hipMemsetAsync(*p, 0, tiles, c->stream));
+      }
+      c->tflags_cap = tiles;
+      c->alt_flagged = false;   // whatever the partner buffer holds was written without flags
+      c->igp_flags_valid = false;
+    }
+  }
   {
     Span sp(c, CMX_T_SPLAT);
     c->last_used_lds = use_lds;
     if (use_lds) c->fallback_pending = true;
-    if (use_lds) launch_be_splat_lds(a, binned(c), c->stream);
-    else launch_be_splat(a, deriv, c->stream);
+    if (use_lds) {
+      BinnedEvents b = binned(c);
+      if (use_flags) { b.tflags = c->d_tflags; b.tflags_tiles_x = (c->Wp + kTileX - 1) / kTileX; }
+      launch_be_splat_lds(a, b, c->stream);
+    } else {
+      launch_be_splat(a, deriv, c->stream);
+    }
   }
+  c->accum_flagged = use_flags;
   HIP_TRY(c, hipGetLastError());
   c->accum_count = (size_t)(2 + P) * np;
   c->last_P = P;
@@ -1552,6 +1614,12 @@ static int be_first_iter(cmx_ctx *c) {
   if (!c->first_iter) return CMX_OK;
   if (c->ig_nonzero) {
     HIP_TRY(c, hipMemcpyAsync(c->d_IGp, c->d_IG, np * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    c->igp_flags_valid = false;
+    if (c->d_igp_flags) {  // where the global map is non-zero: the image passes cannot skip those tiles
+      HIP_TRY(c, hipMemsetAsync(c->d_igp_flags, 0, c->tflags_cap, c->stream));
+      launch_tile_flags(c->d_IGp, c->Wp, c->Hp, c->d_igp_flags, c->stream);
+      c->igp_flags_valid = true;
+    }
     AlphaArgs a{};
     a.igp = c->d_IGp;
     a.il_old = c->d_accum;

@@ -64,6 +64,12 @@ struct ImgArgs {
   int tiles_x;
   float *zero_ptr;      // optional: the OTHER accumulation buffer (previous evaluation's planes); every workgroup clears
   int zero_planes;      // its own tile there, so the next evaluation needs no memset launch (ping-pong accumulation)
+  // tile occupancy (one byte per kTileX x kTileY tile; back end, LDS splat): a panorama is mostly empty, so the image
+  // passes skip every tile with no vote (and no global-map content) within the filter's reach
+  const unsigned char *flags_cur;   // tiles of src_a/src_b that received votes in this evaluation; null = all tiles
+  const unsigned char *flags_igp;   // tiles where igp is non-zero (only read when igp and flags_cur are set)
+  unsigned char *flags_other;       // tiles of zero_ptr that are dirty: cleared (and un-flagged) selectively; null = all
+  int tiles_y;
 };
 
 // fused image pass of the adjoint gradient: B = G*A (moments of B), Jt = G^T B^ in ONE kernel.
@@ -146,6 +152,8 @@ struct BinnedEvents {
   const Chunk *chunks;
   int nchunks;
   unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
+  unsigned char *tflags;   // optional: image-tile occupancy map marked by every vote that reaches global memory
+  int tflags_tiles_x;
 };
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
@@ -165,6 +173,7 @@ void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, 
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
+void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);

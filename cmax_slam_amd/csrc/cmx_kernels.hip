@@ -171,6 +171,34 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Tile occupancy (ImgArgs::flags_*): is there anything non-zero within `reach` pixels of tile (tx, ty)?
+__device__ __forceinline__ bool tile_active(const ImgArgs &a, int tx, int ty, int reach, int TX, int TY) {
+  if (!a.flags_cur) return true;
+  const int nx = (reach + TX - 1) / TX, ny = (reach + TY - 1) / TY;
+  bool any = false;
+  for (int dy = -ny; dy <= ny; dy++)
+    for (int dx = -nx; dx <= nx; dx++) {
+      const int x = tx + dx, y = ty + dy;
+      if (x < 0 || y < 0 || x >= a.tiles_x || y >= a.tiles_y) continue;  // REFLECT_101 mirrors pixels of the same tiles
+      const int t = y * a.tiles_x + x;
+      any = any || a.flags_cur[t] != 0 || (a.igp && a.flags_igp && a.flags_igp[t] != 0);
+    }
+  return any;
+}
+
+__global__ __launch_bounds__(256) void tile_flags_kernel(const float *plane, int W, int H, int tiles_x, unsigned char *flags) {
+  const size_t n = (size_t)W * H;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    if (plane[i] != 0.f) {
+      const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+      flags[(y / kTileY) * tiles_x + x / kTileX] = 1;
+    }
+}
+void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s) {
+  const int tiles_x = (W + kTileX - 1) / kTileX;
+  hipLaunchKernelGGL(tile_flags_kernel, dim3(1024), dim3(256), 0, s, plane, W, H, tiles_x, flags);
+}
+
 size_t image_lds_bytes(int r) {
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
   return sizeof(float) * ((size_t)rawW * rawH + (size_t)kTileX * rawH) + sizeof(double) * 4;
@@ -207,10 +235,22 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; j++) valid[j] = (x0 + tx < W) && (y0 + tq * 4 + j < H);
   if (a.zero_ptr && g == 0) {  // clear this tile of the other accumulation buffer (nobody reads it during this launch)
-    for (int pl = 0; pl < a.zero_planes; pl++)
+    const bool dirty = !a.flags_other || a.flags_other[tile] != 0;
+    if (dirty) {
+      for (int pl = 0; pl < a.zero_planes; pl++)
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (valid[j]) a.zero_ptr[(size_t)pl * np + (size_t)(y0 + tq * 4 + j) * W + (x0 + tx)] = 0.f;
+        for (int j = 0; j < 4; j++)
+          if (valid[j]) a.zero_ptr[(size_t)pl * np + (size_t)(y0 + tq * 4 + j) * W + (x0 + tx)] = 0.f;
+    }
+    __syncthreads();  // every thread has read the flag
+    if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+  }
+  if (!tile_active(a, tile % a.tiles_x, tile / a.tiles_x, r, kTileX, kTileY)) {  // empty neighbourhood: all sums are zero
+    if (tid == 0 && g == 0) {
+      a.partials[(size_t)0 * a.nblk + tile] = 0.0;
+      a.partials[(size_t)1 * a.nblk + tile] = 0.0;
+    }
+    return;
   }
 
   // pass over plane 0 (k == -1) then the group's derivative planes
@@ -442,6 +482,7 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
 // 2r halo; the moments of B are taken over the tile's own pixels only, so every pixel is counted once.
 // Tile shape / workgroup size are template parameters (swept on MI355X with tools/sweep_image_tile.sh: < 10 % effect).
 constexpr int kAdjTX = 64, kAdjTY = 16, kAdjThreads = 1024;
+static_assert(kAdjTX == kTileX && kAdjTY == kTileY, "the tile-occupancy flags are shared by both image kernels");
 
 size_t image_adjoint_lds_bytes(int r) {
   const size_t aw = kAdjTX + 4 * r, ah = kAdjTY + 4 * r, bw = kAdjTX + 2 * r, bh = kAdjTY + 2 * r;
@@ -482,11 +523,25 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
   if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
-    for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
-      const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
-      const int gx = x0 + (q % TX), gy = y0 + (q / TX);
-      if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
+    const bool dirty = !a.flags_other || a.flags_other[tile] != 0;
+    if (dirty) {
+      for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
+        const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
+        const int gx = x0 + (q % TX), gy = y0 + (q / TX);
+        if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
+      }
     }
+    __syncthreads();  // every thread has read the flag
+    if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+  }
+  // nothing non-zero within 2r of this tile: B and Jt vanish on it, and no vote cell (the only place the gather
+  // reads Jt) lies in it -- leave Jt untouched, contribute zero moments
+  if (!tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + tile] = 0.0;
+      a.partials[(size_t)1 * a.nblk + tile] = 0.0;
+    }
+    return;
   }
 
   for (int idx = tid; idx < aw * ah; idx += NT) {
