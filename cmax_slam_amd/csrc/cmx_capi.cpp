@@ -112,6 +112,9 @@ struct cmx_ctx {
   bool accum_flagged = false;     // every non-zero pixel of d_accum lies in a tile flagged in d_tflags
   bool alt_flagged = false;       // the same for d_accum_alt / d_tflags_alt
   bool igp_flags_valid = false;
+  unsigned *d_tile_list = nullptr, *d_tile_count = nullptr;  // compacted work list of the image passes (large panoramas)
+  size_t tile_list_cap = 0;
+  int tile_count_sel = 0;
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
   int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
   int64_t reuse_hits = 0;
@@ -588,6 +591,27 @@ int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip) {
   return CMX_OK;
 }
 
+// large panoramas: compact the tiles that need work (call once a.partials / flags / zero_ptr are final)
+int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
+  if (!a.flags_cur || a.nblk <= kTileListMin) return CMX_OK;
+  if ((size_t)a.nblk > c->tile_list_cap || !c->d_tile_list) {
+    if (c->d_tile_list) HIP_TRY(c, hipFree(c->d_tile_list));
+    if (c->d_tile_count) HIP_TRY(c, hipFree(c->d_tile_count));
+    c->d_tile_list = c->d_tile_count = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_tile_list, (size_t)a.nblk * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tile_count, 2 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_count, 0, 2 * sizeof(unsigned), c->stream));
+    c->tile_list_cap = (size_t)a.nblk;
+    c->tile_count_sel = 0;
+  }
+  unsigned *cur = c->d_tile_count + c->tile_count_sel, *next = c->d_tile_count + (c->tile_count_sel ^ 1);
+  c->tile_count_sel ^= 1;  // this pass counts in `cur` and zeroes `next` for the pass after it
+  launch_tile_list(a, reach, c->d_tile_list, cur, next, c->stream);
+  a.tile_list = c->d_tile_list;
+  a.tile_count = cur;
+  return CMX_OK;
+}
+
 // image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
   const int W = c->imgW, H = c->imgH;
@@ -662,6 +686,8 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   }
   {
     Span sp(c, CMX_T_IMAGE);
+    rc = maybe_tile_list(c, a, c->radius);
+    if (rc) return rc;
     launch_image_moments(a, c->stream);
     FinalizeArgs f{};
     f.P = P;
@@ -672,8 +698,9 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     f.sums = c->d_sums;
     f.result = c->d_result;
     f.fallback = c->d_fallback;
-    if (P == 0 && a.nblk <= 2048) {
+    if (P == 0 && (a.nblk <= 2048 || a.tile_list)) {
       f.direct = 1;
+      f.nvalid = a.tile_count;  // list path: partial rows are compact, one entry per listed tile
       issue_finalize(c, f, false);
     } else {
       issue_finalize(c, f, true);
@@ -746,8 +773,13 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   f.partials = c->d_partials;
   f.sums = c->d_sums;
   f.result = c->d_result;
-  const bool direct = a.nblk <= 2048;  // few tiles: finalize sums the per-tile moments itself
+  if (phase != 2) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
+    rc = maybe_tile_list(c, a, 2 * c->radius);
+    if (rc) return rc;
+  }
+  const bool direct = a.nblk <= 2048 || a.tile_list;  // few entries: finalize sums the per-tile moments itself
   f.direct = direct ? 1 : 0;
+  f.nvalid = a.tile_count;
   f.mu_free = 1;
   if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
     f.gpartials = c->d_gpartials;
@@ -951,6 +983,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_cy);
   hipFree(c->d_gpartials);
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
+  hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);

@@ -70,7 +70,15 @@ struct ImgArgs {
   const unsigned char *flags_igp;   // tiles where igp is non-zero (only read when igp and flags_cur are set)
   unsigned char *flags_other;       // tiles of zero_ptr that are dirty: cleared (and un-flagged) selectively; null = all
   int tiles_y;
+  // large panoramas (> kTileListMin tiles): a one-workgroup pre-pass (launch_tile_list) compacts the tiles that need
+  // work into tile_list (bit 31: active = run the filters, bit 30: dirty = clear the partner's tile; low bits: tile) and
+  // the image kernels walk that list with a bounded grid instead of launching one workgroup per panorama tile
+  const unsigned *tile_list;
+  const unsigned *tile_count;
 };
+constexpr int kTileListMin = 2048, kTileListGrid = 1024;
+// reach: pixels of filter support beyond the tile (r for the moments pass, 2r for the adjoint pass)
+void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, hipStream_t s);
 
 // fused image pass of the adjoint gradient: B = G*A (moments of B), Jt = G^T B^ in ONE kernel.
 // G^T(B - mu) = G^T B - mu*c with c = G^T 1 = cx(x)*cy(y) (1 in the interior, differs only within r of the border), and the
@@ -117,6 +125,7 @@ struct FinalizeArgs {
   int gblocks, gP;
   unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
   int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
+  const unsigned *nvalid;  // direct mode: device count of valid entries per row (tile work list); null = nblk
   int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
   unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
 };

@@ -199,6 +199,55 @@ void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, h
   hipLaunchKernelGGL(tile_flags_kernel, dim3(1024), dim3(256), 0, s, plane, W, H, tiles_x, flags);
 }
 
+// One thread per tile: classify it active / dirty from the occupancy flags of its neighbourhood, un-flag the partner's
+// dirty tiles, compact the listed tiles (wave ballot -> workgroup offsets -> one atomic per workgroup on the list
+// counter).  The order of the list does not matter (tiles are independent).  count[0] is this pass's counter, count[1]
+// the next pass's: it is zeroed here, so no memset sits between two passes (the host alternates the pair).
+__global__ __launch_bounds__(1024) void tile_list_kernel(ImgArgs a, int reach, unsigned *list, unsigned *count, unsigned *next_count) {
+  __shared__ unsigned wave_tot[16];
+  __shared__ unsigned block_base;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x * 1024 + tid;
+  if (t == 0) *next_count = 0u;
+  const int nx = (reach + kTileX - 1) / kTileX, ny = (reach + kTileY - 1) / kTileY;
+  bool listed = false;
+  unsigned entry = 0;
+  if (t < ntiles) {
+    const int tx = t % a.tiles_x, ty = t / a.tiles_x;
+    const bool dirty = a.zero_ptr && (!a.flags_other || a.flags_other[t] != 0);
+    bool active = false;
+    for (int dy = -ny; dy <= ny; dy++)
+      for (int dx = -nx; dx <= nx; dx++) {
+        const int x = tx + dx, y = ty + dy;
+        if (x >= 0 && y >= 0 && x < a.tiles_x && y < a.tiles_y) {
+          const int q = y * a.tiles_x + x;
+          active = active || a.flags_cur[q] != 0 || (a.igp && a.flags_igp && a.flags_igp[q] != 0);
+        }
+      }
+    if (dirty && a.flags_other) a.flags_other[t] = 0;
+    listed = active || dirty;
+    entry = (unsigned)t | (active ? 0x80000000u : 0u) | (dirty ? 0x40000000u : 0u);
+  }
+  const unsigned long long m = __ballot(listed);
+  const unsigned before = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned tot = 0;
+    for (int w = 0; w < 16; w++) tot += wave_tot[w];
+    block_base = tot ? atomicAdd(count, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned off = block_base;
+  for (int w = 0; w < wave; w++) off += wave_tot[w];
+  if (listed) list[off + before] = entry;
+}
+void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, hipStream_t s) {
+  const int ntiles = a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL(tile_list_kernel, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, a, reach, list, count, next_count);
+}
+
 size_t image_lds_bytes(int r) {
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
   return sizeof(float) * ((size_t)rawW * rawH + (size_t)kTileX * rawH) + sizeof(double) * 4;
@@ -221,36 +270,44 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   float *raw = reinterpret_cast<float *>(smem_raw + 4 * sizeof(double));
   float *rowb = raw + rawW * rawH;
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
   const int tx = tid & 63, tq = tid >> 6;  // output column, row quad
   const size_t np = (size_t)W * H;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
   const int g = blockIdx.z;                // plane group; group 0 also owns the I moments
   const int k_beg = g * kPlaneGroup;
   const int k_end = min(a.P, k_beg + kPlaneGroup);
+  // one tile per workgroup, or (large panoramas) a walk over the compacted list of tiles that need work
+  const int n_work = a.tile_list ? (int)(*a.tile_count) : a.nblk;
+  for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+  const unsigned entry = a.tile_list ? a.tile_list[wi] : (unsigned)wi;
+  const int tile = (int)(entry & 0x3fffffffu);
+  const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
+  __syncthreads();  // LDS of the previous tile is free
 
   float I[4] = {0.f, 0.f, 0.f, 0.f};
   bool valid[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) valid[j] = (x0 + tx < W) && (y0 + tq * 4 + j < H);
   if (a.zero_ptr && g == 0) {  // clear this tile of the other accumulation buffer (nobody reads it during this launch)
-    const bool dirty = !a.flags_other || a.flags_other[tile] != 0;
+    const bool dirty = a.tile_list ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
     if (dirty) {
       for (int pl = 0; pl < a.zero_planes; pl++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (valid[j]) a.zero_ptr[(size_t)pl * np + (size_t)(y0 + tq * 4 + j) * W + (x0 + tx)] = 0.f;
     }
-    __syncthreads();  // every thread has read the flag
-    if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
-  }
-  if (!tile_active(a, tile % a.tiles_x, tile / a.tiles_x, r, kTileX, kTileY)) {  // empty neighbourhood: all sums are zero
-    if (tid == 0 && g == 0) {
-      a.partials[(size_t)0 * a.nblk + tile] = 0.0;
-      a.partials[(size_t)1 * a.nblk + tile] = 0.0;
+    if (!a.tile_list) {  // (the list pre-pass has already un-flagged it)
+      __syncthreads();   // every thread has read the flag
+      if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
     }
-    return;
+  }
+  const int slot = a.tile_list ? wi : tile;  // row position of this tile's partial moments
+  if (a.tile_list ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, r, kTileX, kTileY)) {
+    if (tid == 0 && g == 0) {  // nothing within reach: all sums are zero
+      a.partials[(size_t)0 * a.nblk + slot] = 0.0;
+      a.partials[(size_t)1 * a.nblk + slot] = 0.0;
+    }
+    continue;
   }
 
   // pass over plane 0 (k == -1) then the group's derivative planes
@@ -306,8 +363,8 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
       if (g == 0) {
         const double t0 = block_sum(sI, red), t1 = block_sum(sII, red);
         if (tid == 0) {
-          a.partials[(size_t)0 * a.nblk + tile] = t0;
-          a.partials[(size_t)1 * a.nblk + tile] = t1;
+          a.partials[(size_t)0 * a.nblk + slot] = t0;
+          a.partials[(size_t)1 * a.nblk + slot] = t1;
         }
       }
     } else {
@@ -318,12 +375,14 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
       }
     }
   }
+  }  // work loop
 }
 
 void launch_image_moments(const ImgArgs &a, hipStream_t s) {
   const int groups = a.P > 0 ? (a.P + kPlaneGroup - 1) / kPlaneGroup : 1;
-  if (a.r == 4) hipLaunchKernelGGL(image_moments_kernel<4>, dim3(a.nblk, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
-  else hipLaunchKernelGGL(image_moments_kernel<-1>, dim3(a.nblk, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
+  const int gx = a.tile_list ? min(a.nblk, kTileListGrid) : a.nblk;
+  if (a.r == 4) hipLaunchKernelGGL(image_moments_kernel<4>, dim3(gx, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
+  else hipLaunchKernelGGL(image_moments_kernel<-1>, dim3(gx, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
 }
 
 // ---------------------------------------------------------------------------------------------- reduce + finalize
@@ -357,7 +416,8 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     const int row = wave & 1, part = wave >> 1;  // 8 waves per row
     double p = 0;
     const double *src = a.partials + (size_t)row * a.nblk;
-    for (int b = part * 64 + lane; b < a.nblk; b += 8 * 64) p += src[b];
+    const int nvalid = a.nvalid ? (int)(*a.nvalid) : a.nblk;  // list path: only the first *nvalid entries were written
+    for (int b = part * 64 + lane; b < nvalid; b += 8 * 64) p += src[b];
     p = wave_sum(p);
     if (lane == 0) shp[wave] = p;
     __syncthreads();
@@ -519,11 +579,16 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   float *bufB = bufR + bw * ah;                                             // B^ (0 outside the image), bw x bh
   float *bufT = bufB + bw * bh;                                             // row pass of G^T, TX x bh
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
+  // one tile per workgroup, or (large panoramas) a walk over the compacted list of tiles that need work
+  const int n_work = a.tile_list ? (int)(*a.tile_count) : a.nblk;
+  for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+  const unsigned entry = a.tile_list ? a.tile_list[wi] : (unsigned)wi;
+  const int tile = (int)(entry & 0x3fffffffu);
+  const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
+  __syncthreads();  // LDS of the previous tile is free
   if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
-    const bool dirty = !a.flags_other || a.flags_other[tile] != 0;
+    const bool dirty = a.tile_list ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
     if (dirty) {
       for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
         const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
@@ -531,17 +596,20 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
         if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
       }
     }
-    __syncthreads();  // every thread has read the flag
-    if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+    if (!a.tile_list) {  // (the list pre-pass has already un-flagged it)
+      __syncthreads();   // every thread has read the flag
+      if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+    }
   }
   // nothing non-zero within 2r of this tile: B and Jt vanish on it, and no vote cell (the only place the gather
   // reads Jt) lies in it -- leave Jt untouched, contribute zero moments
-  if (!tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
+  const int slot = a.tile_list ? wi : tile;  // row position of this tile's partial moments
+  if (a.tile_list ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
     if (tid == 0) {
-      a.partials[(size_t)0 * a.nblk + tile] = 0.0;
-      a.partials[(size_t)1 * a.nblk + tile] = 0.0;
+      a.partials[(size_t)0 * a.nblk + slot] = 0.0;
+      a.partials[(size_t)1 * a.nblk + slot] = 0.0;
     }
-    return;
+    continue;
   }
 
   for (int idx = tid; idx < aw * ah; idx += NT) {
@@ -582,8 +650,8 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   {
     const double t0 = block_sum_n(sI, red, NT / 64), t1 = block_sum_n(sII, red, NT / 64);
     if (tid == 0) {
-      a.partials[(size_t)0 * a.nblk + tile] = t0;
-      a.partials[(size_t)1 * a.nblk + tile] = t1;
+      a.partials[(size_t)0 * a.nblk + slot] = t0;
+      a.partials[(size_t)1 * a.nblk + slot] = t1;
     }
   }
   __syncthreads();
@@ -623,14 +691,16 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
       g.jt[(size_t)gy * W + gx] = s;
     }
   }
+  }  // work loop
 }
 
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s) {
+  const int gx = a.img.tile_list ? min(a.img.nblk, kTileListGrid) : a.img.nblk;
   if (a.img.r == 4)
-    hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads>), dim3(a.img.nblk), dim3(kAdjThreads),
+    hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads>), dim3(gx), dim3(kAdjThreads),
                        image_adjoint_lds_bytes(4), s, a);
   else
-    hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads>), dim3(a.img.nblk), dim3(kAdjThreads),
+    hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads>), dim3(gx), dim3(kAdjThreads),
                        image_adjoint_lds_bytes(a.img.r), s, a);
 }
 
