@@ -257,7 +257,10 @@ size_t image_lds_bytes(int r) {
 // LDS: raw tile with halo -> row-blurred tile -> column pass in registers -> fp64 moments.
 // Row pass:  s = k[0]*S[x-r]; s += k[j]*S[x-r+j]           (generic row filter order)
 // Col pass:  s = k[r]*T[y];   s += k[r+j]*(T[y+j]+T[y-j])  (symmetric column filter order)
-template <int R>  // R >= 0: compile-time radius (loops unroll, taps live in registers, index maths is constant); -1: a.r
+// LIST: walk the compacted tile work list with a bounded grid (large panoramas); otherwise one tile per workgroup and
+// the loop below runs exactly once (kept as a loop so that both forms share one body; a runtime trip count costs the
+// one-tile form its register allocation -- the taps spill -- hence the compile-time switch)
+template <int R, bool LIST>  // R >= 0: compile-time radius (loops unroll, taps live in registers, index maths is constant); -1: a.r
 __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int r = (R >= 0) ? R : a.r;
@@ -276,33 +279,32 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   const int g = blockIdx.z;                // plane group; group 0 also owns the I moments
   const int k_beg = g * kPlaneGroup;
   const int k_end = min(a.P, k_beg + kPlaneGroup);
-  // one tile per workgroup, or (large panoramas) a walk over the compacted list of tiles that need work
-  const int n_work = a.tile_list ? (int)(*a.tile_count) : a.nblk;
-  for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-  const unsigned entry = a.tile_list ? a.tile_list[wi] : (unsigned)wi;
+  const int n_work = LIST ? (int)(*a.tile_count) : 0;
+  for (int wi = blockIdx.x, once = 1; LIST ? (wi < n_work) : (once != 0); wi += gridDim.x, once = 0) {
+  const unsigned entry = LIST ? a.tile_list[wi] : (unsigned)wi;
   const int tile = (int)(entry & 0x3fffffffu);
   const int x0 = (tile % a.tiles_x) * kTileX, y0 = (tile / a.tiles_x) * kTileY;
-  __syncthreads();  // LDS of the previous tile is free
+  if (LIST) __syncthreads();  // LDS of the previous tile is free
 
   float I[4] = {0.f, 0.f, 0.f, 0.f};
   bool valid[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) valid[j] = (x0 + tx < W) && (y0 + tq * 4 + j < H);
   if (a.zero_ptr && g == 0) {  // clear this tile of the other accumulation buffer (nobody reads it during this launch)
-    const bool dirty = a.tile_list ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
+    const bool dirty = LIST ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
     if (dirty) {
       for (int pl = 0; pl < a.zero_planes; pl++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (valid[j]) a.zero_ptr[(size_t)pl * np + (size_t)(y0 + tq * 4 + j) * W + (x0 + tx)] = 0.f;
     }
-    if (!a.tile_list) {  // (the list pre-pass has already un-flagged it)
+    if (!LIST) {  // (the list pre-pass has already un-flagged it)
       __syncthreads();   // every thread has read the flag
       if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
     }
   }
-  const int slot = a.tile_list ? wi : tile;  // row position of this tile's partial moments
-  if (a.tile_list ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, r, kTileX, kTileY)) {
+  const int slot = LIST ? wi : tile;  // row position of this tile's partial moments
+  if (LIST ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, r, kTileX, kTileY)) {
     if (tid == 0 && g == 0) {  // nothing within reach: all sums are zero
       a.partials[(size_t)0 * a.nblk + slot] = 0.0;
       a.partials[(size_t)1 * a.nblk + slot] = 0.0;
@@ -380,9 +382,16 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
 
 void launch_image_moments(const ImgArgs &a, hipStream_t s) {
   const int groups = a.P > 0 ? (a.P + kPlaneGroup - 1) / kPlaneGroup : 1;
-  const int gx = a.tile_list ? min(a.nblk, kTileListGrid) : a.nblk;
-  if (a.r == 4) hipLaunchKernelGGL(image_moments_kernel<4>, dim3(gx, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
-  else hipLaunchKernelGGL(image_moments_kernel<-1>, dim3(gx, 1, groups), dim3(kImgThreads), image_lds_bytes(a.r), s, a);
+  const size_t lds = image_lds_bytes(a.r);
+  if (a.tile_list) {
+    const dim3 g(min(a.nblk, kTileListGrid), 1, groups);
+    if (a.r == 4) hipLaunchKernelGGL((image_moments_kernel<4, true>), g, dim3(kImgThreads), lds, s, a);
+    else hipLaunchKernelGGL((image_moments_kernel<-1, true>), g, dim3(kImgThreads), lds, s, a);
+  } else {
+    const dim3 g(a.nblk, 1, groups);
+    if (a.r == 4) hipLaunchKernelGGL((image_moments_kernel<4, false>), g, dim3(kImgThreads), lds, s, a);
+    else hipLaunchKernelGGL((image_moments_kernel<-1, false>), g, dim3(kImgThreads), lds, s, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- reduce + finalize
@@ -563,7 +572,7 @@ __device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves)
   return s;
 }
 
-template <int R, int TX, int TY, int NT>
+template <int R, int TX, int TY, int NT, bool LIST>  // LIST: see image_moments_kernel
 __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const ImgArgs &a = g.img;
@@ -580,15 +589,14 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   float *bufT = bufB + bw * bh;                                             // row pass of G^T, TX x bh
   const int tid = threadIdx.x;
   const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
-  // one tile per workgroup, or (large panoramas) a walk over the compacted list of tiles that need work
-  const int n_work = a.tile_list ? (int)(*a.tile_count) : a.nblk;
-  for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-  const unsigned entry = a.tile_list ? a.tile_list[wi] : (unsigned)wi;
+  const int n_work = LIST ? (int)(*a.tile_count) : 0;
+  for (int wi = blockIdx.x, once = 1; LIST ? (wi < n_work) : (once != 0); wi += gridDim.x, once = 0) {
+  const unsigned entry = LIST ? a.tile_list[wi] : (unsigned)wi;
   const int tile = (int)(entry & 0x3fffffffu);
   const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
-  __syncthreads();  // LDS of the previous tile is free
+  if (LIST) __syncthreads();  // LDS of the previous tile is free
   if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
-    const bool dirty = a.tile_list ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
+    const bool dirty = LIST ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
     if (dirty) {
       for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
         const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
@@ -596,15 +604,15 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
         if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
       }
     }
-    if (!a.tile_list) {  // (the list pre-pass has already un-flagged it)
+    if (!LIST) {  // (the list pre-pass has already un-flagged it)
       __syncthreads();   // every thread has read the flag
       if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
     }
   }
   // nothing non-zero within 2r of this tile: B and Jt vanish on it, and no vote cell (the only place the gather
   // reads Jt) lies in it -- leave Jt untouched, contribute zero moments
-  const int slot = a.tile_list ? wi : tile;  // row position of this tile's partial moments
-  if (a.tile_list ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
+  const int slot = LIST ? wi : tile;  // row position of this tile's partial moments
+  if (LIST ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
     if (tid == 0) {
       a.partials[(size_t)0 * a.nblk + slot] = 0.0;
       a.partials[(size_t)1 * a.nblk + slot] = 0.0;
@@ -695,13 +703,16 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
 }
 
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s) {
-  const int gx = a.img.tile_list ? min(a.img.nblk, kTileListGrid) : a.img.nblk;
-  if (a.img.r == 4)
-    hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads>), dim3(gx), dim3(kAdjThreads),
-                       image_adjoint_lds_bytes(4), s, a);
-  else
-    hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads>), dim3(gx), dim3(kAdjThreads),
-                       image_adjoint_lds_bytes(a.img.r), s, a);
+  const size_t lds = image_adjoint_lds_bytes(a.img.r);
+  if (a.img.tile_list) {
+    const dim3 g(min(a.img.nblk, kTileListGrid));
+    if (a.img.r == 4) hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, a);
+    else hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, a);
+  } else {
+    const dim3 g(a.img.nblk);
+    if (a.img.r == 4) hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, a);
+    else hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- gather passes
