@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from cmax_slam_amd import _lib, synth
-from util import RTOL, rel_scalar, rel_vec
+from util import RTOL, grad_cancellation_scale, rel_scalar, rel_vec
 
 pytestmark = pytest.mark.gpu
 N_FE = int(os.environ.get("CMX_FUZZ_FE", "10"))   # CMX_FUZZ_FE=300 CMX_FUZZ_BE=300 for a deeper one-off sweep
@@ -91,6 +91,12 @@ def test_backend_random_configuration(hip, oracle, seed):
         tag = (seed, step, W, H, Wp, Hp, order, K, nf, N, batch, rate, sigma, measure, kind, fast)
         assert rel_scalar(c, c_ref) < RTOL, tag
         if want:
-            assert rel_vec(g, g_ref) < RTOL, tag
+            # 1e-5 of the gradient, plus the fp32 noise floor of the formula itself where the gradient is a small
+            # difference of large sums (4 of 250 random configurations, all with sigma >= 2 near a stationary point,
+            # deviate by 1.4e-5..2.3e-5 of |g| in BOTH the adjoint and the reference-shaped GPU path)
+            iwe_ref, planes_ref = ref.iwe(x, planes=True)
+            floor = 3e-7 * grad_cancellation_scale(iwe_ref, planes_ref, measure)
+            err = np.abs(g - g_ref).max()
+            assert err <= RTOL * np.abs(g_ref).max() + floor, tag + (err, np.abs(g_ref).max(), floor)
     if IG is not None:
         assert rel_scalar(be.alpha, ref.alpha) < RTOL
