@@ -19,3 +19,14 @@ for _ in range(2):
     c, g = be.eval(np.zeros(w.P)); t2 = time.perf_counter()
     c, g = be.eval(np.full(w.P, 1e-3)); t3 = time.perf_counter()
     print("be set_window %.3f ms, first eval (with binning) %.3f ms, next eval %.3f ms" % ((t1-t)*1e3, (t2-t1)*1e3, (t3-t2)*1e3))
+# small packets cut from a device-resident event store (the end-to-end example's regime: 60k events at 240x180)
+s = synth.event_stream(2e6, 0.2, 240, 180, 200.0, 200.0, 119.5, 89.5)
+store = evaluator.EventStore(s.W, s.H, len(s.x)); store.push(s.x, s.y, s.t_ns)
+fe2 = evaluator.FrontendEvaluator(s.W, s.H, s.lut); fe2.set_fast_path()
+for k in range(4):
+    first = 50_000 + 20_000 * k
+    t = time.perf_counter(); fe2.set_packet_from(store, first, 60_000, int(s.t_ns[first + 30_000]), s.fx, s.fy, s.cx, s.cy); t1 = time.perf_counter()
+    c, g = fe2.eval((0.2, 1.5, 0.3)); t2 = time.perf_counter()
+    c, g = fe2.eval((0.21, 1.5, 0.3)); t3 = time.perf_counter()
+    c = fe2.eval((0.22, 1.5, 0.3), False)[0]; t4 = time.perf_counter()
+    print("60k-event packet from the store: set %.3f ms, first eval (with binning) %.3f ms, next fdf %.3f ms, f %.3f ms" % ((t1-t)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3))
