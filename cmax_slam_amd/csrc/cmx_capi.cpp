@@ -752,7 +752,9 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
   const int P2 = 2 * (P > 0 ? P : 1);
   rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * P2);
   if (rc) return rc;
-  const int parts_per_batch = (c->per_batch + 62) / 64 + 1;
+  // four events per lane in the back-end gather when a lane's four events cannot straddle a batch boundary
+  const int slice_shift = (c->kind == KIND_BE && c->per_batch % 4 == 0) ? 8 : 6;
+  const int parts_per_batch = ((c->per_batch + (1 << slice_shift) - 2) >> slice_shift) + 1;
   if (c->kind == KIND_BE) {
     rc = ensure(c, c->d_vparts, c->vparts_cap, (size_t)(c->nb > 0 ? c->nb : 1) * parts_per_batch * 6);
     if (rc) return rc;
@@ -823,6 +825,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
       g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
       g.vparts = c->d_vparts;
       g.parts_per_batch = parts_per_batch;
+      g.slice_shift = slice_shift;
       if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream);
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }

@@ -111,7 +111,8 @@ struct BeGatherArgs {
   const float *cx, *cy;    // as in FeGatherArgs
   int r;
   double *vparts;          // [nb][parts_per_batch][6]: per-batch partial sums of V (3) and of the border vector U (3)
-  int parts_per_batch;     // 64-event slices a batch can touch
+  int parts_per_batch;     // wave slices a batch can touch
+  int slice_shift;         // log2 of the events one wave pass covers: 6 (one event per lane) or 8 (four per lane)
 };
 
 struct FinalizeArgs {
