@@ -102,7 +102,9 @@ def main():
         n_total, img = len(w.x), "%dx%d" % (w.Wp, w.Hp)
         workload_obj = w
     if adjoint:
-        ev.set_fast_path()
+        ev.set_fast_path()       # the library's default, set explicitly
+    else:
+        ev.set_reference_path()  # derivative planes + one global atomic per vote
     # every timed step is a FULL evaluation: the df-after-f image reuse (on by default, used by the solver) is off here
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
 

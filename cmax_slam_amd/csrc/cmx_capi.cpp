@@ -55,7 +55,7 @@ struct cmx_ctx {
   double sigma = 0;
   int radius = 0;
   float taps[2 * kMaxRadius + 1] = {1.f};
-  int grad_mode = CMX_GRAD_PLANES, splat_mode = 0;
+  int grad_mode = CMX_GRAD_ADJOINT, splat_mode = 1;  // production configuration by default; cmx_set_option selects the reference-shaped path
 
   // front end
   double fx = 0, fy = 0, cx = 0, cy = 0;

@@ -71,9 +71,16 @@ class _Evaluator:
                 "reuse_hits": int(s[4])}
 
     def set_fast_path(self):
-        """The production configuration: adjoint gradient + LDS-privatised splat (+ image reuse, on by default)."""
+        """The production configuration and the library's default: adjoint gradient + LDS-privatised splat (+ image
+        reuse, on by default)."""
         self.set_grad_mode(_lib.GRAD_ADJOINT)
         self.set_splat_mode(1)
+
+    def set_reference_path(self):
+        """The reference's own data flow: derivative planes, one global fp32 atomic per vote (14-50x slower; also
+        what produces the derivative images)."""
+        self.set_grad_mode(_lib.GRAD_PLANES)
+        self.set_splat_mode(0)
 
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""

@@ -82,8 +82,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "create failed: %s\n", cmx_status_string(rc));
     return 1;
   }
-  cmx_set_option(est.cmx, CMX_OPT_GRAD_MODE, CMX_GRAD_ADJOINT);
-  cmx_set_option(est.cmx, CMX_OPT_SPLAT_MODE, 1);
+  // (a new context already runs the production configuration: adjoint gradient + LDS-privatised splat)
   rc = cmx_frontend_set_packet(est.cmx, n, x.data(), y.data(), t.data(), t_ref, K[0], K[1], K[2], K[3], 100, 1.0, CMX_VARIANCE);
   if (rc != CMX_OK) {
     fprintf(stderr, "set_packet failed: %s: %s\n", cmx_status_string(rc), cmx_last_error(est.cmx));

@@ -55,9 +55,9 @@ enum {
 
 /* cmx_set_option keys */
 enum {
-  CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_PLANES (default) | CMX_GRAD_ADJOINT */
-  CMX_OPT_SPLAT_MODE = 2, /* 0 = one global fp32 atomic per vote (default);
-                             1 = LDS-privatised: events are sorted once per packet/window by the 32x32 destination
+  CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_ADJOINT (default) | CMX_GRAD_PLANES */
+  CMX_OPT_SPLAT_MODE = 2, /* 0 = one global fp32 atomic per vote;
+                             1 (default) = LDS-privatised: events are sorted once per packet/window by the 32x32 destination
                                  tile of their vote, workgroups accumulate in LDS and flush touched pixels; votes that
                                  leave a window (parameters drifted) take the global path, so results stay exact;
                                  applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */

@@ -28,4 +28,22 @@ def hip():
     L = _lib.lib()
     assert L.cmx_device_count() > 0, "no HIP device visible: -m gpu tests need a GPU"
     from cmax_slam_amd import evaluator
-    return evaluator
+    import types
+
+    # The parity tests were written against the reference-shaped path (derivative planes, global atomics) as the
+    # default and opt into the production path with set_fast_path(); the library's own default is the production
+    # path, so the fixture restores the tests' default here.  Both paths stay covered.
+    class FrontendEvaluator(evaluator.FrontendEvaluator):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.set_reference_path()
+
+    class BackendEvaluator(evaluator.BackendEvaluator):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.set_reference_path()
+
+    ns = types.SimpleNamespace(**{k: v for k, v in vars(evaluator).items() if not k.startswith("__")})
+    ns.FrontendEvaluator = FrontendEvaluator
+    ns.BackendEvaluator = BackendEvaluator
+    return ns
