@@ -155,10 +155,25 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
+// wave64 sum of a double with DPP moves (no LDS crossbar): inclusive row_shr scan inside each row of 16 lanes, then
+// row_bcast15 / row_bcast31 carry the row totals upwards; lane 63 holds the total, read back as a wave-uniform value
+// (valid in every lane).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);  // lanes without a source add 0
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row = row total
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // block-wide sum of a per-thread double; result valid in thread 0.  red: 4 doubles of LDS per call site.
@@ -752,7 +767,7 @@ int fe_gather_blocks(int n) {
 }
 
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
-  __shared__ double red[4];
+  __shared__ double red[4 * 6];
   const FeSplatArgs &a = g.ev;
   double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
   constexpr int U = 4;  // events in flight per thread (latency-bound gathers)
@@ -800,18 +815,24 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
       }
     }
   }
-  // partial table layout: [column][block], columns = S1 (3) then S2 (3)
+  // partial table layout: [column][block], columns = S1 (3) then S2 (3).  One barrier for all six sums: wave sums,
+  // one LDS row per wave, six threads add the four rows (in the order block_sum uses).  The border sums S2 are zero
+  // for almost every wave: their shuffles are skipped wave-uniformly.
+  double v[6];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const double t = block_sum(acc[k], red);
-    if (threadIdx.x == 0) g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = t;
+  for (int k = 0; k < 3; k++) v[k] = wave_sum(acc[k]);
+  const bool any2 = g.cx && __any(acc2[0] != 0.0 || acc2[1] != 0.0 || acc2[2] != 0.0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) v[3 + k] = any2 ? wave_sum(acc2[k]) : 0.0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) red[wave * 6 + k] = v[k];
   }
-  if (g.cx) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const double t = block_sum(acc2[k], red);
-      if (threadIdx.x == 0) g.gpartials[(size_t)(3 + k) * gridDim.x + blockIdx.x] = t;
-    }
+  __syncthreads();
+  if (threadIdx.x < (g.cx ? 6 : 3)) {
+    const int k = threadIdx.x;
+    g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
   }
 }
 
