@@ -186,6 +186,19 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// two block-wide sums behind one pair of barriers (wave order as in block_sum); red: 2 * nwaves doubles
+__device__ __forceinline__ void block_sum2(double v0, double v1, double *red, int nwaves, double &t0, double &t1) {
+  v0 = wave_sum(v0);
+  v1 = wave_sum(v1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { red[2 * wave] = v0; red[2 * wave + 1] = v1; }
+  __syncthreads();
+  t0 = 0;
+  t1 = 0;
+  for (int w = 0; w < nwaves; w++) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+}
+
 // Tile occupancy (ImgArgs::flags_*): is there anything non-zero within `reach` pixels of tile (tx, ty)?
 __device__ __forceinline__ bool tile_active(const ImgArgs &a, int tx, int ty, int reach, int TX, int TY) {
   if (!a.flags_cur) return true;
@@ -265,7 +278,7 @@ void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *cou
 
 size_t image_lds_bytes(int r) {
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
-  return sizeof(float) * ((size_t)rawW * rawH + (size_t)kTileX * rawH) + sizeof(double) * 4;
+  return sizeof(float) * ((size_t)rawW * rawH + (size_t)kTileX * rawH) + sizeof(double) * 8;
 }
 
 // One workgroup = one 64x16 output tile x one group of <= kPlaneGroup derivative planes (blockIdx.z).
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   for (int j = 0; j < 2 * kMaxRadius + 1; j++) taps[j] = (R < 0 || j <= 2 * R) ? a.taps[j] : 0.f;
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
   double *red = reinterpret_cast<double *>(smem_raw);
-  float *raw = reinterpret_cast<float *>(smem_raw + 4 * sizeof(double));
+  float *raw = reinterpret_cast<float *>(smem_raw + 8 * sizeof(double));
   float *rowb = raw + rawW * rawH;
   const int tid = threadIdx.x;
   const int tx = tid & 63, tq = tid >> 6;  // output column, row quad
@@ -378,14 +391,16 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
     }
     if (k < 0) {
       if (g == 0) {
-        const double t0 = block_sum(sI, red), t1 = block_sum(sII, red);
+        double t0, t1;
+        block_sum2(sI, sII, red, kImgThreads / 64, t0, t1);
         if (tid == 0) {
           a.partials[(size_t)0 * a.nblk + slot] = t0;
           a.partials[(size_t)1 * a.nblk + slot] = t1;
         }
       }
     } else {
-      const double t0 = block_sum(sD, red), t1 = block_sum(sID, red);
+      double t0, t1;
+      block_sum2(sD, sID, red, kImgThreads / 64, t0, t1);
       if (tid == 0) {
         a.partials[(size_t)(2 + 2 * k) * a.nblk + tile] = t0;
         a.partials[(size_t)(3 + 2 * k) * a.nblk + tile] = t1;
@@ -570,7 +585,7 @@ static_assert(kAdjTX == kTileX && kAdjTY == kTileY, "the tile-occupancy flags ar
 
 size_t image_adjoint_lds_bytes(int r) {
   const size_t aw = kAdjTX + 4 * r, ah = kAdjTY + 4 * r, bw = kAdjTX + 2 * r, bh = kAdjTY + 2 * r;
-  return sizeof(double) * 16 + sizeof(float) * (aw * ah + bw * ah + bw * bh + (size_t)kAdjTX * bh);
+  return sizeof(double) * 32 + sizeof(float) * (aw * ah + bw * ah + bw * bh + (size_t)kAdjTX * bh);
 }
 int image_adjoint_tiles_x(int W) { return (W + kAdjTX - 1) / kAdjTX; }
 int image_adjoint_tiles(int W, int H) { return image_adjoint_tiles_x(W) * ((H + kAdjTY - 1) / kAdjTY); }
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   for (int j = 0; j < 2 * kMaxRadius + 1; j++) taps[j] = (R < 0 || j <= 2 * R) ? a.taps[j] : 0.f;
   const int aw = TX + 4 * r, ah = TY + 4 * r, bw = TX + 2 * r, bh = TY + 2 * r;
   double *red = reinterpret_cast<double *>(smem_raw);
-  float *bufA = reinterpret_cast<float *>(smem_raw + 16 * sizeof(double));  // raw, aw x ah
+  float *bufA = reinterpret_cast<float *>(smem_raw + 32 * sizeof(double));  // raw, aw x ah
   float *bufR = bufA + aw * ah;                                             // row-blurred raw, bw x ah
   float *bufB = bufR + bw * ah;                                             // B^ (0 outside the image), bw x bh
   float *bufT = bufB + bw * bh;                                             // row pass of G^T, TX x bh
@@ -671,7 +686,8 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
     }
   }
   {
-    const double t0 = block_sum_n(sI, red, NT / 64), t1 = block_sum_n(sII, red, NT / 64);
+    double t0, t1;
+    block_sum2(sI, sII, red, NT / 64, t0, t1);
     if (tid == 0) {
       a.partials[(size_t)0 * a.nblk + slot] = t0;
       a.partials[(size_t)1 * a.nblk + slot] = t1;
