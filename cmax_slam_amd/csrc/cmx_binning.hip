@@ -133,8 +133,7 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
     double px[kUnroll], py[kUnroll], pz[kUnroll], dt[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
-      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
-      px[u] = l[0]; py[u] = l[1]; pz[u] = l[2];
+      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
       dt[u] = a.batch_dt[bi[u]];
     }
 #pragma unroll
@@ -191,8 +190,7 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     double b0[U], b1[U], b2[U], R[U][9];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
-      b0[u] = l[0]; b1[u] = l[1]; b2[u] = l[2];
+      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
       const double *Rp = a.poseR[bi[u]].R;
 #pragma unroll
       for (int k = 0; k < 9; k++) R[u][k] = Rp[k];

@@ -41,6 +41,7 @@ struct cmx_ctx {
   // sensor + LUT
   int W = 0, H = 0;
   double *d_lut = nullptr;
+  double *d_lut2 = nullptr;  // (x, y) pairs, 16-byte entries: present when the caller's table has z == 1 everywhere
 
   // packed events
   uint32_t *d_xy = nullptr;
@@ -380,6 +381,17 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   const size_t nl = (size_t)W * H * 3;
   HIP_TRY(c, hipMalloc((void **)&c->d_lut, nl * sizeof(double)));
   HIP_TRY(c, hipMemcpy(c->d_lut, lut, nl * sizeof(double), hipMemcpyHostToDevice));
+  {  // image_geometry's rays are (x, y, 1): then the hot kernels read 16-byte (x, y) entries with one load
+    const size_t npx = nl / 3;
+    bool unit_z = true;
+    for (size_t i = 0; i < npx && unit_z; i++) unit_z = lut[3 * i + 2] == 1.0;
+    if (unit_z && npx > 0) {
+      std::vector<double> xy(2 * npx);
+      for (size_t i = 0; i < npx; i++) { xy[2 * i] = lut[3 * i]; xy[2 * i + 1] = lut[3 * i + 1]; }
+      HIP_TRY(c, hipMalloc((void **)&c->d_lut2, 2 * npx * sizeof(double)));
+      HIP_TRY(c, hipMemcpy(c->d_lut2, xy.data(), 2 * npx * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   c->result_cap = 4096;
   HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
@@ -536,6 +548,7 @@ FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]) {
   a.xy = c->d_xy;
   a.batch_dt = c->d_batch_dt;
   a.lut = c->d_lut;
+  a.lut2 = c->d_lut2;
   a.planes = c->d_accum;
   return a;
 }
@@ -556,6 +569,7 @@ BeSplatArgs be_args(const cmx_ctx *c) {
   a.poseR = c->d_poseR;
   a.poses = c->d_poses;
   a.lut = c->d_lut;
+  a.lut2 = c->d_lut2;
   a.planes = c->d_accum;
   return a;
 }
@@ -959,6 +973,7 @@ void cmx_destroy(cmx_ctx *c) {
   for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
   for (auto e : c->event_pool) hipEventDestroy(e);
   hipFree(c->d_lut);
+  hipFree(c->d_lut2);
   hipFree(c->d_xy);
   if (c->h_xy) hipHostFree(c->h_xy);
   hipFree(c->d_batch_dt);

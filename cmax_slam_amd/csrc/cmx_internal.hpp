@@ -22,6 +22,7 @@ struct FeSplatArgs {
   const uint32_t *xy;
   const double *batch_dt;  // per batch: time_batch.toSec() - time_ref.toSec()
   const double *lut;       // W*H*3
+  const double *lut2;      // W*H*2 (x, y), 16-byte entries, present when every z == 1 (image_geometry's rays); else null
   float *planes;           // [1 + 3][H][W]: IWE, dI/dwx, dI/dwy, dI/dwz
 };
 
@@ -46,6 +47,7 @@ struct BeSplatArgs {
   const PoseR *poseR;
   const PoseEntry *poses;
   const double *lut;
+  const double *lut2;      // as in FeSplatArgs
   float *planes;  // [2 + P][Hp][Wp]: IL_old, IL_new, derivative planes
 };
 

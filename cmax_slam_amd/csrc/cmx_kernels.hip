@@ -809,8 +809,7 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
-      px[u] = l[0]; py[u] = l[1]; pz[u] = l[2];
+      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -942,8 +941,7 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
       double b0[4], b1[4], b2[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const double *l = a.lut + 3 * ((size_t)((e[u] >> 16) & 0x7fff) * a.W + (e[u] & 0xffff));
-        b0[u] = l[0]; b1[u] = l[1]; b2[u] = l[2];
+        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {

@@ -14,6 +14,19 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
 }
 
 // per-event front-end warp: fp64 first-order rotation + pinhole; fp32 bilinear offsets; optional 2x3 Jacobian rows
+// bearing vector of sensor pixel (ex, ey): one 16-byte load when the table's z column is all ones
+template <typename Args>
+__device__ __forceinline__ void load_bearing(const Args &a, int ex, int ey, double &b0, double &b1, double &b2) {
+  const size_t i = (size_t)ey * a.W + ex;
+  if (a.lut2) {
+    const double2 v = *reinterpret_cast<const double2 *>(a.lut2 + 2 * i);
+    b0 = v.x; b1 = v.y; b2 = 1.0;
+  } else {
+    const double *l = a.lut + 3 * i;
+    b0 = l[0]; b1 = l[1]; b2 = l[2];
+  }
+}
+
 struct FeWarp {
   int xx, yy;
   float dx, dy;
@@ -56,8 +69,9 @@ __device__ __forceinline__ FeWarp fe_warp_math(const FeSplatArgs &a, double px, 
 template <bool DERIV>
 __device__ __forceinline__ FeWarp fe_warp_core(const FeSplatArgs &a, uint32_t e, double dt) {
   const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
-  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
-  return fe_warp_math<DERIV>(a, b[0], b[1], b[2], dt);
+  double b0, b1, b2;
+  load_bearing(a, ex, ey, b0, b1, b2);
+  return fe_warp_math<DERIV>(a, b0, b1, b2, dt);
 }
 
 template <bool DERIV>
@@ -141,11 +155,12 @@ __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e,
 template <int DERIV>
 __device__ __forceinline__ BeWarp be_warp_core(const BeSplatArgs &a, uint32_t e, int batch) {
   const int ex = e & 0xffff, ey = (e >> 16) & 0x7fff;
-  const double *b = a.lut + 3 * ((size_t)ey * a.W + ex);
+  double b0, b1, b2;
+  load_bearing(a, ex, ey, b0, b1, b2);
   double R[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) R[k] = a.poseR[batch].R[k];
-  return be_warp_math<DERIV>(a, e, batch, b[0], b[1], b[2], R);
+  return be_warp_math<DERIV>(a, e, batch, b0, b1, b2, R);
 }
 
 template <int DERIV>
