@@ -160,9 +160,10 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
     }
   }
 }
-void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s) {
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
-  hipLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+  else hipLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
 }
 
 __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
@@ -229,9 +230,10 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     }
   }
 }
-void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s) {
+void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
-  hipLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  if (t0 || t1) hipExtLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+  else hipLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
 }
 
 }  // namespace cmx

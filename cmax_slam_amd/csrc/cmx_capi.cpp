@@ -154,6 +154,8 @@ struct cmx_ctx {
   // timing
   bool timing = false;
   int timing_mask = 0;  // bit i: record HIP events around kernel class i
+  int timing_every = 1;           // sample every n-th evaluation
+  unsigned long long timing_tick = 0;  // evaluations (accumulate calls) since timing was enabled
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;
   double t_ms[CMX_T_COUNT] = {0};
@@ -294,23 +296,34 @@ hipEvent_t get_event(cmx_ctx *c) {
   hipEventCreate(&e);
   return e;
 }
+// kernel_exact = true: the launcher attaches the two events to the kernel itself (hipExtLaunchKernelGGL start / stop:
+// the dispatch's own begin / end timestamps, what rocprofv3 reports); otherwise the events are recorded on the
+// stream around whatever the scope launches (kernel time + boundaries).
 struct Span {
   cmx_ctx *c;
   TimedSpan s{};
-  bool on;
-  Span(cmx_ctx *ctx, int cls) : c(ctx), on(ctx->timing && ((ctx->timing_mask >> cls) & 1)) {
+  bool on, kernel_exact, used = false;
+  Span(cmx_ctx *ctx, int cls, bool exact = false)
+      : c(ctx), on(ctx->timing && ((ctx->timing_mask >> cls) & 1) && (ctx->timing_tick % ctx->timing_every) == 0),
+        kernel_exact(exact) {
     if (on) {
       s.cls = cls;
       s.a = get_event(c);
       s.b = get_event(c);
-      hipEventRecord(s.a, c->stream);
+      if (!kernel_exact) hipEventRecord(s.a, c->stream);
     }
   }
+  hipEvent_t t0() { used = true; return on && kernel_exact ? s.a : nullptr; }
+  hipEvent_t t1() { return on && kernel_exact ? s.b : nullptr; }
   ~Span() {
-    if (on) {
-      hipEventRecord(s.b, c->stream);
-      c->spans.push_back(s);
+    if (!on) return;
+    if (kernel_exact && !used) {  // nothing was launched with the events: give them back
+      c->event_pool.push_back(s.a);
+      c->event_pool.push_back(s.b);
+      return;
     }
+    if (!kernel_exact) hipEventRecord(s.b, c->stream);
+    c->spans.push_back(s);
   }
 };
 void collect_spans(cmx_ctx *c) {  // call after the stream has been synchronised
@@ -817,7 +830,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
     if (!direct) launch_reduce_partials(f, c->stream);
   }
   {
-    Span sp(c, CMX_T_GATHER);
+    Span sp(c, CMX_T_GATHER, /*exact=*/true);
     if (c->kind == KIND_FE) {
       FeGatherArgs g{};
       g.ev = fe_args(c, c->last_x);
@@ -828,7 +841,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
         g.sxy = c->d_sxy;
         g.sbatch = c->d_sbatch;
       }
-      if (c->n_packed > 0) launch_fe_gather(g, c->stream);
+      if (c->n_packed > 0) launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     } else {
       BeGatherArgs g{};
@@ -840,7 +853,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase = 0) {
       g.vparts = c->d_vparts;
       g.parts_per_batch = parts_per_batch;
       g.slice_shift = slice_shift;
-      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream);
+      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }
     if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
@@ -1060,8 +1073,10 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
 
 int cmx_timing_enable(cmx_ctx *c, int on) {
   if (!c) return CMX_ERR_INVALID_ARG;
-  c->timing = on != 0;
-  c->timing_mask = on;
+  c->timing = (on & 0xff) != 0;
+  c->timing_mask = on & 0xff;
+  c->timing_every = (on >> 8) > 0 ? (on >> 8) : 1;  // bits 8..: sample every n-th evaluation only
+  c->timing_tick = 0;
   return CMX_OK;
 }
 int cmx_timing_get(cmx_ctx *c, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]) {
@@ -1188,6 +1203,7 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
 }
 
 static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+  c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
   const size_t np = (size_t)c->W * c->H;
   int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);
   if (rc) return rc;
@@ -1199,11 +1215,11 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
     if (rc) return rc;
   }
   {
-    Span sp(c, CMX_T_SPLAT);
+    Span sp(c, CMX_T_SPLAT, /*exact=*/true);
     c->last_used_lds = use_lds;
     if (use_lds) c->fallback_pending = true;
-    if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream);
-    else launch_fe_splat(a, nplanes > 1, c->stream);
+    if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream, sp.t0(), sp.t1());
+    else launch_fe_splat(a, nplanes > 1, c->stream, sp.t0(), sp.t1());
   }
   HIP_TRY(c, hipGetLastError());
   c->accum_count = nplanes * np;
@@ -1582,6 +1598,7 @@ int cmx_backend_set_window_from(cmx_ctx *c, const cmx_events *e, int64_t first, 
 }
 
 static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
+  c->timing_tick++;  // see fe_accumulate
   const size_t np = (size_t)c->Wp * c->Hp;
   const int Kopt = c->K - c->num_fixed;
   c->last_adjoint = want_grad && adjoint_ok(c);
@@ -1629,15 +1646,15 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     }
   }
   {
-    Span sp(c, CMX_T_SPLAT);
+    Span sp(c, CMX_T_SPLAT, /*exact=*/true);
     c->last_used_lds = use_lds;
     if (use_lds) c->fallback_pending = true;
     if (use_lds) {
       BinnedEvents b = binned(c);
       if (use_flags) { b.tflags = c->d_tflags; b.tflags_tiles_x = (c->Wp + kTileX - 1) / kTileX; }
-      launch_be_splat_lds(a, b, c->stream);
+      launch_be_splat_lds(a, b, c->stream, sp.t0(), sp.t1());
     } else {
-      launch_be_splat(a, deriv, c->stream);
+      launch_be_splat(a, deriv, c->stream, sp.t0(), sp.t1());
     }
   }
   c->accum_flagged = use_flags;

@@ -2,6 +2,7 @@
 // cmx_capi.cpp.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -176,13 +177,15 @@ int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *kin, uint32_t
 void launch_apply_perm(const uint32_t *xy, const uint32_t *idx_sorted, int per_batch, int n, uint32_t *sxy,
                        uint32_t *sbatch, hipStream_t s);
 void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int ntiles_plus2, int *tile_start, hipStream_t s);
-void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s);
-void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s);
+// t0 / t1 (optional): events bracketing exactly the kernel(s) of the launch (hipExtLaunchKernelGGL start / stop events,
+// the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
-void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s);
+void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,
                           PoseR *outR, PoseEntry *out, hipStream_t s);
-void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s);
+void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_image_moments(const ImgArgs &a, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
@@ -190,8 +193,8 @@ void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
-int launch_fe_gather(const FeGatherArgs &a, hipStream_t s);  // returns the number of blocks (rows of gpartials)
-int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s);  // returns the rows of gpartials (batch-kernel blocks)
+int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the number of blocks (rows of gpartials)
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the rows of gpartials (batch-kernel blocks)
 int be_batch_blocks(int nb);
 int gather_blocks(int n);
 int fe_gather_blocks(int n);

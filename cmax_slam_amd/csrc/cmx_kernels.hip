@@ -17,6 +17,12 @@
 #include "cmx_internal.hpp"
 #include "cmx_warp.hpp"
 
+// launch with optional kernel-exact timing events (null, null = plain launch)
+#define CMX_LAUNCH(kernel, grid, block, lds, stream, t0, t1, ...)                                            \
+  do {                                                                                                      \
+    if ((t0) || (t1)) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, t0, t1, 0, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+  } while (0)
 namespace cmx {
 
 // ---------------------------------------------------------------------------------------------- K1
@@ -54,10 +60,10 @@ static int splat_grid(int n) {
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
-void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s) {
+void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (a.n <= 0) return;
-  if (deriv) hipLaunchKernelGGL(fe_splat_kernel<true>, dim3(splat_grid(a.n)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(fe_splat_kernel<false>, dim3(splat_grid(a.n)), dim3(256), 0, s, a);
+  if (deriv) CMX_LAUNCH(fe_splat_kernel<true>, dim3(splat_grid(a.n)), dim3(256), 0, s, t0, t1, a);
+  else CMX_LAUNCH(fe_splat_kernel<false>, dim3(splat_grid(a.n)), dim3(256), 0, s, t0, t1, a);
 }
 
 // ---------------------------------------------------------------------------------------------- K0
@@ -136,15 +142,15 @@ __global__ __launch_bounds__(256) void be_splat_kernel(BeSplatArgs a) {
   }
 }
 
-void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s) {
+void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (a.n <= 0) return;
   const dim3 g(splat_grid(a.n)), b(256);
   if (a.order == 2) {
-    if (deriv) hipLaunchKernelGGL((be_splat_kernel<2, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((be_splat_kernel<2, false>), g, b, 0, s, a);
+    if (deriv) CMX_LAUNCH((be_splat_kernel<2, true>), g, b, 0, s, t0, t1, a);
+    else CMX_LAUNCH((be_splat_kernel<2, false>), g, b, 0, s, t0, t1, a);
   } else {
-    if (deriv) hipLaunchKernelGGL((be_splat_kernel<4, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((be_splat_kernel<4, false>), g, b, 0, s, a);
+    if (deriv) CMX_LAUNCH((be_splat_kernel<4, true>), g, b, 0, s, t0, t1, a);
+    else CMX_LAUNCH((be_splat_kernel<4, false>), g, b, 0, s, t0, t1, a);
   }
 }
 
@@ -851,9 +857,9 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   }
 }
 
-int launch_fe_gather(const FeGatherArgs &a, hipStream_t s) {
+int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int blocks = fe_gather_blocks(a.ev.n);
-  hipLaunchKernelGGL(fe_gather_kernel, dim3(blocks), dim3(256), 0, s, a);
+  CMX_LAUNCH(fe_gather_kernel, dim3(blocks), dim3(256), 0, s, t0, t1, a);
   return blocks;
 }
 
@@ -1028,9 +1034,10 @@ int be_batch_blocks(int nb) {
   return blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
 }
 
-int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s) {
-  if (a.slice_shift == 8) hipLaunchKernelGGL(be_gather4_kernel, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, a);
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+  // (t0, t1) bracket the per-event kernel; the per-batch pass that follows is not part of that span
+  if (a.slice_shift == 8) CMX_LAUNCH(be_gather4_kernel, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, t0, t1, a);
+  else CMX_LAUNCH(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, t0, t1, a);
   const int blocks = be_batch_blocks(nb);
   if (a.ev.order == 2) hipLaunchKernelGGL(be_gather_batch_kernel<2>, dim3(blocks), dim3(256), 0, s, a, nb);
   else hipLaunchKernelGGL(be_gather_batch_kernel<4>, dim3(blocks), dim3(256), 0, s, a, nb);

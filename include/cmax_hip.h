@@ -280,7 +280,9 @@ int cmx_bearing_lut(int W, int H, const double K[9], const double D[5], const do
 /* ------------------------------------------------------------------ timing hooks ------------------------
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
  * cmx_timing_enable(ctx, mask) makes every evaluation record events around the kernel classes whose bit is set
- * (bit CMX_T_SPLAT, ...; 0x1f = all, 0 = off);
+ * (bit CMX_T_SPLAT, ...; 0x1f = all, 0 = off); mask | (n << 8) samples every n-th evaluation only.  The per-event
+ * kernels (splat, gather) carry their events on the kernel itself (hipExtLaunchKernelGGL start / stop: the dispatch's
+ * own timestamps, the same rocprofv3 reports); the other classes are bracketed on the stream;
  * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
 enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COUNT = 5 };
 /* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
