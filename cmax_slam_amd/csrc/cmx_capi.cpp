@@ -41,6 +41,7 @@ struct cmx_ctx {
   // sensor + LUT
   int W = 0, H = 0;
   double *d_lut = nullptr;
+  long long *d_batch_err = nullptr;  // error kind / position reported by the device-side batch-time pass
   double *d_lut2 = nullptr;  // (x, y) pairs, 16-byte entries: present when the caller's table has z == 1 everywhere
 
   // packed events
@@ -987,6 +988,7 @@ void cmx_destroy(cmx_ctx *c) {
   for (auto e : c->event_pool) hipEventDestroy(e);
   hipFree(c->d_lut);
   hipFree(c->d_lut2);
+  hipFree(c->d_batch_err);
   hipFree(c->d_xy);
   if (c->h_xy) hipHostFree(c->h_xy);
   hipFree(c->d_batch_dt);
@@ -1395,9 +1397,10 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     if (rc) return rc;
     xy = c->h_xy;
   }
-  std::vector<long long> bt((size_t)nbatches);
+  std::vector<long long> bt(d_raw ? 0 : (size_t)nbatches);
   std::atomic<int> err_kind(0);
   std::atomic<long long> err_at(-1);
+  if (!d_raw)  // (windows cut from the event store get their batch times from a kernel, below)
   parallel_ranges(nbatches, [&](int64_t b0, int64_t b1) {
     for (int64_t b = b0; b < b1; b++) {
       const int64_t beg = b * B;
@@ -1407,7 +1410,7 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
       const long long st = tb - start_ns;
       if (st < 0 || st / dt_ns + order > K) { err_kind = CMX_ERR_SPLINE_RANGE; err_at = tb; return; }
       bt[(size_t)b] = tb;
-      if (rate == 1 || d_raw) continue;  // packed below by a flat, vectorisable loop (packed index == event index) / on the device
+      if (rate == 1) continue;  // packed below by a flat, vectorisable loop (packed index == event index)
       uint32_t *dst = xy + b * per_batch;
       for (int64_t e = beg; e < end; e += rate)
         *dst++ = (uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u);
@@ -1453,7 +1456,14 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     else
       HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n_packed_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   }
-  if (nb) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
+  if (nb && !d_raw) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
+  if (nb && d_raw) {  // batch times + their validation on the device; the two error words come back with the final sync
+    if (!c->d_batch_err) HIP_TRY(c, hipMalloc((void **)&c->d_batch_err, 2 * sizeof(long long)));
+    long long *d_err = c->d_batch_err;
+    HIP_TRY(c, hipMemsetAsync(d_err, 0, 2 * sizeof(long long), c->stream));
+    launch_be_batch_times(reinterpret_cast<const long long *>(d_t), (long long)n, B, nb, (long long)start_ns, (long long)dt_ns, order,
+                          K, c->d_batch_t, d_err, c->stream);
+  }
   const size_t np = (size_t)c->Wp * c->Hp;
   if (IG == CMX_KEEP_MAP) {
     c->ig_nonzero = true;  // resident map: contents unknown to the host; the alpha kernel counts the non-zeros itself
@@ -1473,6 +1483,14 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   c->h_result[kAlphaSlot] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (nb && d_raw) {
+    long long e[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(e, c->d_batch_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e[0] == CMX_ERR_TIME_ORDER) return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", e[1]);
+    if (e[0] == CMX_ERR_SPLINE_RANGE)
+      return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", e[1], K,
+                  (long long)start_ns, (long long)dt_ns);
+  }
   c->n_packed = (int)n_packed_total;
   c->per_batch = per_batch;
   c->nb = nb;

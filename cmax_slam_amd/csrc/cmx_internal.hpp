@@ -209,6 +209,8 @@ void launch_sobel_moments(const SobelArgs &a, hipStream_t s);
 int sobel_blocks(int W, int H);
 
 // back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
+void launch_be_batch_times(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns, int order, int K,
+                           long long *bt, long long *err, hipStream_t s);
 void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,
                                int n_packed, long long t_next, uint32_t *out, hipStream_t s);
 

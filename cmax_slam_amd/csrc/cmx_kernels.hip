@@ -14,6 +14,7 @@
 // Numerics: geometry in fp64 exactly as the reference, weights/accumulators fp32.  This file is compiled with
 // -ffp-contract=off so the fp64 warp, the fp32 weights and the fp32 blur are bit-identical to the CPU path for
 // identical inputs; the only reordering is the fp32 atomic accumulation.
+#include "../../include/cmax_hip.h"
 #include "cmx_internal.hpp"
 #include "cmx_warp.hpp"
 
@@ -1096,6 +1097,41 @@ __global__ void be_pack_from_store_kernel(const uint32_t *raw, const long long *
 void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,
                                int n_packed, long long t_next, uint32_t *out, hipStream_t s) {
   hipLaunchKernelGGL(be_pack_from_store_kernel, dim3(2048), dim3(256), 0, s, raw, t, n, B, rate, per_batch, n_packed, t_next, out);
+}
+
+// Per-batch pose times of a window cut from the event store, on the device (the host loop over 50k batches costs more
+// than a millisecond): time_batch = t_first + Duration((t_last - t_first).toSec() * 0.5) with ros::Duration's
+// floor + round, exactly the host's time_batch_ns (event_pano_warper.cpp:239-242).  err[0] = first kind of error seen
+// (CMX_ERR_TIME_ORDER / CMX_ERR_SPLINE_RANGE), err[1] = where.
+__global__ void be_batch_times_kernel(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns,
+                                      int order, int K, long long *bt, long long *err) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    const long long beg = (long long)b * B;
+    const long long end = (n - beg > B) ? beg + B : n;
+    const long long t_first = t[beg], t_last = t[end - 1];
+    if (t_last < t_first) {
+      if (atomicCAS((unsigned long long *)&err[0], 0ull, (unsigned long long)CMX_ERR_TIME_ORDER) == 0ull) err[1] = beg;
+      continue;
+    }
+    const long long d = t_last - t_first;
+    long long ds = d / 1000000000LL, dn = d % 1000000000LL;
+    if (dn < 0) { dn += 1000000000LL; ds -= 1; }
+    const double half = ((double)ds + 1e-9 * (double)dn) * 0.5;
+    const long long hs = (long long)floor(half);
+    const long long hn = (long long)round((half - (double)hs) * 1e9);
+    const long long tb = t_first + hs * 1000000000LL + hn;
+    const long long st = tb - start_ns;
+    if (st < 0 || st / dt_ns + order > K) {
+      if (atomicCAS((unsigned long long *)&err[0], 0ull, (unsigned long long)CMX_ERR_SPLINE_RANGE) == 0ull) err[1] = tb;
+      continue;
+    }
+    bt[b] = tb;
+  }
+}
+void launch_be_batch_times(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns, int order, int K,
+                           long long *bt, long long *err, hipStream_t s) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(be_batch_times_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, t, n, B, nb, start_ns, dt_ns, order, K, bt, err);
 }
 
 // ---------------------------------------------------------------------------------------------- Sobel moments

@@ -70,6 +70,31 @@ def test_backend_window_from_the_store(hip, oracle, rate):
     assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
 
 
+def test_store_window_batch_times_are_validated_on_the_device(hip):
+    """Windows cut from the store get their per-batch pose times (ros::Duration arithmetic) from a kernel; a batch time
+    outside the spline's support must come back as CMX_ERR_SPLINE_RANGE exactly as on the host path, and the context
+    must stay usable."""
+    from cmax_slam_amd import _lib
+    w = synth.backend_window(20_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 1, 0.2, seed=53)
+    store = hip.EventStore(w.W, w.H, capacity=len(w.x))
+    store.push(w.x, w.y, w.t_ns)
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    for kw in (dict(start_ns=w.start_ns + 10_000_000), dict(knots=w.knots_init[:3])):  # starts too late / ends too early
+        with pytest.raises(hip.CmaxHipError) as e:
+            be.set_window_from(store, 0, len(w.x), w.order, kw.get("knots", w.knots_init), kw.get("start_ns", w.start_ns),
+                               w.dt_ns, 0, w.t_next_win_beg_ns)
+        assert e.value.status == _lib.ERR_SPLINE_RANGE
+        x = np.zeros(64)
+        c = _lib.C.c_double()
+        assert _lib.lib().cmx_backend_eval(be._ctx, x.ctypes.data_as(_lib.c_dp), _lib.C.byref(c), None) == _lib.ERR_STATE  # no half-installed window
+    be.set_window_from(store, 0, len(w.x), w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    host = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    host.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    d = np.full(w.P, 0.004)
+    (c0, g0), (c1, g1) = be.eval(d), host.eval(d)
+    assert rel_scalar(c0, c1) < 1e-7 and rel_vec(g0, g1) < 1e-6  # same batch times, same events
+
+
 def test_store_setup_is_cheaper_than_reupload(hip):
     p = synth.config2()
     store = hip.EventStore(p.W, p.H, capacity=len(p.x))
