@@ -1,7 +1,7 @@
 """BASELINE config 1 (ecrot_synth front end: 100k events, 240x180): the CPU oracle and the HIP path side by side --
 one fdf evaluation and one full FR-CG solve from omega = 0 (the same restated driver over both)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np
 from cmax_slam_amd import _lib, synth, evaluator, solver
 from oracle import pyoracle as po
