@@ -80,6 +80,67 @@ void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int count, int 
   hipLaunchKernelGGL(tile_lower_bound_kernel, dim3((count + 255) / 256), dim3(256), 0, s, keys_sorted, n, count, tile_start);
 }
 
+// Chunk table on the device: tile t owns the sorted events [tile_start[t], tile_start[t+1]); it is cut into chunks of at
+// most M events.  One workgroup: per-tile chunk counts, an exclusive scan, then the full-size chunks of every tile
+// first and the remainders after them (largest-first ordering keeps the tail of the launch short).  Entry `ntiles` is
+// the sentinel tile of events whose vote is not accepted under the binning parameters: no LDS window.
+__global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x,
+                                                            int margin, int M, Chunk *chunks, int *count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_sh[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2) base_sh[tid] = 0;
+  __syncthreads();
+  // pass 0: full chunks; pass 1: the remainder chunk of each tile
+  for (int pass = 0; pass < 2; pass++) {
+    for (int t0 = 0; t0 <= ntiles; t0 += 1024) {
+      const int t = t0 + tid;
+      int beg = 0, len = 0, nfull = 0, rem = 0;
+      if (t <= ntiles) {
+        beg = tile_start[t];
+        len = tile_start[t + 1] - beg;
+        if (len < 0) len = 0;
+        nfull = len / M;
+        rem = len - nfull * M;
+      }
+      const int mine = pass == 0 ? nfull : (rem > 0 ? 1 : 0);
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      int off = base_sh[0] + incl - mine, tot = 0;
+      for (int w = 0; w < 16; w++) {
+        if (w < wave) off += wave_tot[w];
+        tot += wave_tot[w];
+      }
+      if (mine > 0) {
+        const bool sentinel = (t == ntiles);
+        const int tile = t / planes_per_tile, plane = t % planes_per_tile;
+        const int wx0 = sentinel ? -200000000 : (tile % tiles_x) * kBinTile - margin;
+        const int wy0 = sentinel ? -200000000 : (tile / tiles_x) * kBinTile - margin;
+        if (pass == 0) {
+          for (int k = 0; k < nfull; k++) chunks[off + k] = Chunk{wx0, wy0, beg + k * M, beg + (k + 1) * M, plane, 0};
+        } else {
+          chunks[off] = Chunk{wx0, wy0, beg + nfull * M, beg + len, plane, 0};
+        }
+      }
+      __syncthreads();
+      if (tid == 0) base_sh[0] += tot;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *count = base_sh[0];
+}
+void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
+                         int *count, hipStream_t s) {
+  hipLaunchKernelGGL(build_chunks_kernel, dim3(1), dim3(1024), 0, s, tile_start, ntiles, planes_per_tile, tiles_x, margin, M,
+                     chunks, count);
+}
+
 // ---------------------------------------------------------------------------------------------- LDS splats
 // One workgroup = one chunk of sorted events.  win: kBinWindow^2 fp32 per plane.
 // LDS accumulators are 64-bit fixed point (2^-30 units), not fp32: on gfx950 ds_add_f32 retires ONE lane at a time
@@ -112,6 +173,7 @@ constexpr int kUnroll = 4;  // events in flight per thread: the loop is latency-
 
 __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];
+  if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
@@ -168,6 +230,7 @@ void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_
 
 __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];  // one plane per chunk: the sort key separates IL_old / IL_new events
+  if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;

@@ -132,7 +132,9 @@ struct cmx_ctx {
   size_t tile_start_cap = 0;
   Chunk *d_chunks = nullptr;
   size_t chunks_cap = 0;
-  int nchunks = 0;
+  int nchunks = 0;          // launch bound of the chunk table (its true length lives in d_nchunks)
+  int *d_nchunks = nullptr;
+  bool nchunks_exact = false;  // nchunks has been replaced by the table's true length (read back after the first evaluation)
   unsigned *d_fallback = nullptr;
   int64_t rebin_count = 0;
   double last_fallback_frac = 0;
@@ -493,7 +495,15 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   }
   rc = ensure(c, c->d_tile_start, c->tile_start_cap, (size_t)ntiles + 2);
   if (rc) return rc;
-  std::vector<int> ts((size_t)ntiles + 2, 0);
+  // chunk size: hot tiles are split so that ~3 workgroups per CU exist; big chunks amortise the window flush
+  int M = n / 768;
+  M = M < 2048 ? 2048 : (M > 32768 ? 32768 : M);
+  M = (M + 255) / 256 * 256;
+  // every tile contributes floor(len/M) full chunks and at most one remainder: an upper bound known on the host
+  const int max_chunks = (n / M) + ntiles + 2;
+  rc = ensure(c, c->d_chunks, c->chunks_cap, (size_t)max_chunks);
+  if (rc) return rc;
+  if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
   if (n > 0) {
     if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
     else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
@@ -512,30 +522,16 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       return fail(c, CMX_ERR_HIP, "rocprim radix sort failed");
     launch_apply_perm(c->d_xy, c->d_idx_s, c->per_batch, n, c->d_sxy, c->d_sbatch, c->stream);
     launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
-    HIP_TRY(c, hipMemcpyAsync(ts.data(), c->d_tile_start, ((size_t)ntiles + 2) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
+    launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->nchunks = max_chunks;
+    c->nchunks_exact = false;
+  } else {
+    HIP_TRY(c, hipMemsetAsync(c->d_nchunks, 0, sizeof(int), c->stream));
+    c->nchunks = 0;
+    c->nchunks_exact = true;
   }
-  // chunk table: hot tiles are split so that ~3 workgroups per CU exist; big chunks amortise the window flush
-  int M = n / 768;
-  M = M < 2048 ? 2048 : (M > 32768 ? 32768 : M);
-  M = (M + 255) / 256 * 256;
-  std::vector<Chunk> chunks;
-  for (int t = 0; t <= ntiles; t++) {
-    const int beg = ts[t], end = ts[t + 1];
-    if (end <= beg) continue;
-    const bool sentinel = (t == ntiles);
-    const int tile = t / planes_per_tile, plane = t % planes_per_tile;
-    const int wx0 = sentinel ? -200000000 : (tile % tiles_x) * kBinTile - kBinMargin;
-    const int wy0 = sentinel ? -200000000 : (tile / tiles_x) * kBinTile - kBinMargin;
-    for (int b = beg; b < end; b += M) chunks.push_back(Chunk{wx0, wy0, b, (b + M < end) ? b + M : end, plane, 0});
-  }
-  std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return (a.end - a.beg) > (b.end - b.beg); });
-  rc = ensure(c, c->d_chunks, c->chunks_cap, chunks.size());
-  if (rc) return rc;
-  if (!chunks.empty())
-    HIP_TRY(c, hipMemcpyAsync(c->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // chunks vector goes out of scope
-  c->nchunks = (int)chunks.size();
   c->bin_valid = true;
   c->rebin_count++;
   c->last_fallback_frac = 0;
@@ -548,6 +544,7 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.sbatch = c->d_sbatch;
   b.chunks = c->d_chunks;
   b.nchunks = c->nchunks;
+  b.nchunks_dev = c->d_nchunks;
   b.fallback = c->d_fallback;
   return b;
 }
@@ -892,6 +889,11 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false) {
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->nchunks_exact && c->bin_valid && c->d_nchunks) {  // once per binning: launch exactly the chunks that exist
+    int nch = 0;
+    if (hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
+    c->nchunks_exact = true;
+  }
   if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[kFallbackSlot] / (double)c->n_packed;
   c->fallback_pending = false;
   // timing spans are resolved lazily (cmx_timing_get) so that timed evaluations wait exactly like untimed ones
@@ -988,6 +990,7 @@ void cmx_destroy(cmx_ctx *c) {
   for (auto e : c->event_pool) hipEventDestroy(e);
   hipFree(c->d_lut);
   hipFree(c->d_lut2);
+  hipFree(c->d_nchunks);
   hipFree(c->d_batch_err);
   hipFree(c->d_xy);
   if (c->h_xy) hipHostFree(c->h_xy);
@@ -1067,7 +1070,12 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
   if (!c || !stats) return CMX_ERR_INVALID_ARG;
   stats[0] = (double)c->rebin_count;
   stats[1] = c->last_fallback_frac;
-  stats[2] = (double)c->nchunks;
+  {  // true length of the chunk table (device-resident until the first evaluation after a binning has been collected)
+    int nch = c->nchunks;
+    if (!c->nchunks_exact && c->d_nchunks && c->bin_valid && bind(c) == CMX_OK && hipStreamSynchronize(c->stream) == hipSuccess)
+      (void)hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost);
+    stats[2] = (double)nch;
+  }
   stats[3] = (double)c->n_packed;
   stats[4] = (double)c->reuse_hits;
   return CMX_OK;
