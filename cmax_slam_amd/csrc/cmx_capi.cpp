@@ -987,9 +987,9 @@ class HostPool {
 };
 
 template <typename F>
-void parallel_ranges(int64_t n, F fn) {
+void parallel_ranges(int64_t n, F fn, int64_t serial_below = 262144) {
   int T = HostPool::get().workers() + 1;
-  if (n < 262144) T = 1;
+  if (n < serial_below) T = 1;
   if (T <= 1) { fn((int64_t)0, n); return; }
   const int64_t per = (n + T - 1) / T;
   const int parts = (int)((n + per - 1) / per);
@@ -999,9 +999,16 @@ void parallel_ranges(int64_t n, F fn) {
   });
 }
 
-int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
+// argument checks only; the coordinate range is validated inside the packing pass (one sweep over the events instead
+// of two) and, if that pass saw an offender, located by check_events below
+int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
   if (n < 0 || n > kMaxEvents) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld (limit %lld)", (long long)n, (long long)kMaxEvents);
   if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
+  return CMX_OK;
+}
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
+  int rc0 = check_event_args(c, n, x, y, t);
+  if (rc0) return rc0;
   const int W = c->W, H = c->H;
   std::atomic<int64_t> bad(-1);
   parallel_ranges(n, [&](int64_t a, int64_t b) {
@@ -1234,7 +1241,7 @@ static int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   // computeContrast's switch (local_focus_funcs.cpp:98-109): 1 = mean square, 2 = gradient magnitude, default = variance
   if (contrast_measure != CMX_MEAN_SQUARE && contrast_measure != CMX_GRADIENT_MAGNITUDE) contrast_measure = CMX_VARIANCE;
   if (!d_raw) {
-    rc = check_events(c, n, x, y, t_ns);
+    rc = check_event_args(c, n, x, y, t_ns);
     if (rc) return rc;
   } else if (n < 0 || n > kMaxEvents) {
     return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
@@ -1253,18 +1260,30 @@ static int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     rc = ensure_pinned_xy(c, (size_t)n);
     if (rc) return rc;
     xy = c->h_xy;
+    std::atomic<unsigned> out_of_range(0);
+    const unsigned W = (unsigned)c->W, H = (unsigned)c->H;
     parallel_ranges(n, [&](int64_t a, int64_t b) {
-      for (int64_t i = a; i < b; i++) xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+      unsigned acc = 0;
+      for (int64_t i = a; i < b; i++) {
+        acc |= (unsigned)(x[i] >= W) | (unsigned)(y[i] >= H);
+        xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+      }
+      if (acc) out_of_range = 1;
     });
+    if (out_of_range.load()) return check_events(c, n, x, y, t_ns);  // locate and report the offender
   }
   std::vector<double> dts((size_t)nb);
   const double tref = time_to_sec(t_ref_ns);
-  for (int b = 0; b < nb; b++) {
-    const int64_t beg = (int64_t)b * event_batch_size;
-    const int64_t end = (beg + event_batch_size < n) ? beg + event_batch_size : n;
-    if (t_ns[end - 1] < t_ns[beg]) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", b);
-    dts[b] = time_to_sec(time_batch_ns(t_ns[beg], t_ns[end - 1])) - tref;
-  }
+  std::atomic<int> bad_batch(-1);
+  parallel_ranges(nb, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t beg = b * event_batch_size;
+      const int64_t end = (beg + event_batch_size < n) ? beg + event_batch_size : n;
+      if (t_ns[end - 1] < t_ns[beg]) { bad_batch = (int)b; return; }
+      dts[(size_t)b] = time_to_sec(time_batch_ns(t_ns[beg], t_ns[end - 1])) - tref;
+    }
+  }, /*serial_below=*/4096);
+  if (bad_batch.load() >= 0) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", bad_batch.load());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   rc = ensure(c, c->d_xy, c->xy_cap, (size_t)n);
   if (rc) return rc;
@@ -1454,7 +1473,7 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
   // the back end's switch (global_focus_funcs.cpp:61-69) knows mean square only; everything else is variance
   if (contrast_measure != CMX_MEAN_SQUARE) contrast_measure = CMX_VARIANCE;
   if (!d_raw) {
-    rc = check_events(c, n, x, y, t_ns);
+    rc = check_event_args(c, n, x, y, t_ns);
     if (rc) return rc;
   } else if (n < 0 || n > kMaxEvents) {
     return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
@@ -1484,6 +1503,8 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
     xy = c->h_xy;
   }
   std::vector<long long> bt(d_raw ? 0 : (size_t)nbatches);
+  std::atomic<unsigned> out_of_range(0);  // some event outside the sensor: seen by the packing pass, located afterwards
+  const unsigned sensor_w = (unsigned)c->W, sensor_h = (unsigned)c->H;
   std::atomic<int> err_kind(0);
   std::atomic<long long> err_at(-1);
   if (!d_raw)  // (windows cut from the event store get their batch times from a kernel, below)
@@ -1498,8 +1519,12 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
       bt[(size_t)b] = tb;
       if (rate == 1) continue;  // packed below by a flat, vectorisable loop (packed index == event index)
       uint32_t *dst = xy + b * per_batch;
-      for (int64_t e = beg; e < end; e += rate)
+      unsigned acc = 0;
+      for (int64_t e = beg; e < end; e += rate) {
+        acc |= (unsigned)(x[e] >= sensor_w) | (unsigned)(y[e] >= sensor_h);
         *dst++ = (uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u);
+      }
+      if (acc) out_of_range = 1;
     }
   });
   if (rate == 1 && !d_raw)
@@ -1507,9 +1532,19 @@ static int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const ui
       const uint16_t *__restrict xs = x, *__restrict ys = y;
       const int64_t *__restrict ts = t_ns;
       uint32_t *__restrict out = xy;
-      for (int64_t e = a0; e < a1; e++)
+      unsigned acc = 0;
+      for (int64_t e = a0; e < a1; e++) {
+        acc |= (unsigned)(xs[e] >= sensor_w) | (unsigned)(ys[e] >= sensor_h);
         out[e] = (uint32_t)xs[e] | ((uint32_t)ys[e] << 16) | ((uint32_t)(ts[e] < t_next_win_beg_ns) << 31);
+      }
+      if (acc) out_of_range = 1;
     });
+  // (with sub-sampling only the sampled events were looked at: the reference reads nothing else either, but the ABI
+  // promises that every event handed over is inside the sensor)
+  if (!d_raw && (out_of_range.load() || rate != 1)) {
+    rc = check_events(c, n, x, y, t_ns);
+    if (rc) return rc;
+  }
   if (err_kind.load() == CMX_ERR_TIME_ORDER)
     return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", err_at.load());
   if (err_kind.load() == CMX_ERR_SPLINE_RANGE)
