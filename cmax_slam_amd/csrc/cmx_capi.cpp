@@ -374,9 +374,9 @@ RcclApi &rccl() {
   }();
   return api;
 }
-int comm_allreduce(cmx_ctx *c, void *buf, size_t count, ncclDataType_t dt) {
+int comm_allreduce(cmx_ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op = ncclSum) {
   if (!c->comm || count == 0) return CMX_OK;
-  const ncclResult_t r = rccl().AllReduce(buf, buf, count, dt, ncclSum, c->comm, c->stream);
+  const ncclResult_t r = rccl().AllReduce(buf, buf, count, dt, op, c->comm, c->stream);
   if (r != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(r));
   return CMX_OK;
 }
@@ -1373,10 +1373,47 @@ static bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) 
 // evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
 static int finish_begin(cmx_ctx *c, int kind, int want_grad);
 static int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
+// Large panoramas: the ranks' votes cover a few tile rows of a mostly empty map.  All-reduce (max) the tile-occupancy
+// flags (a few KB), read them back, and sum only the band of rows any rank touched -- 64 MB per evaluation become
+// ~16 MB at 4096x2048 (BASELINE config 5).  Every rank derives the band from the same reduced flags, so the collectives
+// match by construction.  Returns 1 if it handled the exchange, 0 if the caller should exchange the planes whole.
+constexpr size_t kSparseExchangeMinPlaneBytes = (size_t)8 << 20;
+static int exchange_touched_rows(cmx_ctx *c, int *handled) {
+  *handled = 0;
+  const size_t np = (size_t)c->Wp * c->Hp;
+  if (c->kind != KIND_BE || !c->accum_flagged || !c->d_tflags || np * sizeof(float) < kSparseExchangeMinPlaneBytes ||
+      c->accum_count != 2 * np)
+    return CMX_OK;
+  const int tiles_x = (c->Wp + kTileX - 1) / kTileX, tiles_y = (c->Hp + kTileY - 1) / kTileY;
+  int rc = comm_allreduce(c, c->d_tflags, (size_t)tiles_x * tiles_y, ncclUint8, ncclMax);
+  if (rc) return rc;
+  std::vector<unsigned char> flags((size_t)tiles_x * tiles_y);
+  HIP_TRY(c, hipMemcpyAsync(flags.data(), c->d_tflags, flags.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int r0 = tiles_y, r1 = -1;
+  for (int ty = 0; ty < tiles_y; ty++)
+    for (int tx = 0; tx < tiles_x; tx++)
+      if (flags[(size_t)ty * tiles_x + tx]) { r0 = ty < r0 ? ty : r0; r1 = ty > r1 ? ty : r1; break; }
+  *handled = 1;
+  if (r1 < r0) return CMX_OK;  // nobody voted anywhere
+  const size_t row0 = (size_t)r0 * kTileY, row1 = std::min((size_t)(r1 + 1) * kTileY, (size_t)c->Hp);
+  for (int plane = 0; plane < 2; plane++) {
+    rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, ncclFloat);
+    if (rc) return rc;
+  }
+  return CMX_OK;
+}
+
 static int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad) {
   int rc = CMX_OK;
   if (exchange_planes) {
-    rc = comm_allreduce(c, c->d_accum, c->accum_count, ncclFloat);  // sum of the ranks' partial planes
+    int handled = 0;
+    rc = exchange_touched_rows(c, &handled);
+    if (rc) return rc;
+    if (!handled) {
+      rc = comm_allreduce(c, c->d_accum, c->accum_count, ncclFloat);  // sum of the ranks' partial planes
+      c->accum_flagged = false;  // the planes now hold other ranks' votes this rank's occupancy flags know nothing about
+    }
     if (rc) return rc;
   }
   rc = finish_begin(c, kind, grad != nullptr);
@@ -1766,9 +1803,9 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     rc = do_binning(c, nullptr, &a);
     if (rc) return rc;
   }
-  // tile occupancy: only for the LDS splat into this context's own ping-pong buffers (planes that are all-reduced
-  // across ranks or owned by the caller would need the flags exchanged as well)
-  const bool use_flags = use_lds && c->pingpong_planes > 0 && !c->comm && !c->accum_external;
+  // tile occupancy: only for the LDS splat into this context's own ping-pong buffers (with a communicator attached the
+  // flags are all-reduced with the planes, finish_sharded; planes owned by the caller are exchanged by the caller)
+  const bool use_flags = use_lds && c->pingpong_planes > 0 && !c->accum_external;
   if (use_flags) {
     const size_t tiles = (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY);
     if (tiles > c->tflags_cap || !c->d_tflags || !c->d_tflags_alt || !c->d_igp_flags) {

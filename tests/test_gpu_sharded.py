@@ -13,7 +13,7 @@ import pytest
 
 from cmax_slam_amd import synth
 from cmax_slam_amd.dist import ShardedEvaluator, attach_torch_accum, batch_range
-from util import RTOL, rel_scalar, rel_vec
+from util import RTOL, rel_img, rel_scalar, rel_vec
 
 pytestmark = pytest.mark.gpu
 
@@ -176,3 +176,40 @@ def test_native_rccl_communicator_world1(hip, oracle):
     c, g = be.eval(d)
     c_ref, g_ref = rb.eval(d)
     assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
+
+
+def test_touched_rows_exchange_on_a_large_panorama_world1(hip):
+    """Planes of 8 MB and more are exchanged as the band of tile rows any rank voted into (flags all-reduced with max
+    first).  With one rank the collectives are identities, so every result must equal the run without a communicator --
+    across a sequence of evaluations that moves the votes, alternates cost-only and gradient calls (ping-pong buffers,
+    image reuse) and includes a non-zero global map."""
+    w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 2048, 1024, 2, 5, 1, 0.2, seed=45)
+    IG = np.zeros((w.Hp, w.Wp), np.float32)
+    IG[300:340, 900:1100] = 1.5      # map content in rows the events of this window do not reach
+    IG[500:520, 1000:1040] = 0.7
+    plain = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    shard = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    for ev in (plain, shard):
+        ev.set_fast_path()
+        ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
+                      w.batch, w.sample_rate, w.sigma, 0, IG)
+    shard.comm_attach(shard.comm_unique_id(), 0, 1)
+    rng = np.random.default_rng(7)
+    big = np.tile([0.2, 0.0, 0.0], w.P // 3)   # a pitch of 11 degrees: the votes move to other tile rows
+    for i, d in enumerate([np.zeros(w.P), big, rng.normal(0, 0.01, w.P), -big, np.zeros(w.P), np.zeros(w.P)]):
+        want = i % 2 == 0 or i == 5
+        c0, g0 = plain.eval(d, want)
+        c1, g1 = shard.eval(d, want)
+        assert rel_scalar(c1, c0) < 1e-7, (i, c0, c1)
+        if want:
+            assert rel_vec(g1, g0) < 1e-6, i
+        assert rel_img(shard.get_plane(_lib_plane("IL_OLD")), plain.get_plane(_lib_plane("IL_OLD"))) < 1e-6
+    assert rel_scalar(shard.alpha, plain.alpha) < 1e-7 and plain.alpha > 0
+    x0, r0 = plain.setupProblemAndOptimize()
+    x1, r1 = shard.setupProblemAndOptimize()
+    assert abs(r1["final_cost"] - r0["final_cost"]) < 1e-3 * abs(r0["final_cost"])
+
+
+def _lib_plane(name):
+    from cmax_slam_amd import _lib
+    return getattr(_lib, "PLANE_" + name)
