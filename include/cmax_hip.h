@@ -212,7 +212,9 @@ int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
 /* Native exchange: attach an RCCL communicator to the context (one process per GPU) and every cmx_*_eval / cmx_*_solve
  * performs the all-reduces itself, in place, on the context's stream -- partial planes after the splat, and the 2P
  * partial gradient sums after the gather pass (adjoint mode).  All ranks therefore see identical contrast / gradient
- * and take identical optimiser decisions.  Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher
+ * and take identical optimiser decisions.  Back-end planes of 8 MB and more are exchanged as the band of image rows some
+ * rank voted into (their tile-occupancy flags are all-reduced with max first); smaller planes travel whole.
+ * Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher
  * distributes it by whatever means it has (torch.distributed broadcast in bench.py, MPI, a file).  RCCL is dlopen()ed
  * at this point only; hosts that never attach a communicator do not need it installed. */
 #define CMX_COMM_ID_BYTES 128
