@@ -781,9 +781,9 @@ int gather_blocks(int n) {
   const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~130 VGPRs: 3 blocks/CU is its occupancy)
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
-// front end: one workgroup per kFeGatherPerBlock events up to the cap (tools/sweep_fe_gather.sh: 1024 -> 16.9 us,
-// 1536 -> 18.3 us, 512 -> 18.0 us per 1M events)
-constexpr int kFeGatherPerBlock = 1024, kFeGatherCap = 2048;
+// front end: one workgroup per kFeGatherPerBlock events up to the cap (tools/sweep_fe_gather.sh, with two events in
+// flight per thread: 512 -> 11.6 us, 1024 -> 11.9 us, 2048 -> 15.3 us per 1M events)
+constexpr int kFeGatherPerBlock = 512, kFeGatherCap = 4096;
 int fe_gather_blocks(int n) {
   int blocks = (n + kFeGatherPerBlock - 1) / kFeGatherPerBlock;
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
