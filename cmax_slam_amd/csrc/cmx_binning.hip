@@ -91,8 +91,11 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 2) base_sh[tid] = 0;
   __syncthreads();
-  // pass 0: full chunks; pass 1: the remainder chunk of each tile
-  for (int pass = 0; pass < 2; pass++) {
+  // pass 0: the full chunks of every tile; passes 1..5: the remainder chunks by falling size class (> M/2, > M/4, > M/8,
+  // > M/16, rest): largest first, so that no big chunk is left to start when the rest of the launch has drained
+  for (int pass = 0; pass < 6; pass++) {
+    const int lo = pass == 0 ? 0 : (pass == 5 ? 0 : (M >> pass));       // remainder must exceed lo ...
+    const int hi = pass <= 1 ? M : (M >> (pass - 1));                   // ... and not exceed hi (classes are disjoint)
     for (int t0 = 0; t0 <= ntiles; t0 += 1024) {
       const int t = t0 + tid;
       int beg = 0, len = 0, nfull = 0, rem = 0;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
         nfull = len / M;
         rem = len - nfull * M;
       }
-      const int mine = pass == 0 ? nfull : (rem > 0 ? 1 : 0);
+      const int mine = pass == 0 ? nfull : ((rem > lo && rem <= hi) ? 1 : 0);
       int incl = mine;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
