@@ -63,8 +63,8 @@ double orc_be_alpha(const float *IGp, const float *IL, int npix) {
 }
 
 /* EventWarper::warpAndAccumulateEvents  event_pano_warper.cpp:233-336 */
-static int be_warp_batch(const orc_be_cfg *c, orc_be_state *st, const uint16_t *x, const uint16_t *y,
-                         const int64_t *t_ns, int64_t beg, int64_t end, const double *knots, float *planes) {
+int orc_be_warp_batch(const orc_be_cfg *c, orc_be_state *st, const uint16_t *x, const uint16_t *y,
+                      const int64_t *t_ns, int64_t beg, int64_t end, const double *knots, float *planes) {
   const int n3 = 3 * c->order;
   const size_t np = (size_t)c->Wp * c->Hp;
   /* :239-242 */
@@ -160,7 +160,7 @@ int orc_be_iwe(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t 
   for (int64_t beg = 0; beg < n - 1; beg += c->batch) {
     const int64_t left = n - beg;
     const int64_t end = (left > c->batch) ? beg + c->batch : n;
-    int rc = be_warp_batch(c, st, x, y, t_ns, beg, end, knots, planes);
+    int rc = orc_be_warp_batch(c, st, x, y, t_ns, beg, end, knots, planes);
     if (rc) return rc;
   }
   for (size_t i = 0; i < np; i++) st->IL[i] = st->IL_old[i] + st->IL_new[i]; /* :199 cv::add */

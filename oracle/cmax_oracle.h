@@ -63,6 +63,9 @@ typedef struct {
 int orc_fe_iwe(const orc_fe_cfg *c, int64_t n, const uint16_t *x, const uint16_t *y,
                const int64_t *t_ns, int64_t t_ref_ns, const double omega[3],
                float *iwe, float *deriv, int blur);
+/* one batch of warpAndAccumulateEvents (local_image_warped_events.cpp:59-170); events [beg, end) */
+void orc_fe_warp_batch(const orc_fe_cfg *c, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                       int64_t beg, int64_t end, int64_t t_ref_ns, const double omega[3], float *iwe, float *deriv);
 /* local_contrast_fdf body without the sign flip (local_optim_contrast_gsl.cpp:20-56):
  * returns contrast, grad[3] if non-NULL. */
 int orc_fe_eval(const orc_fe_cfg *c, int64_t n, const uint16_t *x, const uint16_t *y,
@@ -111,6 +114,9 @@ typedef struct {
  * iwe: Hp*Wp; planes: P=3*(K-num_fixed) planes of Hp*Wp contiguous, or NULL. */
 int orc_be_iwe(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t *x, const uint16_t *y,
                const int64_t *t_ns, const double *knots_xyzw, float *iwe, float *planes);
+/* one batch of EventWarper::warpAndAccumulateEvents (event_pano_warper.cpp:233-336); votes into st->IL_old / IL_new */
+int orc_be_warp_batch(const orc_be_cfg *c, orc_be_state *st, const uint16_t *x, const uint16_t *y,
+                      const int64_t *t_ns, int64_t beg, int64_t end, const double *knots_xyzw, float *planes);
 /* global_contrast_fdf body without sign flip (global_optim_contrast_gsl_analytical.cpp:17-68):
  * knots0 = temp-trajectory knots before the update; drotv: 3*(K-num_fixed). */
 int orc_be_eval(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t *x, const uint16_t *y,
@@ -141,6 +147,15 @@ int orc_fullpiv_qr_solve(int rows, int cols, const double *A_rowmajor, const dou
 /* CMaxSLAM::precomputeBearingVectors (cmax_slam.cpp:106-120) over image_geometry + cv::undistortPoints */
 void orc_bearing_lut(int W, int H, const double K[9], const double D[5], const double R[9], const double P[12],
                      double *lut);
+
+/* ---- all-cores OpenMP variant (allcores.c, liboracle_mt.so only) -- NOT the reference, which is single-threaded:
+ * contiguous batch ranges per thread, thread-private images summed in thread order.  nthreads <= 0: all cores. */
+int orc_mt_max_threads(void);
+int orc_fe_eval_mt(const orc_fe_cfg *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                   int64_t t_ref_ns, const double omega[3], int nthreads, double *contrast, double *grad);
+int orc_be_eval_mt(const orc_be_cfg *c, orc_be_state *st, int64_t n, const uint16_t *x, const uint16_t *y,
+                   const int64_t *t_ns, const double *knots0_xyzw, const double *drotv, int nthreads,
+                   double *contrast, double *grad);
 
 #ifdef __cplusplus
 }

@@ -24,9 +24,9 @@ static void matx_mul_d(const double *a, const double *b, double *out, int m, int
 }
 
 /* warpAndAccumulateEvents  local_image_warped_events.cpp:59-170 */
-static void fe_warp_batch(const orc_fe_cfg *c, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
-                          int64_t beg, int64_t end, int64_t t_ref_ns, const double omega[3], float *iwe,
-                          float *deriv) {
+void orc_fe_warp_batch(const orc_fe_cfg *c, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                       int64_t beg, int64_t end, int64_t t_ref_ns, const double omega[3], float *iwe,
+                       float *deriv) {
   /* :68-76  shared pose for the batch */
   const int64_t time_batch = orc_time_batch_ns(t_ns[beg], t_ns[end - 1]);
   const double dt = orc_time_to_sec(time_batch) - orc_time_to_sec(t_ref_ns);
@@ -98,7 +98,7 @@ int orc_fe_iwe(const orc_fe_cfg *c, int64_t n, const uint16_t *x, const uint16_t
   for (int64_t beg = 0; beg < n; beg += c->batch) { /* :22-28 */
     int64_t end = beg + c->batch;
     if (end > n) end = n;
-    fe_warp_batch(c, x, y, t_ns, beg, end, t_ref_ns, omega, iwe, deriv);
+    orc_fe_warp_batch(c, x, y, t_ns, beg, end, t_ref_ns, omega, iwe, deriv);
   }
   if (blur && c->sigma > 0) { /* :32-38 */
     orc_gaussian_blur(iwe, c->W, c->H, 1, c->sigma);

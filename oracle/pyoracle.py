@@ -41,9 +41,10 @@ class BeState(C.Structure):
 
 def build(force=False):
     """Compile liboracle.so (and _ref/libbasalt_ref.so when the reference tree is present)."""
-    so = os.path.join(_HERE, "liboracle.so")
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    # make is incremental: a stale library after a source edit is rebuilt, an up-to-date one costs milliseconds
+    subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so", "liboracle_mt.so"])
     if os.path.isdir("/root/reference/thirdparty/basalt-headers"):
         ref = os.path.join(_HERE, "_ref", "libbasalt_ref.so")
         if force or not os.path.exists(ref):
@@ -98,6 +99,25 @@ def lib():
         L.orc_bearing_lut.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
         _LIB = L
     return _LIB
+
+
+_MT = None
+
+
+def mt_lib():
+    """The all-cores OpenMP variant (liboracle_mt.so): NOT the reference, which is single-threaded."""
+    global _MT
+    if _MT is None:
+        so = os.path.join(_HERE, "liboracle_mt.so")
+        if not os.path.exists(so):
+            build()
+        M = C.CDLL(so)
+        M.orc_mt_max_threads.restype = C.c_int
+        M.orc_fe_eval_mt.argtypes = [C.POINTER(FeCfg), C.c_int64, c_u16p, c_u16p, c_i64p, C.c_int64, c_dp, C.c_int, c_dp, c_dp]
+        M.orc_be_eval_mt.argtypes = [C.POINTER(BeCfg), C.POINTER(BeState), C.c_int64, c_u16p, c_u16p, c_i64p, c_dp, c_dp,
+                                     C.c_int, c_dp, c_dp]
+        _MT = M
+    return _MT
 
 
 def ref_lib():
@@ -201,6 +221,17 @@ class Frontend:
         rc = lib().orc_fe_eval(C.byref(self.cfg), *self._ev(), _dp(om), C.byref(c), _dp(g) if want_grad else None)
         if rc:
             raise ValueError("oracle front-end: invalid event coordinates")
+        return c.value, (g if want_grad else None)
+
+    def eval_allcores(self, omega, want_grad=True, nthreads=0):
+        """The same evaluation on `nthreads` host threads (0 = all): thread-private images, NOT the reference."""
+        om = _c(omega, np.float64)
+        c = C.c_double()
+        g = np.zeros(3)
+        rc = mt_lib().orc_fe_eval_mt(C.byref(self.cfg), *self._ev(), _dp(om), int(nthreads), C.byref(c),
+                                     _dp(g) if want_grad else None)
+        if rc:
+            raise ValueError("oracle front-end (all cores) failed rc=%d" % rc)
         return c.value, (g if want_grad else None)
 
 
@@ -377,6 +408,19 @@ class Backend:
                                C.byref(c), _dp(g) if want_grad else None, None)
         if rc:
             raise ValueError("oracle back-end failed rc=%d" % rc)
+        return c.value, (g[:P] if want_grad else None)
+
+    def eval_allcores(self, drotv, want_grad=True, nthreads=0):
+        """The same evaluation on `nthreads` host threads (0 = all): thread-private planes, NOT the reference."""
+        d = _c(drotv, np.float64).reshape(-1)
+        P = 3 * (self.K - self.num_fixed)
+        assert d.size == P
+        c = C.c_double()
+        g = np.zeros(max(P, 1))
+        rc = mt_lib().orc_be_eval_mt(C.byref(self.cfg), C.byref(self.state), *self._ev(), _dp(self.knots), _dp(d),
+                                     int(nthreads), C.byref(c), _dp(g) if want_grad else None)
+        if rc:
+            raise ValueError("oracle back-end (all cores) failed rc=%d" % rc)
         return c.value, (g[:P] if want_grad else None)
 
 

@@ -218,3 +218,31 @@ def test_map_upkeep_restatement(oracle, win):
     be.mark_visited(q, 0)
     be.mark_visited(q, 0)
     assert be.update_times.max() == 255  # cv::add on CV_8U saturates
+
+
+def test_allcores_variant_matches_the_single_thread_oracle(oracle, pkt):
+    """liboracle_mt.so (bench.py's labelled all-cores figure) is the same algorithm: with one thread it is the
+    sequential vote order exactly; with several it differs only through the fp32 summation order of the votes."""
+    for measure in (0, 1):
+        fe = _fe(oracle, pkt, measure=measure)
+        om = (0.4, -0.3, 0.2)
+        c, g = fe.eval(om)
+        c1, g1 = fe.eval_allcores(om, True, 1)
+        assert abs(c1 - c) <= 1e-12 * abs(c) and np.abs(g1 - g).max() <= 1e-12 * np.abs(g).max()
+        for T in (2, 3, 7):
+            cT, gT = fe.eval_allcores(om, True, T)
+            assert abs(cT - c) <= 1e-6 * abs(c)
+            assert np.abs(gT - g).max() <= 1e-5 * np.abs(g).max()
+        cf, _ = fe.eval_allcores(om, False, 4)
+        assert abs(cf - c) <= 1e-6 * abs(c)
+    w = synth.backend_window(30_001, 64, 48, 80.0, 80.0, 31.5, 23.5, 256, 128, order=4, K=7, num_fixed=3, T=0.2, seed=5)
+    for n in (len(w.x), len(w.x) - 100):  # with and without the skipped trailing single-event batch
+        be = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, w.batch, w.sample_rate, w.sigma, 0)
+        be.set_window(w.x[:n], w.y[:n], w.t_ns[:n], w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+        d = 0.01 * np.sin(np.arange(w.P))
+        c, g = be.eval(d)
+        c1, g1 = be.eval_allcores(d, True, 1)
+        assert abs(c1 - c) <= 1e-12 * abs(c) and np.abs(g1 - g).max() <= 1e-12 * np.abs(g).max()
+        cT, gT = be.eval_allcores(d, True, 5)
+        assert abs(cT - c) <= 1e-6 * abs(c)
+        assert np.abs(gT - g).max() <= 1e-5 * np.abs(g).max()
