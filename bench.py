@@ -53,6 +53,7 @@ def main():
                          "context's stream); torch = torch.distributed.all_reduce on evaluator-owned torch tensors")
     ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-parity", action="store_true", help="also at N=1: re-evaluate on a fresh evaluator and report the difference (always on for N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -223,6 +224,18 @@ def main():
                          "alg_bytes_per_event": bpe, "events_per_launch": int(ev_per_launch), "avg_launch_ms": avg_ms},
             "contrast": c,
         }
+        if world > 1 and "comm" in kernel_ms:
+            # RCCL collectives of one evaluation as seen by rank 0 on its stream (calibration steps, every span timed):
+            # the exchange itself plus the wait for the slowest rank
+            n_comm = tim_all["comm"][1] / max(tim_all[dom][1], 1)
+            out["comm"] = {"ms_per_step": kernel_ms["comm"] * n_comm, "collectives_per_step": n_comm,
+                           "share_of_step": kernel_ms["comm"] * n_comm / ms_per_step}
+        if world > 1 or args.check_parity:
+            # parity of the sharded evaluation with the whole problem on ONE GPU (rank 0, untimed, after the timed region)
+            try:
+                out["parity_vs_1gpu"] = parity_vs_single_gpu(args, evaluator, _lib, workload_obj, x0, adjoint, local_rank, c, g)
+            except Exception as e:
+                out["parity_vs_1gpu"] = {"error": str(e)}
         if world == 1 and args.solves > 0:
             out["cmax"] = cmax_solves(args, ev, workload_obj, _lib)
         if world == 1 and not args.no_cpu_baseline:
@@ -230,6 +243,27 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def parity_vs_single_gpu(args, evaluator, _lib, obj, x0, adjoint, device, c_sharded, g_sharded):
+    """The same N x per-GPU events evaluated by one evaluator without a communicator on rank 0's GPU; relative
+    differences of contrast and gradient against what the sharded evaluation returned (fp32 vote order only)."""
+    if args.workload == "frontend":
+        one = evaluator.FrontendEvaluator(obj.W, obj.H, obj.lut, device=device)
+        one.set_packet(obj.x, obj.y, obj.t_ns, obj.t_ref_ns, obj.fx, obj.fy, obj.cx, obj.cy, obj.batch, obj.sigma, _lib.VARIANCE)
+    else:
+        one = evaluator.BackendEvaluator(obj.W, obj.H, obj.lut, obj.Wp, obj.Hp, device=device)
+        one.set_window(obj.x, obj.y, obj.t_ns, obj.order, obj.knots_init, obj.start_ns, obj.dt_ns, obj.num_fixed,
+                       obj.t_next_win_beg_ns, obj.batch, obj.sample_rate, obj.sigma, _lib.VARIANCE)
+    if adjoint:
+        one.set_fast_path()
+    else:
+        one.set_reference_path()
+    c1, g1 = one.eval(x0, True)
+    one.close()
+    g1, gs = np.asarray(g1), np.asarray(g_sharded)
+    return {"contrast_rel": abs(c_sharded - c1) / abs(c1), "grad_rel_inf": float(np.abs(gs - g1).max() / np.abs(g1).max()),
+            "tolerance": 1e-5}
 
 
 def cmax_solves(args, ev, obj, _lib):
@@ -249,6 +283,16 @@ def cmax_solves(args, ev, obj, _lib):
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
     return {"iters_per_s": iters / el, "evals_per_s": evals / el, "solves": args.solves, "iters_per_solve": iters / args.solves,
             "ms_per_solve": el / args.solves * 1e3, "final_cost": rep["final_cost"], "solution": [float(v) for v in x[:6]]}
+
+
+def host_cpu():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return "%s x%d" % (line.split(":", 1)[1].strip(), os.cpu_count() or 1)
+    except OSError:
+        pass
+    return "unknown x%d" % (os.cpu_count() or 1)
 
 
 def cpu_baseline(args, obj, x0):
@@ -273,7 +317,7 @@ def cpu_baseline(args, obj, x0):
     out = {"value": len(obj.x) * n / el, "unit": "events/s", "cores": 1, "kind": "port",
            "sample": "%d full fdf evaluations of the same %d-event workload (%.1f s), single thread like the reference"
                      % (n, len(obj.x), el),
-           "ms_per_step": el / n * 1e3}
+           "ms_per_step": el / n * 1e3, "host": host_cpu()}
     # beside it, labelled: the same restatement on every host core (thread-private images summed in thread order).
     # NOT the reference -- cmax_slam runs each path on one thread -- and not `cpu_baseline.value`.
     try:

@@ -376,6 +376,7 @@ RcclApi &rccl() {
 }
 int comm_allreduce(cmx_ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op = ncclSum) {
   if (!c->comm || count == 0) return CMX_OK;
+  Span sp(c, CMX_T_COMM);  // on the stream: the collective itself plus the wait for the slowest rank
   const ncclResult_t r = rccl().AllReduce(buf, buf, count, dt, op, c->comm, c->stream);
   if (r != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(r));
   return CMX_OK;

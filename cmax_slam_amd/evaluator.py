@@ -136,7 +136,7 @@ class _Evaluator:
         every: sample every n-th evaluation only (the per-event kernels are timed through events attached to the
         kernel itself, which costs ~1.5 us per timed launch)."""
         if on is True:
-            mask = 0x1F
+            mask = (1 << _lib.T_COUNT) - 1
         elif not on:
             mask = 0
         else:
