@@ -1,0 +1,367 @@
+// cmx_context.cpp -- context life cycle, options, timing and error text of the C ABI (include/cmax_hip.h), plus the
+// host-side helpers every entry point shares.  All compute is in cmx_kernels.hip / cmx_binning.hip.
+#include "cmx_context.hpp"
+
+int fail(cmx_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+int bind_device(cmx_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return CMX_OK;
+}
+
+// ---- ros::Time arithmetic (roscpp noetic semantics), needed to reproduce the per-batch pose time:
+//   time_batch = time_first + (time_last - time_first) * 0.5         [Duration*double -> fromSec: floor + round]
+//   reference: local_image_warped_events.cpp:68-75, event_pano_warper.cpp:239-242
+long long time_batch_ns(long long t_first, long long t_last) {
+  const long long d = t_last - t_first;
+  long long ds = d / 1000000000LL, dn = d % 1000000000LL;
+  if (dn < 0) { dn += 1000000000LL; ds -= 1; }
+  const double half = ((double)ds + 1e-9 * (double)dn) * 0.5;
+  const long long hs = (long long)floor(half);
+  const long long hn = (long long)round((half - (double)hs) * 1e9);
+  return t_first + hs * 1000000000LL + hn;
+}
+double time_to_sec(long long t_ns) {  // ros::Time::toSec
+  return (double)(t_ns / 1000000000LL) + 1e-9 * (double)(t_ns % 1000000000LL);
+}
+
+// c1d[q] = (G^T 1)_q for one axis of length L: taps that stay inside + the taps the forward pass reflected back
+// (see adjoint_kernel / image_adjoint_kernel).  1 in the interior; only the outer r pixels differ.
+int upload_gt1(cmx_ctx *c) {
+  const int r = c->radius;
+  for (int axis = 0; axis < 2; axis++) {
+    const int L = axis == 0 ? c->imgW : c->imgH;
+    if (L <= 0) continue;
+    std::vector<float> v((size_t)L);
+    for (int q = 0; q < L; q++) {
+      double s = 0;
+      for (int j = -r; j <= r; j++)
+        if (q - j >= 0 && q - j < L) s += (double)c->taps[r + j];
+      if (L > 2 * r + 1) {
+        if (1 <= q && q <= r)
+          for (int m = 0; m <= r - q; m++) s += (double)c->taps[r + q + m];
+        if (L - 1 - r <= q && q <= L - 2) {
+          const int d = L - 1 - q;
+          for (int m = 0; m <= r - d; m++) s += (double)c->taps[r + d + m];
+        }
+      }
+      v[(size_t)q] = (float)s;
+    }
+    float *&dst = axis == 0 ? c->d_cx : c->d_cy;
+    size_t &cap = axis == 0 ? c->cx_cap : c->cy_cap;
+    int rc = ensure(c, dst, cap, (size_t)L);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return CMX_OK;
+}
+
+// cv::GaussianBlur(Size(0,0), sigma) on CV_32F: ksize = cvRound(sigma*8+1)|1; fp64 kernel normalised, cast to fp32
+int setup_blur(cmx_ctx *c, double sigma) {
+  c->sigma = sigma;
+  if (!(sigma > 0)) {
+    c->radius = 0;
+    c->taps[0] = 1.f;
+    return upload_gt1(c);
+  }
+  const int n = ((int)lrint(sigma * 4 * 2 + 1)) | 1;
+  const int r = n / 2;
+  if (r > kMaxRadius) return fail(c, CMX_ERR_INVALID_ARG, "blur_sigma %.3f needs radius %d > %d", sigma, r, kMaxRadius);
+  double t[2 * kMaxRadius + 1], sum = 0;
+  const double scale2X = -0.5 / (sigma * sigma);
+  for (int i = 0; i < n; i++) {
+    const double x = i - (n - 1) * 0.5;
+    t[i] = exp(scale2X * x * x);
+    sum += t[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; i++) c->taps[i] = (float)(t[i] * sum);
+  c->radius = r;
+  return upload_gt1(c);
+}
+
+// ---- timing helpers
+hipEvent_t get_event(cmx_ctx *c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+void collect_spans(cmx_ctx *c) {  // call after the stream has been synchronised
+  for (auto &s : c->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      c->t_ms[s.cls] += ms;
+      c->t_n[s.cls] += 1;
+    }
+    c->event_pool.push_back(s.a);
+    c->event_pool.push_back(s.b);
+  }
+  c->spans.clear();
+}
+
+int create_common(cmx_ctx **out, int kind, int device, int W, int H, const double *lut) {
+  if (!out) return CMX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || !lut) return CMX_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CMX_ERR_HIP;  // no CPU fallback
+  if (device < 0 || device >= ndev) return CMX_ERR_INVALID_ARG;
+  cmx_ctx *c = new cmx_ctx();
+  c->kind = kind;
+  c->device = device;
+  c->W = W;
+  c->H = H;
+  *out = c;  // returned even on failure below so the caller can read cmx_last_error and destroy it
+  HIP_TRY(c, hipSetDevice(device));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  const size_t nl = (size_t)W * H * 3;
+  HIP_TRY(c, hipMalloc((void **)&c->d_lut, nl * sizeof(double)));
+  HIP_TRY(c, hipMemcpy(c->d_lut, lut, nl * sizeof(double), hipMemcpyHostToDevice));
+  {  // image_geometry's rays are (x, y, 1): then the hot kernels read 16-byte (x, y) entries with one load
+    const size_t npx = nl / 3;
+    bool unit_z = true;
+    for (size_t i = 0; i < npx && unit_z; i++) unit_z = lut[3 * i + 2] == 1.0;
+    if (unit_z && npx > 0) {
+      std::vector<double> xy(2 * npx);
+      for (size_t i = 0; i < npx; i++) { xy[2 * i] = lut[3 * i]; xy[2 * i + 1] = lut[3 * i + 1]; }
+      HIP_TRY(c, hipMalloc((void **)&c->d_lut2, 2 * npx * sizeof(double)));
+      HIP_TRY(c, hipMemcpy(c->d_lut2, xy.data(), 2 * npx * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  c->result_cap = 4096;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
+  memset(c->h_result, 0, c->result_cap * sizeof(double));
+  return CMX_OK;
+}
+
+int ensure_accum(cmx_ctx *c, size_t need);
+
+int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
+  if (n < 0 || n > kMaxEvents) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld (limit %lld)", (long long)n, (long long)kMaxEvents);
+  if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
+  return CMX_OK;
+}
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
+  int rc0 = check_event_args(c, n, x, y, t);
+  if (rc0) return rc0;
+  const int W = c->W, H = c->H;
+  std::atomic<int64_t> bad(-1);
+  parallel_ranges(n, [&](int64_t a, int64_t b) {
+    unsigned acc = 0;
+    for (int64_t i = a; i < b; i++) acc |= (unsigned)(x[i] >= W) | (unsigned)(y[i] >= H);
+    if (acc)
+      for (int64_t i = a; i < b; i++)
+        if (x[i] >= W || y[i] >= H) {
+          int64_t cur = bad.load();
+          while ((cur < 0 || i < cur) && !bad.compare_exchange_weak(cur, i)) {}
+          break;
+        }
+  });
+  const int64_t i = bad.load();
+  if (i >= 0)
+    return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, x[i], y[i], W, H);
+  return CMX_OK;
+}
+
+int ensure_pinned_xy(cmx_ctx *c, size_t n) {
+  if (n <= c->h_xy_cap && c->h_xy) return CMX_OK;
+  if (c->h_xy) HIP_TRY(c, hipHostFree(c->h_xy));
+  c->h_xy = nullptr;
+  c->h_xy_cap = 0;
+  const size_t cap = n + n / 4 + 1024;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_xy, cap * sizeof(uint32_t), hipHostMallocDefault));
+  c->h_xy_cap = cap;
+  return CMX_OK;
+}
+
+// =============================================================================================== generic
+const char *cmx_version(void) { return "cmax-hip 0.1 (gfx950)"; }
+
+int cmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *cmx_last_error(const cmx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char *cmx_status_string(int s) {
+  switch (s) {
+    case CMX_OK: return "ok";
+    case CMX_ERR_INVALID_ARG: return "invalid argument";
+    case CMX_ERR_EVENT_RANGE: return "event coordinates outside the sensor";
+    case CMX_ERR_HIP: return "HIP runtime error (no GPU / launch failure)";
+    case CMX_ERR_SPLINE_RANGE: return "batch time outside the spline's knot support";
+    case CMX_ERR_STATE: return "call sequence error";
+    case CMX_ERR_TIME_ORDER: return "event batch spans a negative time interval";
+    default: return "unknown status";
+  }
+}
+
+void cmx_destroy(cmx_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  hipFree(c->d_lut);
+  hipFree(c->d_lut2);
+  hipFree(c->d_nchunks);
+  hipFree(c->d_batch_err);
+  hipFree(c->d_xy);
+  if (c->h_xy) hipHostFree(c->h_xy);
+  hipFree(c->d_batch_dt);
+  hipFree(c->d_batch_t);
+  hipFree(c->d_poses);
+  hipFree(c->d_poseR);
+  if (c->h_spline) hipHostFree(c->h_spline);
+  hipFree(c->d_IG);
+  hipFree(c->d_visits);
+  hipFree(c->d_mask);
+  hipFree(c->d_IGp);
+  hipFree(c->d_alpha);
+  if (!c->accum_external) hipFree(c->d_accum);
+  hipFree(c->d_accum_alt);
+  hipFree(c->d_scratch);
+  hipFree(c->d_partials);
+  hipFree(c->d_sums);
+  hipFree(c->d_keys); hipFree(c->d_keys_s); hipFree(c->d_idx); hipFree(c->d_idx_s); hipFree(c->d_sxy); hipFree(c->d_sbatch);
+  hipFree(c->d_sort_temp);
+  hipFree(c->d_tile_start);
+  hipFree(c->d_chunks);
+  hipFree(c->d_fallback);
+  hipFree(c->d_itilde);
+  hipFree(c->d_cx);
+  hipFree(c->d_cy);
+  hipFree(c->d_gpartials);
+  hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
+  hipFree(c->d_tile_list); hipFree(c->d_tile_count);
+  hipFree(c->d_vparts);
+  if (!c->gsum_external) hipFree(c->d_gsum);
+  if (c->h_result) hipHostFree(c->h_result);
+  comm_release(c);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int cmx_set_option(cmx_ctx *c, int key, int value) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  switch (key) {
+    case CMX_OPT_GRAD_MODE:
+      if (value != CMX_GRAD_PLANES && value != CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "bad grad mode %d", value);
+      c->grad_mode = value;
+      return CMX_OK;
+    case CMX_OPT_SPLAT_MODE:
+      if (value != 0 && value != 1) return fail(c, CMX_ERR_INVALID_ARG, "bad splat mode %d", value);
+      c->splat_mode = value;
+      c->bin_valid = false;
+      return CMX_OK;
+    case CMX_OPT_REUSE_IMAGE:
+      c->reuse_image = value != 0;
+      return CMX_OK;
+    case CMX_OPT_SPIN_WAIT:
+      c->ticket_wait = value != 0;
+      return CMX_OK;
+    default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
+  }
+}
+
+int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) { HIP_TRY(c, hipStreamDestroy(c->stream)); c->stream = nullptr; c->own_stream = false; }
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return CMX_OK;
+}
+
+int cmx_get_stats(cmx_ctx *c, double stats[8]) {
+  if (!c || !stats) return CMX_ERR_INVALID_ARG;
+  stats[0] = (double)c->rebin_count;
+  stats[1] = c->last_fallback_frac;
+  {  // true length of the chunk table (device-resident until the first evaluation after a binning has been collected)
+    int nch = c->nchunks;
+    if (!c->nchunks_exact && c->d_nchunks && c->bin_valid && bind_device(c) == CMX_OK && hipStreamSynchronize(c->stream) == hipSuccess)
+      (void)hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost);
+    stats[2] = (double)nch;
+  }
+  stats[3] = (double)c->n_packed;
+  stats[4] = (double)c->reuse_hits;
+  return CMX_OK;
+}
+
+int cmx_timing_enable(cmx_ctx *c, int on) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  c->timing = (on & 0xff) != 0;
+  c->timing_mask = on & 0xff;
+  c->timing_every = (on >> 8) > 0 ? (on >> 8) : 1;  // bits 8..: sample every n-th evaluation only
+  c->timing_tick = 0;
+  return CMX_OK;
+}
+int cmx_timing_get(cmx_ctx *c, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  if (!c->spans.empty()) {
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
+  }
+  for (int i = 0; i < CMX_T_COUNT; i++) {
+    if (ms) ms[i] = c->t_ms[i];
+    if (launches) launches[i] = c->t_n[i];
+    c->t_ms[i] = 0;
+    c->t_n[i] = 0;
+  }
+  return CMX_OK;
+}
+
+size_t cmx_accum_capacity(const cmx_ctx *c) {
+  if (!c) return 0;
+  if (c->kind == KIND_FE) return (size_t)4 * c->W * c->H;
+  const int P = 3 * (c->K - c->num_fixed);
+  return (size_t)(2 + (P > 0 ? P : 0)) * c->Wp * c->Hp;
+}
+int cmx_set_accum_buffer(cmx_ctx *c, void *device_ptr, size_t n_floats) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->accum_external && c->d_accum) HIP_TRY(c, hipFree(c->d_accum));
+  c->d_accum = (float *)device_ptr;
+  c->accum_cap = device_ptr ? n_floats : 0;
+  c->accum_external = device_ptr != nullptr;
+  c->accumulated = false;
+  return CMX_OK;
+}
+void *cmx_accum_ptr(const cmx_ctx *c) { return c ? c->d_accum : nullptr; }
+size_t cmx_accum_count(const cmx_ctx *c) { return c ? c->accum_count : 0; }
+
+int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots) {
+  const double t = t_beg + idx_traj_beg * dt_knots;
+  return (int64_t)(1e9 * t);
+}
+

@@ -1,0 +1,279 @@
+// cmx_context.hpp -- the evaluator context behind include/cmax_hip.h's opaque cmx_ctx / cmx_events, and the helpers
+// the translation units of the C ABI share:
+//   cmx_context.cpp   context life cycle, options, timing, error text, event validation
+//   cmx_pipeline.cpp  one evaluation on the stream: accumulate buffers, tile sort, image passes, gather, finalize, ticket
+//   cmx_frontend.cpp  cmx_frontend_*      cmx_backend.cpp  cmx_backend_*      cmx_events.cpp  cmx_events_*
+//   cmx_comm.cpp      RCCL communicator inside the evaluator (sharded evaluations)
+// Internal to libcmaxhip.so; gfx950 only.  There is NO CPU fallback: every entry point fails loudly without HIP.
+#pragma once
+#include "../../include/cmax_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "cmx_hostpool.hpp"
+#include "cmx_internal.hpp"
+
+using namespace cmx;  // internal header of one library: the parameter blocks of cmx_internal.hpp are used unqualified
+
+enum { KIND_FE = 1, KIND_BE = 2 };
+constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
+
+struct TimedSpan { int cls; hipEvent_t a, b; };
+typedef struct ncclComm *ncclComm_t;  // as <rccl/rccl.h> declares it; only cmx_comm.cpp includes that header
+
+struct cmx_ctx {
+  int kind = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // sensor + LUT
+  int W = 0, H = 0;
+  double *d_lut = nullptr;
+  long long *d_batch_err = nullptr;  // error kind / position reported by the device-side batch-time pass
+  double *d_lut2 = nullptr;  // (x, y) pairs, 16-byte entries: present when the caller's table has z == 1 everywhere
+
+  // packed events
+  uint32_t *d_xy = nullptr;
+  size_t xy_cap = 0;
+  uint32_t *h_xy = nullptr;  // pinned staging for the packed events (host packing runs on several threads)
+  size_t h_xy_cap = 0;
+  int n_packed = 0, per_batch = 1, nb = 0;
+  bool have_data = false;
+
+  // config shared by both ends
+  int batch = 100, sample_rate = 1, measure = CMX_VARIANCE;
+  double sigma = 0;
+  int radius = 0;
+  float taps[2 * kMaxRadius + 1] = {1.f};
+  int grad_mode = CMX_GRAD_ADJOINT, splat_mode = 1;  // production configuration by default; cmx_set_option selects the reference-shaped path
+
+  // front end
+  double fx = 0, fy = 0, cx = 0, cy = 0;
+  double *d_batch_dt = nullptr;
+  size_t batch_cap = 0;
+
+  // back end
+  int Wp = 0, Hp = 0, order = 0, K = 0, num_fixed = 0;
+  long long *d_batch_t = nullptr;
+  PoseEntry *d_poses = nullptr;
+  PoseR *d_poseR = nullptr;
+  size_t batch_t_cap = 0, poses_cap = 0, poseR_cap = 0;
+  SplineArgs *h_spline = nullptr;  // temp-trajectory description, passed to the pose-table kernel by value
+  std::vector<Quat> knots0;
+  float *d_IG = nullptr, *d_IGp = nullptr;
+  unsigned char *d_visits = nullptr, *d_mask = nullptr;  // IG_update_times_map_ and the per-pose scratch mask
+  bool ig_nonzero = false, first_iter = true;
+  double *d_alpha = nullptr;
+
+  // image planes
+  int imgW = 0, imgH = 0;  // W,H (front end) or Wp,Hp (back end)
+  float *d_accum = nullptr;
+  size_t accum_cap = 0, accum_count = 0;
+  // ping-pong partner of d_accum (fast path, context-owned memory only): the image kernel of evaluation k clears the
+  // buffer evaluation k-1 used, so evaluation k+1 splats into it without a memset launch
+  float *d_accum_alt = nullptr;
+  size_t accum_alt_cap = 0;
+  bool accum_clean = false, alt_clean = false;  // buffer known to be all-zero over the planes the fast path uses
+  int pingpong_planes = 0;                     // planes being ping-ponged by the pending evaluation (0 = off)
+  bool accum_external = false;
+  float *d_scratch = nullptr;  // blurred-plane readback scratch
+  size_t scratch_cap = 0;
+  int last_P = 0;              // derivative planes produced by the last accumulate()
+  bool accumulated = false;
+
+  // adjoint-gradient scratch: Jt plane, per-block gradient partials
+  float *d_itilde = nullptr;  // Jt = G^T (G I)
+  size_t itilde_cap = 0;
+  float *d_cx = nullptr, *d_cy = nullptr;  // G^T 1 = cx(x)*cy(y): column sums of the REFLECT_101 blur operator
+  size_t cx_cap = 0, cy_cap = 0;
+  double *d_gpartials = nullptr;
+  size_t gpartials_cap = 0;
+  double *d_vparts = nullptr;  // back end: per-batch partial V sums of the gather pass
+  size_t vparts_cap = 0;
+  double *d_gsum = nullptr;   // this rank's partial gradient sums [P] (caller-owned when external: RCCL reduces it in place)
+  size_t gsum_cap = 0;
+  bool gsum_external = false;
+  bool finish_pending = false; // finish_begin ran, finish_end has not
+  int pending_P = 0;
+  bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
+  // back end: image-tile occupancy of the two ping-pong accumulation buffers and of IGp (see ImgArgs::flags_*)
+  unsigned char *d_tflags = nullptr, *d_tflags_alt = nullptr, *d_igp_flags = nullptr;
+  size_t tflags_cap = 0;          // tiles
+  bool accum_flagged = false;     // every non-zero pixel of d_accum lies in a tile flagged in d_tflags
+  bool alt_flagged = false;       // the same for d_accum_alt / d_tflags_alt
+  bool igp_flags_valid = false;
+  unsigned *d_tile_list = nullptr, *d_tile_count = nullptr;  // compacted work list of the image passes (large panoramas)
+  size_t tile_list_cap = 0;
+  int tile_count_sel = 0;
+  bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
+  int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
+  int64_t reuse_hits = 0;
+  double last_x[3 * kMaxKnots] = {0};  // parameters of the last accumulate (the gather pass re-warps the events)
+
+  // LDS-privatised splat (CMX_OPT_SPLAT_MODE = 1): events sorted by destination tile, chunk table
+  bool bin_valid = false;
+  uint32_t *d_keys = nullptr, *d_keys_s = nullptr, *d_idx = nullptr, *d_idx_s = nullptr, *d_sxy = nullptr, *d_sbatch = nullptr;
+  size_t bin_cap = 0;
+  void *d_sort_temp = nullptr;
+  size_t sort_temp_cap = 0;
+  int *d_tile_start = nullptr;
+  size_t tile_start_cap = 0;
+  Chunk *d_chunks = nullptr;
+  size_t chunks_cap = 0;
+  int nchunks = 0;          // launch bound of the chunk table (its true length lives in d_nchunks)
+  int *d_nchunks = nullptr;
+  bool nchunks_exact = false;  // nchunks has been replaced by the table's true length (read back after the first evaluation)
+  unsigned *d_fallback = nullptr;
+  int64_t rebin_count = 0;
+  double last_fallback_frac = 0;
+  bool last_used_lds = false;
+  bool fallback_pending = false;  // an LDS splat ran since the counter was last read back
+
+  // reductions
+  double *d_partials = nullptr, *d_sums = nullptr;
+  size_t partials_cap = 0, sums_cap = 0;
+  double *h_result = nullptr, *d_result = nullptr;  // mapped pinned host
+  unsigned long long ticket_issued = 0;  // ticket of the last finalize launch (see sync_and_collect)
+  int ticket_nout = 0;                   // result words that launch writes
+  bool ticket_wait = true;
+  size_t result_cap = 0;
+
+  // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+
+  // timing
+  bool timing = false;
+  int timing_mask = 0;  // bit i: record HIP events around kernel class i
+  int timing_every = 1;           // sample every n-th evaluation
+  unsigned long long timing_tick = 0;  // evaluations (accumulate calls) since timing was enabled
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  double t_ms[CMX_T_COUNT] = {0};
+  int64_t t_n[CMX_T_COUNT] = {0};
+};
+
+// device-resident event store: the stream is uploaded once; packets and windows are
+// cut from it on the device
+struct cmx_events {
+  int device = 0, W = 0, H = 0;
+  size_t capacity = 0;
+  int64_t first_index = 0;   // global sequence number of slot 0
+  size_t size = 0;           // events held
+  uint32_t *d_xy[2] = {nullptr, nullptr};  // x | y << 16 ; two buffers: drop_before compacts into the other one
+  int64_t *d_t[2] = {nullptr, nullptr};
+  int cur = 0;
+  std::vector<int64_t> h_t;  // host mirror of the timestamps (per-batch pose times are formed on the host)
+  std::string err;
+};
+
+
+// ---- error text + HIP call checking
+int fail(cmx_ctx *c, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+
+#define HIP_TRY(c, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail((c), CMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int ensure(cmx_ctx *c, T *&ptr, size_t &cap, size_t need) {
+  if (need <= cap && ptr) return CMX_OK;
+  if (ptr) HIP_TRY(c, hipFree(ptr));
+  ptr = nullptr;
+  cap = 0;
+  size_t n = need ? need : 1;
+  HIP_TRY(c, hipMalloc((void **)&ptr, n * sizeof(T)));
+  cap = n;
+  return CMX_OK;
+}
+
+// ---- cmx_context.cpp
+int bind_device(cmx_ctx *c);
+long long time_batch_ns(long long t_first, long long t_last);
+double time_to_sec(long long t_ns);
+int upload_gt1(cmx_ctx *c);
+int setup_blur(cmx_ctx *c, double sigma);
+hipEvent_t get_event(cmx_ctx *c);
+void collect_spans(cmx_ctx *c);  // call after the stream has been synchronised
+int create_common(cmx_ctx **out, int kind, int device, int W, int H, const double *lut);
+int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
+int ensure_pinned_xy(cmx_ctx *c, size_t n);
+
+// kernel_exact = true: the launcher attaches the two events to the kernel itself (hipExtLaunchKernelGGL start / stop:
+// the dispatch's own begin / end timestamps, what rocprofv3 reports); otherwise the events are recorded on the
+// stream around whatever the scope launches (kernel time + boundaries).
+struct Span {
+  cmx_ctx *c;
+  TimedSpan s{};
+  bool on, kernel_exact, used = false;
+  Span(cmx_ctx *ctx, int cls, bool exact = false)
+      : c(ctx), on(ctx->timing && ((ctx->timing_mask >> cls) & 1) && (ctx->timing_tick % ctx->timing_every) == 0),
+        kernel_exact(exact) {
+    if (on) {
+      s.cls = cls;
+      s.a = get_event(c);
+      s.b = get_event(c);
+      if (!kernel_exact) hipEventRecord(s.a, c->stream);
+    }
+  }
+  hipEvent_t t0() { used = true; return on && kernel_exact ? s.a : nullptr; }
+  hipEvent_t t1() { return on && kernel_exact ? s.b : nullptr; }
+  ~Span() {
+    if (!on) return;
+    if (kernel_exact && !used) {  // nothing was launched with the events: give them back
+      c->event_pool.push_back(s.a);
+      c->event_pool.push_back(s.b);
+      return;
+    }
+    if (!kernel_exact) hipEventRecord(s.b, c->stream);
+    c->spans.push_back(s);
+  }
+};
+
+// ---- cmx_pipeline.cpp
+int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast);
+int ensure_accum(cmx_ctx *c, size_t need);
+int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be);
+BinnedEvents binned(const cmx_ctx *c);
+FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]);
+BeSplatArgs be_args(const cmx_ctx *c);
+bool adjoint_ok(const cmx_ctx *c);
+void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce);
+int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip);
+int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach);
+int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd);
+int run_adjoint(cmx_ctx *c, int P, int phase = 0);
+int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
+bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
+int finish_begin(cmx_ctx *c, int kind, int want_grad);
+int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
+int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the first evaluation of a window
+
+// ---- cmx_comm.cpp
+int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad);
+void comm_release(cmx_ctx *c);  // destroys an attached communicator (cmx_destroy)
+
+// ---- cmx_frontend.cpp / cmx_backend.cpp: the bodies behind set_packet / set_window and their *_from forms
+// (d_raw != nullptr: the events are already on the device -- event store)
+int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                       const uint32_t *d_raw, int64_t t_ref_ns, double fx, double fy, double cx, double cy,
+                       int event_batch_size, double blur_sigma, int contrast_measure);
+int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                       const uint32_t *d_raw, const int64_t *d_t, int order, int K, const double *knots_xyzw,
+                       int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size,
+                       int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);

@@ -1,0 +1,193 @@
+// cmx_frontend.cpp -- cmx_frontend_*: the drop-in for local_contrast_{f,df,fdf}
+// (src/frontend/local_optim_contrast_gsl.cpp:20-70 -> local_image_warped_events.cpp:10-170 -> local_focus_funcs.cpp:82-120).
+#include "cmx_context.hpp"
+
+int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *lut) {
+  int rc = create_common(out, KIND_FE, device, W, H, lut);
+  if (rc) return rc;
+  (*out)->imgW = W;
+  (*out)->imgH = H;
+  return CMX_OK;
+}
+
+// d_raw != nullptr: the events are already on the device (event store), x / y are unused and t_ns is the store's
+// host mirror of the timestamps
+int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                              const uint32_t *d_raw, int64_t t_ref_ns, double fx, double fy, double cx, double cy,
+                              int event_batch_size, double blur_sigma, int contrast_measure) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  c->have_data = false;
+  c->accumulated = false;
+  c->x_valid = false;
+  if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
+  // computeContrast's switch (local_focus_funcs.cpp:98-109): 1 = mean square, 2 = gradient magnitude, default = variance
+  if (contrast_measure != CMX_MEAN_SQUARE && contrast_measure != CMX_GRADIENT_MAGNITUDE) contrast_measure = CMX_VARIANCE;
+  if (!d_raw) {
+    rc = check_event_args(c, n, x, y, t_ns);
+    if (rc) return rc;
+  } else if (n < 0 || n > kMaxEvents) {
+    return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld", (long long)n);
+  }
+  rc = setup_blur(c, blur_sigma);
+  if (rc) return rc;
+  c->fx = fx; c->fy = fy; c->cx = cx; c->cy = cy;
+  c->batch = event_batch_size;
+  c->measure = contrast_measure;
+
+  // SoA packing + per-batch dt = time_batch.toSec() - time_ref.toSec()  (local_image_warped_events.cpp:68-75)
+  const int nb = (int)((n + event_batch_size - 1) / event_batch_size);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging buffer may still feed the previous upload
+  uint32_t *xy = nullptr;
+  if (!d_raw) {
+    rc = ensure_pinned_xy(c, (size_t)n);
+    if (rc) return rc;
+    xy = c->h_xy;
+    std::atomic<unsigned> out_of_range(0);
+    const unsigned W = (unsigned)c->W, H = (unsigned)c->H;
+    parallel_ranges(n, [&](int64_t a, int64_t b) {
+      unsigned acc = 0;
+      for (int64_t i = a; i < b; i++) {
+        acc |= (unsigned)(x[i] >= W) | (unsigned)(y[i] >= H);
+        xy[i] = (uint32_t)x[i] | ((uint32_t)y[i] << 16);
+      }
+      if (acc) out_of_range = 1;
+    });
+    if (out_of_range.load()) return check_events(c, n, x, y, t_ns);  // locate and report the offender
+  }
+  std::vector<double> dts((size_t)nb);
+  const double tref = time_to_sec(t_ref_ns);
+  std::atomic<int> bad_batch(-1);
+  parallel_ranges(nb, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t beg = b * event_batch_size;
+      const int64_t end = (beg + event_batch_size < n) ? beg + event_batch_size : n;
+      if (t_ns[end - 1] < t_ns[beg]) { bad_batch = (int)b; return; }
+      dts[(size_t)b] = time_to_sec(time_batch_ns(t_ns[beg], t_ns[end - 1])) - tref;
+    }
+  }, /*serial_below=*/4096);
+  if (bad_batch.load() >= 0) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", bad_batch.load());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = ensure(c, c->d_xy, c->xy_cap, (size_t)n);
+  if (rc) return rc;
+  rc = ensure(c, c->d_batch_dt, c->batch_cap, (size_t)nb);
+  if (rc) return rc;
+  if (n) {
+    if (d_raw) HIP_TRY(c, hipMemcpyAsync(c->d_xy, d_raw, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_batch_dt, dts.data(), (size_t)nb * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->n_packed = (int)n;
+  c->per_batch = event_batch_size;
+  c->nb = nb;
+  c->have_data = true;
+  c->bin_valid = false;
+  return CMX_OK;
+}
+
+int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
+                            int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
+                            double blur_sigma, int contrast_measure) {
+  return fe_set_packet_impl(c, n, x, y, t_ns, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma, contrast_measure);
+}
+
+static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+  c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
+  const size_t np = (size_t)c->W * c->H;
+  int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);
+  if (rc) return rc;
+  FeSplatArgs a = fe_args(c, omega);
+  for (int k = 0; k < 3; k++) c->last_x[k] = omega[k];
+  const bool use_lds = c->splat_mode == 1 && nplanes == 1 && c->n_packed > 0;
+  if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
+    rc = do_binning(c, &a, nullptr);
+    if (rc) return rc;
+  }
+  {
+    Span sp(c, CMX_T_SPLAT, /*exact=*/true);
+    c->last_used_lds = use_lds;
+    if (use_lds) c->fallback_pending = true;
+    if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream, sp.t0(), sp.t1());
+    else launch_fe_splat(a, nplanes > 1, c->stream, sp.t0(), sp.t1());
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->accum_count = nplanes * np;
+  c->last_P = nplanes - 1;
+  c->accumulated = true;
+  c->x_valid = true;
+  return CMX_OK;
+}
+
+int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
+  if (!omega) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  c->last_adjoint = want_grad && adjoint_ok(c);
+  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1);
+}
+
+int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
+  if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
+  if (grad && c->last_P != 3 && !c->last_adjoint)
+    return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
+  else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  if (rc) return rc;
+  rc = sync_and_collect(c, true);
+  if (rc) return rc;
+  *contrast = c->h_result[0];
+  if (grad) for (int k = 0; k < 3; k++) grad[k] = c->h_result[2 + k];
+  return CMX_OK;
+}
+
+int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
+  const bool sharded = c && c->comm;
+  if (c && c->kind == KIND_FE && omega && can_reuse(c, omega, 3, grad != nullptr)) {
+    c->last_adjoint = true;  // image of this very point is resident: adjoint blur + gather only
+    c->reuse_hits++;
+    if (sharded) return finish_sharded(c, KIND_FE, false, contrast, grad);
+    return cmx_frontend_finish(c, contrast, grad);
+  }
+  int rc = cmx_frontend_accumulate(c, omega, grad != nullptr);
+  if (rc) return rc;
+  if (sharded) return finish_sharded(c, KIND_FE, true, contrast, grad);
+  return cmx_frontend_finish(c, contrast, grad);
+}
+
+int cmx_frontend_get_iwe(cmx_ctx *c, const double omega[3], int blur, float *iwe, float *deriv) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
+  if (!omega || !iwe) return fail(c, CMX_ERR_INVALID_ARG, "null argument");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  const size_t np = (size_t)c->W * c->H;
+  const int nplanes = deriv ? 4 : 1;
+  c->last_adjoint = false;
+  rc = fe_accumulate(c, omega, nplanes);
+  c->x_valid = false;
+  if (rc) return rc;
+  rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
+  if (rc) return rc;
+  const float *src = c->d_accum;
+  if (blur && c->radius > 0) {
+    rc = run_image_and_finalize(c, nplanes - 1, c->d_scratch, c->d_scratch + np);
+    if (rc) return rc;
+    src = c->d_scratch;
+  }
+  HIP_TRY(c, hipMemcpyAsync(iwe, src, np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (deriv) {
+    float *inter = c->d_scratch + 4 * np;
+    launch_interleave3(src + np, inter, (int)np, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(deriv, inter, 3 * np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  return sync_and_collect(c);
+}
+

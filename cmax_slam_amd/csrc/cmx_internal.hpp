@@ -1,5 +1,5 @@
-// cmx_internal.hpp -- kernel parameter blocks and launcher prototypes shared by cmx_kernels.hip and
-// cmx_capi.cpp.  gfx950 only.
+// cmx_internal.hpp -- kernel parameter blocks and launcher prototypes shared by cmx_kernels.hip, cmx_binning.hip and
+// the host side of the C ABI (cmx_context.hpp).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

@@ -1,0 +1,555 @@
+// cmx_pipeline.cpp -- one evaluation on the context's stream: accumulation buffers (ping-pong), destination-tile sort,
+// image passes, gather, finalize and the completion ticket.  Shared by the front end and the back end.
+#include "cmx_context.hpp"
+
+// Fast path: swap to the partner buffer if it is known clean, otherwise clear the current one.  After this call
+// c->d_accum is all-zero over `nplanes` planes and c->pingpong_planes tells the image pass to clear the partner.
+int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast) {
+  c->pingpong_planes = 0;
+  const size_t need = (size_t)nplanes * np;
+  if (fast && !c->accum_external) {
+    float *before = c->d_accum;
+    int rc = ensure(c, c->d_accum, c->accum_cap, need);
+    if (rc) return rc;
+    if (c->d_accum != before) c->accum_clean = false;  // fresh allocation: contents undefined
+    if (c->accum_alt_cap < need || !c->d_accum_alt) {
+      rc = ensure(c, c->d_accum_alt, c->accum_alt_cap, c->accum_cap > need ? c->accum_cap : need);
+      if (rc) return rc;
+      c->alt_clean = false;
+      c->alt_flagged = false;  // contents unknown: the next image pass clears every tile
+    }
+    if (c->alt_clean) {
+      std::swap(c->d_accum, c->d_accum_alt);
+      std::swap(c->accum_cap, c->accum_alt_cap);
+      std::swap(c->accum_clean, c->alt_clean);
+      std::swap(c->d_tflags, c->d_tflags_alt);
+      std::swap(c->accum_flagged, c->alt_flagged);
+    }
+    if (!c->accum_clean) {
+      Span sp(c, CMX_T_ZERO);
+      HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
+      if (c->d_tflags) HIP_TRY(c, hipMemsetAsync(c->d_tflags, 0, c->tflags_cap, c->stream));
+    }
+    c->accum_flagged = false;  // set by the caller once a flag-marking splat has been launched into the clean buffer
+    c->accum_clean = false;  // about to be written
+    c->alt_clean = false;    // holds the previous evaluation's planes until this evaluation's image pass clears it
+    c->pingpong_planes = nplanes;
+    return CMX_OK;
+  }
+  int rc = ensure_accum(c, need);
+  if (rc) return rc;
+  {
+    Span sp(c, CMX_T_ZERO);
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, need * sizeof(float), c->stream));
+  }
+  c->accum_clean = false;
+  c->accum_flagged = false;
+  return CMX_OK;
+}
+
+int ensure_accum(cmx_ctx *c, size_t need) {
+  if (c->accum_external) {
+    if (need > c->accum_cap)
+      return fail(c, CMX_ERR_INVALID_ARG, "external accumulation buffer too small: %zu < %zu floats", c->accum_cap, need);
+    return CMX_OK;
+  }
+  return ensure(c, c->d_accum, c->accum_cap, need);
+}
+
+// ---- sort the events by destination tile under the CURRENT parameters and build the chunk table
+int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
+  const int n = c->n_packed;
+  const int W = c->imgW, H = c->imgH;
+  const int tiles_x = (W + kBinTile - 1) / kBinTile, tiles_y = (H + kBinTile - 1) / kBinTile;
+  const int planes_per_tile = fe ? 1 : 2;  // back end: key = 2*tile + (IL_new ? 1 : 0)
+  const int ntiles = tiles_x * tiles_y * planes_per_tile;
+  int rc;
+  if ((size_t)n > c->bin_cap || !c->d_keys) {
+    uint32_t **ptrs[6] = {&c->d_keys, &c->d_keys_s, &c->d_idx, &c->d_idx_s, &c->d_sxy, &c->d_sbatch};
+    for (auto p : ptrs) {
+      if (*p) HIP_TRY(c, hipFree(*p));
+      *p = nullptr;
+      HIP_TRY(c, hipMalloc((void **)p, (size_t)(n > 0 ? n : 1) * sizeof(uint32_t)));
+    }
+    c->bin_cap = (size_t)(n > 0 ? n : 1);
+  }
+  if (!c->d_fallback) {
+    HIP_TRY(c, hipMalloc((void **)&c->d_fallback, sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(c->d_fallback, 0, sizeof(unsigned), c->stream));
+  }
+  rc = ensure(c, c->d_tile_start, c->tile_start_cap, (size_t)ntiles + 2);
+  if (rc) return rc;
+  // chunk size: hot tiles are split so that ~3 workgroups per CU exist; big chunks amortise the window flush
+  int M = n / 768;
+  M = M < 1536 ? 1536 : (M > 32768 ? 32768 : M);  // floor swept on MI355X (1M events: 1536 -> 11.8 us, 2048 -> 12.9, 1024 -> 15.3)
+  M = (M + 255) / 256 * 256;
+  // every tile contributes floor(len/M) full chunks and at most one remainder: an upper bound known on the host
+  const int max_chunks = (n / M) + ntiles + 2;
+  rc = ensure(c, c->d_chunks, c->chunks_cap, (size_t)max_chunks);
+  if (rc) return rc;
+  if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
+  if (n > 0) {
+    if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
+    else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
+    int end_bit = 1;
+    while ((1 << end_bit) <= ntiles) end_bit++;
+    size_t tb = 0;
+    if (sort_pairs_u32(nullptr, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+      return fail(c, CMX_ERR_HIP, "rocprim radix sort (size query) failed");
+    if (tb > c->sort_temp_cap) {
+      if (c->d_sort_temp) HIP_TRY(c, hipFree(c->d_sort_temp));
+      c->d_sort_temp = nullptr;
+      HIP_TRY(c, hipMalloc(&c->d_sort_temp, tb));
+      c->sort_temp_cap = tb;
+    }
+    if (sort_pairs_u32(c->d_sort_temp, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+      return fail(c, CMX_ERR_HIP, "rocprim radix sort failed");
+    launch_apply_perm(c->d_xy, c->d_idx_s, c->per_batch, n, c->d_sxy, c->d_sbatch, c->stream);
+    launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
+    // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
+    launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->nchunks = max_chunks;
+    c->nchunks_exact = false;
+  } else {
+    HIP_TRY(c, hipMemsetAsync(c->d_nchunks, 0, sizeof(int), c->stream));
+    c->nchunks = 0;
+    c->nchunks_exact = true;
+  }
+  c->bin_valid = true;
+  c->rebin_count++;
+  c->last_fallback_frac = 0;
+  return CMX_OK;
+}
+
+BinnedEvents binned(const cmx_ctx *c) {
+  BinnedEvents b{};
+  b.sxy = c->d_sxy;
+  b.sbatch = c->d_sbatch;
+  b.chunks = c->d_chunks;
+  b.nchunks = c->nchunks;
+  b.nchunks_dev = c->d_nchunks;
+  b.fallback = c->d_fallback;
+  return b;
+}
+
+FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]) {
+  FeSplatArgs a{};
+  a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
+  a.wx = omega[0]; a.wy = omega[1]; a.wz = omega[2];
+  a.W = c->W; a.H = c->H;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.xy = c->d_xy;
+  a.batch_dt = c->d_batch_dt;
+  a.lut = c->d_lut;
+  a.lut2 = c->d_lut2;
+  a.planes = c->d_accum;
+  return a;
+}
+
+BeSplatArgs be_args(const cmx_ctx *c) {
+  BeSplatArgs a{};
+  a.W = c->W;
+  a.Wp = c->Wp; a.Hp = c->Hp;
+  a.fx = (double)((c->Wp / 360.0) * 180.0 / 3.1415926535897932384626433832795);  // focalFromFOV(.., 360, 180)
+  a.fy = (double)((c->Hp / 180.0) * 180.0 / 3.1415926535897932384626433832795);
+  a.cxp = (double)c->Wp / 2.0;
+  a.cyp = (double)c->Hp / 2.0;
+  a.per_batch = c->per_batch;
+  a.n = c->n_packed;
+  a.order = c->order;
+  a.num_fixed = c->num_fixed;
+  a.xy = c->d_xy;
+  a.poseR = c->d_poseR;
+  a.poses = c->d_poses;
+  a.lut = c->d_lut;
+  a.lut2 = c->d_lut2;
+  a.planes = c->d_accum;
+  return a;
+}
+
+bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: image larger than the kernel
+  if (c->measure == CMX_GRADIENT_MAGNITUDE) return false;  // Sobel contrast: derivative-plane form only
+  return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
+}
+
+// every evaluation ends in exactly one finalize launch; it carries the ticket sync_and_collect() waits for
+void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
+  f.ticket = ++c->ticket_issued;
+  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  if (with_reduce) launch_finalize(f, c->stream);
+  else launch_finalize_only(f, c->stream);
+}
+
+// ping-pong partner clearing + tile-occupancy flags of an image pass (see ImgArgs)
+int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip) {
+  a.tiles_y = (a.H + kTileY - 1) / kTileY;
+  if (a.zero_ptr) {
+    if (c->alt_flagged && c->d_tflags_alt) {
+      a.flags_other = c->d_tflags_alt;  // clear the dirty tiles only
+    } else if (c->d_tflags_alt) {
+      HIP_TRY(c, hipMemsetAsync(c->d_tflags_alt, 0, c->tflags_cap, c->stream));  // everything is cleared: no flag survives
+    }
+    c->alt_flagged = true;  // clean buffer, no flags: trivially consistent
+  }
+  if (may_skip && c->accum_flagged && c->d_tflags && (!a.igp || c->igp_flags_valid)) {
+    a.flags_cur = c->d_tflags;
+    a.flags_igp = a.igp ? c->d_igp_flags : nullptr;
+  }
+  return CMX_OK;
+}
+
+// large panoramas: compact the tiles that need work (call once a.partials / flags / zero_ptr are final)
+int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
+  if (!a.flags_cur || a.nblk <= kTileListMin) return CMX_OK;
+  if ((size_t)a.nblk > c->tile_list_cap || !c->d_tile_list) {
+    if (c->d_tile_list) HIP_TRY(c, hipFree(c->d_tile_list));
+    if (c->d_tile_count) HIP_TRY(c, hipFree(c->d_tile_count));
+    c->d_tile_list = c->d_tile_count = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_tile_list, (size_t)a.nblk * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tile_count, 2 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_count, 0, 2 * sizeof(unsigned), c->stream));
+    c->tile_list_cap = (size_t)a.nblk;
+    c->tile_count_sel = 0;
+  }
+  unsigned *cur = c->d_tile_count + c->tile_count_sel, *next = c->d_tile_count + (c->tile_count_sel ^ 1);
+  c->tile_count_sel ^= 1;  // this pass counts in `cur` and zeroes `next` for the pass after it
+  launch_tile_list(a, reach, c->d_tile_list, cur, next, c->stream);
+  a.tile_list = c->d_tile_list;
+  a.tile_count = cur;
+  return CMX_OK;
+}
+
+// image pass on the accumulated planes -> partial moments -> contrast/gradient in h_result
+int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd) {
+  const int W = c->imgW, H = c->imgH;
+  const size_t np = (size_t)W * H;
+  ImgArgs a{};
+  a.W = W;
+  a.H = H;
+  a.r = c->radius;
+  memcpy(a.taps, c->taps, sizeof(a.taps));
+  if (c->kind == KIND_FE) {
+    a.src_a = c->d_accum;
+    a.src_b = nullptr;
+    a.igp = nullptr;
+    a.alpha = nullptr;
+    a.dplanes = c->d_accum + np;
+  } else {
+    a.src_a = c->d_accum;
+    a.src_b = c->d_accum + np;
+    a.igp = c->ig_nonzero ? c->d_IGp : nullptr;
+    a.alpha = c->d_alpha;
+    a.dplanes = c->d_accum + 2 * np;
+  }
+  a.P = P;
+  a.out_blur0 = out_blur0;
+  a.out_blurd = out_blurd;
+  if (c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+    a.zero_ptr = c->d_accum_alt;
+    a.zero_planes = c->pingpong_planes;
+    c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs
+  }
+  a.tiles_x = (W + kTileX - 1) / kTileX;
+  a.nblk = a.tiles_x * ((H + kTileY - 1) / kTileY);
+  const size_t nq = 2 + 2 * (size_t)P;
+  int rc = attach_tiles(c, a, /*may_skip=*/P == 0 && !out_blur0 && !out_blurd);
+  if (rc) return rc;
+  rc = ensure(c, c->d_partials, c->partials_cap, nq * a.nblk);
+  if (rc) return rc;
+  rc = ensure(c, c->d_sums, c->sums_cap, nq);
+  if (rc) return rc;
+  if (2 + (size_t)P > c->result_cap - 1) return fail(c, CMX_ERR_INVALID_ARG, "too many derivative planes (%d)", P);
+  a.partials = c->d_partials;
+  if (c->measure == CMX_GRADIENT_MAGNITUDE && c->kind == KIND_FE) {
+    // blurred planes -> scratch, then Sobel moments (reference local_focus_funcs.cpp:47-73), then finalize
+    const size_t np = (size_t)W * H;
+    float *blur = out_blur0;
+    if (!blur) {
+      rc = ensure(c, c->d_scratch, c->scratch_cap, 7 * np);
+      if (rc) return rc;
+      blur = c->d_scratch;
+      a.out_blur0 = blur;
+      a.out_blurd = blur + np;
+    }
+    SobelArgs sa{};
+    sa.W = W; sa.H = H; sa.P = P;
+    sa.planes = blur;
+    sa.nblk = sobel_blocks(W, H);
+    rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)(1 + P) * sa.nblk);
+    if (rc) return rc;
+    sa.partials = c->d_gpartials;
+    Span sp(c, CMX_T_IMAGE);
+    launch_image_moments(a, c->stream);
+    launch_sobel_moments(sa, c->stream);
+    FinalizeArgs f{};
+    f.P = 0; f.nblk = a.nblk; f.measure = 2; f.npix = (double)np;
+    f.partials = c->d_partials; f.sums = c->d_sums; f.result = c->d_result;
+    f.direct = 1;
+    f.gpartials = c->d_gpartials; f.gblocks = sa.nblk; f.gP = P;
+    f.fallback = c->d_fallback;
+    issue_finalize(c, f, false);
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
+  {
+    Span sp(c, CMX_T_IMAGE);
+    rc = maybe_tile_list(c, a, c->radius);
+    if (rc) return rc;
+    launch_image_moments(a, c->stream);
+    FinalizeArgs f{};
+    f.P = P;
+    f.nblk = a.nblk;
+    f.measure = c->measure;
+    f.npix = (double)np;
+    f.partials = c->d_partials;
+    f.sums = c->d_sums;
+    f.result = c->d_result;
+    f.fallback = c->d_fallback;
+    if (P == 0 && (a.nblk <= 2048 || a.tile_list)) {
+      f.direct = 1;
+      f.nvalid = a.tile_count;  // list path: partial rows are compact, one entry per listed tile
+      issue_finalize(c, f, false);
+    } else {
+      issue_finalize(c, f, true);
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
+}
+
+// adjoint gradient: fused image pass (B = G*A with its moments, Jt = G^T B^) -> gather over the events (S1, and S2 for
+// the votes next to the border) -> finalize: contrast from the moments, grad = (2/N)(S1 - mu*S2).
+// phase 0 = everything; 1 = up to the per-rank partial sums (d_gsum, 2P doubles); 2 = finalize from d_gsum.
+int run_adjoint(cmx_ctx *c, int P, int phase) {
+  const int W = c->imgW, H = c->imgH;
+  const size_t np = (size_t)W * H;
+  float *jt_before = c->d_itilde;
+  int rc = ensure(c, c->d_itilde, c->itilde_cap, np);
+  if (rc) return rc;
+  if (c->d_itilde != jt_before)  // tiles the image pass skips keep whatever they held: make that finite from the start
+    HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
+  ImgAdjArgs ia{};
+  ImgArgs &a = ia.img;
+  a.W = W; a.H = H; a.r = c->radius;
+  memcpy(a.taps, c->taps, sizeof(a.taps));
+  a.src_a = c->d_accum;
+  if (c->kind == KIND_BE) {
+    a.src_b = c->d_accum + np;
+    a.igp = c->ig_nonzero ? c->d_IGp : nullptr;
+    a.alpha = c->d_alpha;
+  }
+  a.P = 0;
+  a.tiles_x = image_adjoint_tiles_x(W);
+  a.nblk = image_adjoint_tiles(W, H);
+  if (phase != 2 && c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+    a.zero_ptr = c->d_accum_alt;
+    a.zero_planes = c->pingpong_planes;
+    c->alt_clean = true;
+  }
+  rc = attach_tiles(c, a, /*may_skip=*/true);
+  if (rc) return rc;
+  ia.jt = c->d_itilde;
+  rc = ensure(c, c->d_partials, c->partials_cap, (size_t)2 * a.nblk);
+  if (rc) return rc;
+  rc = ensure(c, c->d_sums, c->sums_cap, 2);
+  if (rc) return rc;
+  // rows of the gather partial table: front end = gather workgroups; back end = workgroups of the per-batch pass
+  const int gb = (c->kind == KIND_FE) ? fe_gather_blocks(c->n_packed) : be_batch_blocks(c->nb);
+  const int P2 = 2 * (P > 0 ? P : 1);
+  rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)gb * P2);
+  if (rc) return rc;
+  // four events per lane in the back-end gather when a lane's four events cannot straddle a batch boundary
+  const int slice_shift = (c->kind == KIND_BE && c->per_batch % 4 == 0) ? 8 : 6;
+  const int parts_per_batch = ((c->per_batch + (1 << slice_shift) - 2) >> slice_shift) + 1;
+  if (c->kind == KIND_BE) {
+    rc = ensure(c, c->d_vparts, c->vparts_cap, (size_t)(c->nb > 0 ? c->nb : 1) * parts_per_batch * 6);
+    if (rc) return rc;
+  }
+  if (2 + (size_t)P > c->result_cap - 2) return fail(c, CMX_ERR_INVALID_ARG, "too many parameters (%d)", P);
+  if (!c->gsum_external) {
+    rc = ensure(c, c->d_gsum, c->gsum_cap, (size_t)P2);
+    if (rc) return rc;
+  } else if ((size_t)P2 > c->gsum_cap) {
+    return fail(c, CMX_ERR_INVALID_ARG, "external gradient buffer too small: %zu < %d doubles", c->gsum_cap, P2);
+  }
+  a.partials = c->d_partials;
+  FinalizeArgs f{};
+  f.P = 0;
+  f.nblk = a.nblk;
+  f.measure = c->measure;
+  f.npix = (double)np;
+  f.partials = c->d_partials;
+  f.sums = c->d_sums;
+  f.result = c->d_result;
+  if (phase != 2) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
+    rc = maybe_tile_list(c, a, 2 * c->radius);
+    if (rc) return rc;
+  }
+  const bool direct = a.nblk <= 2048 || a.tile_list;  // few entries: finalize sums the per-tile moments itself
+  f.direct = direct ? 1 : 0;
+  f.nvalid = a.tile_count;
+  f.mu_free = 1;
+  if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
+    f.gpartials = c->d_gpartials;
+    f.gblocks = gb;
+  } else {           // split call: finalize reads the (all-reduced) per-parameter sums
+    f.gpartials = c->d_gsum;
+    f.gblocks = 1;
+  }
+  f.gP = P;
+  f.fallback = c->d_fallback;
+  if (phase == 2) {
+    issue_finalize(c, f, false);
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
+  {
+    Span sp(c, CMX_T_IMAGE);
+    launch_image_adjoint(ia, c->stream);
+    if (!direct) launch_reduce_partials(f, c->stream);
+  }
+  {
+    Span sp(c, CMX_T_GATHER, /*exact=*/true);
+    if (c->kind == KIND_FE) {
+      FeGatherArgs g{};
+      g.ev = fe_args(c, c->last_x);
+      g.itilde = c->d_itilde;
+      g.gpartials = c->d_gpartials;
+      g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
+      if (c->splat_mode == 1 && c->bin_valid) {  // tile order: the same sorted arrays the LDS splat consumes
+        g.sxy = c->d_sxy;
+        g.sbatch = c->d_sbatch;
+      }
+      if (c->n_packed > 0) launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+    } else {
+      BeGatherArgs g{};
+      g.ev = be_args(c);
+      g.itilde = c->d_itilde;
+      g.P = P;
+      g.gpartials = c->d_gpartials;
+      g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
+      g.vparts = c->d_vparts;
+      g.parts_per_batch = parts_per_batch;
+      g.slice_shift = slice_shift;
+      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
+      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+    }
+    if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
+  }
+  if (phase == 1) {
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
+  issue_finalize(c, f, false);
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
+}
+
+int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
+  // ends_in_finalize: the last thing queued on the stream is an evaluation's finalize kernel.  Wait for it through
+  // its completion ticket in mapped host memory (a few microseconds earlier than the runtime reports the stream idle);
+  // anything slower than the spin budget, and every caller that queued copies or other kernels after the finalize,
+  // takes the ordinary stream synchronisation.
+  bool done = false;
+  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) {
+    const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result);
+    const unsigned long long want = c->ticket_issued;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      if (w[kTicketSlot] == want) {  // ticket seen: accept only a consistent snapshot of the results
+        unsigned long long x = w[kFallbackSlot];
+        for (int k = 0; k < c->ticket_nout; k++) x ^= w[k];
+        if ((x ^ (want * kTicketMix)) == w[kChecksumSlot]) { done = true; break; }
+      }
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+        break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->nchunks_exact && c->bin_valid && c->d_nchunks) {  // once per binning: launch exactly the chunks that exist
+    int nch = 0;
+    if (hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
+    c->nchunks_exact = true;
+  }
+  if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[kFallbackSlot] / (double)c->n_packed;
+  c->fallback_pending = false;
+  // timing spans are resolved lazily (cmx_timing_get) so that timed evaluations wait exactly like untimed ones
+  if (c->spans.size() > 4096) {
+    if (done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
+  }
+  return CMX_OK;
+}
+
+bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) {
+  if (!want_grad || !c->reuse_image || !c->have_data || !c->accumulated || !c->x_valid) return false;
+  if (!adjoint_ok(c) || c->accum_external) return false;
+  return memcmp(x, c->last_x, sizeof(double) * (size_t)n) == 0;
+}
+
+// ---- three-phase finish for sharded adjoint evaluations: begin (image, adjoint blur, gather -> partial gradient
+// sums on the device), caller all-reduces cmx_grad_ptr(), end (finalize + read-back)
+int finish_begin(cmx_ctx *c, int kind, int want_grad) {
+  if (!c || c->kind != kind) return fail(c, CMX_ERR_STATE, "wrong context kind");
+  if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish_begin without accumulate");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  const int P = (kind == KIND_FE) ? 3 : 3 * (c->K - c->num_fixed);
+  if (kind == KIND_BE) {
+    rc = be_first_iter(c);
+    if (rc) return rc;
+  }
+  if (want_grad && c->last_adjoint) {
+    rc = run_adjoint(c, P, 1);
+    c->pending_P = P;
+  } else {
+    if (want_grad && c->last_P != P) return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
+    rc = run_image_and_finalize(c, want_grad ? P : 0, nullptr, nullptr);
+    c->pending_P = -1;  // nothing left to exchange: finish_end only synchronises
+  }
+  if (rc) return rc;
+  c->finish_pending = true;
+  return CMX_OK;
+}
+int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad) {
+  if (!c || c->kind != kind) return fail(c, CMX_ERR_STATE, "wrong context kind");
+  if (!c->finish_pending) return fail(c, CMX_ERR_STATE, "finish_end without finish_begin");
+  if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  const int P = (kind == KIND_FE) ? 3 : 3 * (c->K - c->num_fixed);
+  if (c->pending_P >= 0) {
+    rc = run_adjoint(c, c->pending_P, 2);
+    if (rc) return rc;
+  }
+  c->finish_pending = false;
+  rc = sync_and_collect(c, true);
+  if (rc) return rc;
+  *contrast = c->h_result[0];
+  if (grad) for (int k = 0; k < P; k++) grad[k] = c->h_result[2 + k];
+  return CMX_OK;
+}
+int cmx_frontend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_FE, want_grad); }
+int cmx_frontend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_FE, contrast, grad); }
+int cmx_backend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_BE, want_grad); }
+int cmx_backend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_BE, contrast, grad); }
+void *cmx_grad_ptr(const cmx_ctx *c) { return c ? c->d_gsum : nullptr; }
+size_t cmx_grad_count(const cmx_ctx *c) { return (c && c->finish_pending && c->pending_P > 0) ? (size_t)(2 * c->pending_P) : 0; }
+int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->gsum_external && c->d_gsum) HIP_TRY(c, hipFree(c->d_gsum));
+  c->d_gsum = (double *)device_ptr;
+  c->gsum_cap = device_ptr ? n_doubles : 0;
+  c->gsum_external = device_ptr != nullptr;
+  return CMX_OK;
+}
+

@@ -28,6 +28,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: exactly these symbols are exported */
+#endif
 
 typedef struct cmx_ctx cmx_ctx;
 
@@ -294,6 +297,9 @@ int cmx_get_stats(cmx_ctx *ctx, double stats[8]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
