@@ -92,10 +92,45 @@ __global__ __launch_bounds__(64) void be_pose_table_kernel(const SplineArgs sp, 
   }
 }
 
+// the same table from a spline whose per-pair constants the host has already evaluated (K <= kMaxKnotsPre)
+template <int N, bool WANT_J>
+__global__ __launch_bounds__(64) void be_pose_table_pre_kernel(const SplineArgsPre sp, const long long *batch_t, int nb,
+                                                               PoseR *outR, PoseEntry *out) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nb) return;
+  Mat3 R, J[N];
+  int idx;
+  spline_eval_pre<N, WANT_J>(sp, batch_t[b], R, J, idx);
+  PoseEntry &o = out[b];
+#pragma unroll
+  for (int i = 0; i < 9; i++) outR[b].R[i] = R.m[i];
+  o.idx_cp_beg = idx;
+  if (WANT_J) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o.Jcp[r * (3 * N) + 3 * k + c] = (float)J[k].m[r * 3 + c];
+  }
+}
+
 void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,
                           PoseR *outR, PoseEntry *out, hipStream_t s) {
   if (nb <= 0) return;
   const dim3 g((nb + 63) / 64), b(64);
+  if (spline.K <= kMaxKnotsPre) {
+    SplineArgsPre pre;
+    spline_precompute(spline, pre);
+    if (order == 2) {
+      if (want_j) hipLaunchKernelGGL((be_pose_table_pre_kernel<2, true>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+      else hipLaunchKernelGGL((be_pose_table_pre_kernel<2, false>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+    } else {
+      if (want_j) hipLaunchKernelGGL((be_pose_table_pre_kernel<4, true>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+      else hipLaunchKernelGGL((be_pose_table_pre_kernel<4, false>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+    }
+    return;
+  }
   if (order == 2) {
     if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<2, true>), g, b, 0, s, spline, d_batch_t, nb, outR, out);
     else hipLaunchKernelGGL((be_pose_table_kernel<2, false>), g, b, 0, s, spline, d_batch_t, nb, outR, out);

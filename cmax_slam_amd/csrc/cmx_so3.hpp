@@ -35,6 +35,16 @@ CMX_HD Quat q_mul(Quat a, Quat b) {
   r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
   return q_normalized(r);
 }
+// product re-normalised with one reciprocal instead of four divisions (pose-table chain; <= 1 ulp from q_mul)
+CMX_HD Quat q_mul_rcp(Quat a, Quat b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  const double inv = 1.0 / sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  return Quat{r.x * inv, r.y * inv, r.z * inv, r.w * inv};
+}
 CMX_HD Quat so3_exp(double wx, double wy, double wz) {
   const double theta_sq = wx * wx + wy * wy + wz * wz;
   double imag, real;
@@ -197,6 +207,111 @@ CMX_HD void spline_eval(const SplineArgs &sp, long long t_ns, Mat3 &R, Mat3 *Jbl
   if (WANT_J) Jblocks[N - 1] = Jh;
   R = q_to_R(res);
   if (q_out) *q_out = res;
+}
+
+// ---- the same evaluation with everything that depends on the KNOTS only taken out of the per-batch chain.
+// Of the work spline_eval does per segment, log(knot_i^-1 knot_{i+1}), its inverse left Jacobian and R(knot_i^-1) are
+// the same for every batch of an evaluation: the host computes them once per evaluation (K-1 pairs, < 1 us) and they
+// travel with the knots as kernel arguments.  The pose-table kernel is one thread per batch on < 1 wave per SIMD, i.e.
+// bound by the length of its dependent fp64 chain: per segment this leaves one sqrt, one sin/cos pair (shared by
+// exp(k delta) and the left Jacobian, which only feeds the fp32 Jacobian table) and two scalar divisions.
+constexpr int kMaxKnotsPre = 16;
+struct PairConsts {
+  double delta[3];  // log(knot_i^-1 * knot_{i+1})
+  double Jinv[9];   // leftJacobianInvSO3(delta)
+  double Rc[9];     // R(knot_i^-1)
+};
+struct SplineArgsPre {
+  int order, K;
+  long long start_ns, dt_ns;
+  double blend[kMaxOrder * kMaxOrder];
+  Quat knots[kMaxKnotsPre];
+  PairConsts pair[kMaxKnotsPre - 1];
+};
+static_assert(sizeof(SplineArgsPre) <= 3600, "SplineArgsPre travels as a kernel argument (4 KB limit with the others)");
+
+inline void spline_precompute(const SplineArgs &sp, SplineArgsPre &o) {  // host, once per evaluation
+  o.order = sp.order; o.K = sp.K; o.start_ns = sp.start_ns; o.dt_ns = sp.dt_ns;
+  for (int i = 0; i < kMaxOrder * kMaxOrder; i++) o.blend[i] = sp.blend[i];
+  for (int i = 0; i < sp.K; i++) o.knots[i] = sp.knots[i];
+  for (int i = 0; i + 1 < sp.K; i++) {
+    const Quat p0 = sp.knots[i], p1 = sp.knots[i + 1];
+    so3_log(q_mul(q_conj(p0), p1), o.pair[i].delta);
+    const Mat3 Ji = left_jacobian_inv(o.pair[i].delta), Rc = q_to_R(q_conj(p0));
+    for (int c = 0; c < 9; c++) { o.pair[i].Jinv[c] = Ji.m[c]; o.pair[i].Rc[c] = Rc.m[c]; }
+  }
+}
+
+template <int N, bool WANT_J>
+CMX_HD void spline_eval_pre(const SplineArgsPre &sp, long long t_ns, Mat3 &R, Mat3 *Jblocks, int &start_idx) {
+  const long long st = t_ns - sp.start_ns;
+  const long long s = st / sp.dt_ns;
+  const double u = (double)(st % sp.dt_ns) / (double)sp.dt_ns;
+  double p[N], coeff[N];
+  p[0] = 1.0;
+  double ti = u;
+#pragma unroll
+  for (int j = 1; j < N; j++) { p[j] = 1.0 * ti; ti = ti * u; }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) a += sp.blend[i * N + j] * p[j];
+    coeff[i] = a;
+  }
+  start_idx = (int)s;
+  Quat res = sp.knots[s];
+  Mat3 Jh;
+#pragma unroll
+  for (int i = 0; i < 9; i++) Jh.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) {
+    const PairConsts &pc = sp.pair[s + i];
+    const double k = coeff[i + 1];
+    const double kd[3] = {pc.delta[0] * k, pc.delta[1] * k, pc.delta[2] * k};
+    // exp(k delta): the operations of so3_exp, with sin / cos of the half angle kept for the Jacobian below
+    const double theta_sq = kd[0] * kd[0] + kd[1] * kd[1] + kd[2] * kd[2];
+    double imag, real, sh = 0, ch = 1, theta = 0;
+    const bool tiny = theta_sq < kSophusEps * kSophusEps;
+    if (tiny) {
+      const double t4 = theta_sq * theta_sq;
+      imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * t4;
+      real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * t4;
+    } else {
+      theta = sqrt(theta_sq);
+      const double half = 0.5 * theta;
+      sh = sin(half); ch = cos(half);
+      imag = sh / theta;
+      real = ch;
+    }
+    if (WANT_J) {
+      // leftJacobianSO3(k delta) = I + a H + b H^2 with scalar a, b (fp32 consumers: one division each, and
+      // sin(n) = 2 sh ch, 1 - cos(n) = 2 sh^2 from the half-angle pair)
+      const Mat3 H = m3_hat(kd), H2 = m3_mul(H, H);
+      double a, b;
+      if (theta_sq > kSophusEps) {
+        a = 2.0 * sh * sh / theta_sq;
+        b = (theta - 2.0 * sh * ch) / (theta_sq * theta);
+      } else {
+        a = 0.5; b = 1.0 / 6.0;
+      }
+      Mat3 Jk;
+#pragma unroll
+      for (int c = 0; c < 9; c++) Jk.m[c] = ((c % 4 == 0) ? 1.0 : 0.0) + a * H.m[c] + b * H2.m[c];
+      Jblocks[i] = Jh;
+      Mat3 T = q_to_R(res), Ji, Rc;
+#pragma unroll
+      for (int c = 0; c < 9; c++) { T.m[c] = k * T.m[c]; Ji.m[c] = pc.Jinv[c]; Rc.m[c] = pc.Rc[c]; }
+      T = m3_mul(T, Jk);
+      T = m3_mul(T, Ji);
+      Jh = m3_mul(T, Rc);
+#pragma unroll
+      for (int c = 0; c < 9; c++) Jblocks[i].m[c] -= Jh.m[c];
+    }
+    res = q_mul_rcp(res, Quat{imag * kd[0], imag * kd[1], imag * kd[2], real});
+  }
+  if (WANT_J) Jblocks[N - 1] = Jh;
+  R = q_to_R(res);
 }
 
 // cumulative blending matrix of a uniform B-spline of order N (host only; tiny)

@@ -152,3 +152,20 @@ def test_config3_full_size(hip, oracle):
     tot = be.get_plane(_lib.PLANE_IL_OLD).sum(dtype=np.float64) + be.get_plane(_lib.PLANE_IL_NEW).sum(dtype=np.float64)
     tot_ref = ref.IL_old.sum(dtype=np.float64) + ref.IL_new.sum(dtype=np.float64)
     assert abs(tot - tot_ref) < 1e-5 * len(w.x)
+
+
+@pytest.mark.parametrize("order,K,nf,T", [(2, 16, 1, 0.75), (4, 16, 3, 0.65), (2, 17, 1, 0.8), (4, 24, 3, 1.05)])
+def test_both_pose_table_forms(hip, oracle, order, K, nf, T):
+    """K <= 16: the pose-table kernel takes log / J^-1 / R(knot^-1) of every knot pair from the host (once per
+    evaluation); more knots: the self-contained form.  Same values either way (so3_spline.h:218-274), checked through
+    the planes, the contrast and the gradient in both gradient modes, with large increments on every knot."""
+    w = _window(order, K, nf, T, N=30_000, seed=13)
+    be, ref = _pair(hip, oracle, w)
+    d = np.random.default_rng(K).normal(0, 0.05, w.P)
+    c_ref, g_ref = ref.eval(d)
+    for path in ("fast", "reference"):
+        be.set_fast_path() if path == "fast" else be.set_reference_path()
+        c, g = be.eval(d)
+        assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL, (path, K)
+        assert rel_scalar(be.eval(d, want_grad=False)[0], c_ref) < RTOL
+    np.testing.assert_allclose(be.get_plane(_lib.PLANE_IL_OLD), ref.IL_old, atol=2e-4)
