@@ -80,6 +80,130 @@ void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int count, int 
   hipLaunchKernelGGL(tile_lower_bound_kernel, dim3((count + 255) / 256), dim3(256), 0, s, keys_sorted, n, count, tile_start);
 }
 
+// ---- counting sort by destination tile (the default: up to kCountSortMaxBins keys)
+// The key space is tiny (300 tiles at 640x480, 2 x 1024 at 1024^2, 2 x 8192 at 4096x2048), so a comparison / radix
+// sort of (key, index) pairs is the wrong tool: rocprim picks a merge sort here (21 launches, 167 us per 1M pairs).
+// Three passes instead: (1) keys + histogram -- the warp kernel counts into an LDS histogram and adds its non-zero
+// bins to the global one; (2) one workgroup scans the bins into tile_start / cursor; (3) every workgroup counts its
+// slice again, reserves one run per non-empty bin with a single global atomic and writes its events there (rank
+// inside the run from an LDS atomic).  Order inside a tile is immaterial: the LDS votes are integer adds.
+constexpr int kCountSortMaxBins = 16400;
+constexpr int kBinBlock = 1024;
+extern __shared__ int hist_sh[];
+
+__device__ __forceinline__ void hist_zero(int nbins) {
+  for (int k = threadIdx.x; k < nbins; k += kBinBlock) hist_sh[k] = 0;
+  __syncthreads();
+}
+__device__ __forceinline__ void hist_flush(int nbins, int *ghist) {
+  __syncthreads();
+  for (int k = threadIdx.x; k < nbins; k += kBinBlock) {
+    const int v = hist_sh[k];
+    if (v) atomicAdd(&ghist[k], v);
+  }
+}
+__global__ __launch_bounds__(kBinBlock) void fe_bin_hist_kernel(FeSplatArgs a, int tiles_x, int ntiles, int per_block,
+                                                                uint32_t *keys, int *ghist) {
+  hist_zero(ntiles + 1);
+  const int beg = blockIdx.x * per_block, end = min(a.n, beg + per_block);
+  for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
+    const FeWarp w = fe_warp_event<false>(a, i);
+    const uint32_t key = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    keys[i] = key;
+    atomicAdd(&hist_sh[key], 1);
+  }
+  hist_flush(ntiles + 1, ghist);
+}
+__global__ __launch_bounds__(kBinBlock) void be_bin_hist_kernel(BeSplatArgs a, int tiles_x, int ntiles, int per_block,
+                                                                uint32_t *keys, int *ghist) {
+  hist_zero(2 * ntiles + 1);
+  const int beg = blockIdx.x * per_block, end = min(a.n, beg + per_block);
+  for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
+    const BeWarp w = be_warp_event<0>(a, i);
+    const uint32_t key = w.ok ? (uint32_t)(2 * ((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) + (w.is_old ? 0 : 1))
+                              : (uint32_t)(2 * ntiles);
+    keys[i] = key;
+    atomicAdd(&hist_sh[key], 1);
+  }
+  hist_flush(2 * ntiles + 1, ghist);
+}
+// one workgroup: tile_start[t] = number of events with key < t for t = 0 .. nbins (nbins + 1 entries), cursor = the same
+// offsets as the scatter's allocation pointers; the histogram is cleared for the next binning
+__global__ __launch_bounds__(kBinBlock) void scan_bins_kernel(int *ghist, int nbins, int *tile_start, int *cursor) {
+  __shared__ int wave_tot[kBinBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nbins + kBinBlock - 1) / kBinBlock;
+  const int k0 = tid * per, k1 = min(nbins, k0 + per);
+  int sum = 0;
+  for (int k = k0; k < k1; k++) sum += ghist[k];
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int off = incl - sum;
+  for (int w = 0; w < wave; w++) off += wave_tot[w];
+  for (int k = k0; k < k1; k++) {
+    const int v = ghist[k];
+    tile_start[k] = off;
+    cursor[k] = off;
+    ghist[k] = 0;
+    off += v;
+  }
+  if (tid == kBinBlock - 1) tile_start[nbins] = off;  // the last thread's running offset is the total (empty segments add 0)
+}
+__global__ __launch_bounds__(kBinBlock) void scatter_bins_kernel(const uint32_t *keys, const uint32_t *xy, int per_batch, int n,
+                                                                 int nbins, int per_block, int *cursor, uint32_t *sxy,
+                                                                 uint32_t *sbatch) {
+  hist_zero(nbins);
+  const int beg = blockIdx.x * per_block, end = min(n, beg + per_block);
+  for (int i = beg + threadIdx.x; i < end; i += kBinBlock) atomicAdd(&hist_sh[keys[i]], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nbins; k += kBinBlock) {  // one run per non-empty bin
+    const int v = hist_sh[k];
+    hist_sh[k] = v ? atomicAdd(&cursor[k], v) : 0;
+  }
+  __syncthreads();
+  for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
+    const int pos = atomicAdd(&hist_sh[keys[i]], 1);
+    sxy[pos] = xy[i];
+    sbatch[pos] = (uint32_t)i / (uint32_t)per_batch;
+  }
+}
+bool count_sort_ok(int nbins) { return nbins <= kCountSortMaxBins; }
+static void bin_grid(int n, int &blocks, int &per_block) {
+  blocks = (n + 4095) / 4096;
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  per_block = ((n + blocks - 1) / blocks + kBinBlock - 1) / kBinBlock * kBinBlock;
+}
+static void allow_big_lds() {  // 16400 bins x 4 B is just above the 64 KB default of dynamic LDS
+  static bool done = false;
+  if (done) return;
+  const int bytes = kCountSortMaxBins * (int)sizeof(int);
+  hipFuncSetAttribute((const void *)fe_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipFuncSetAttribute((const void *)be_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipFuncSetAttribute((const void *)scatter_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done = true;
+}
+// keys: n u32 scratch; hist: nbins ints, all zero on entry (left all zero); tile_start: nbins + 1 ints; cursor: nbins ints
+void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,
+                       int per_batch, int n, uint32_t *keys, int *hist, int *tile_start, int *cursor, uint32_t *sxy,
+                       uint32_t *sbatch, hipStream_t s) {
+  allow_big_lds();
+  const int nbins = (fe ? ntiles_img : 2 * ntiles_img) + 1;
+  int blocks, per_block;
+  bin_grid(n, blocks, per_block);
+  const size_t lds = (size_t)nbins * sizeof(int);
+  if (fe) hipLaunchKernelGGL(fe_bin_hist_kernel, dim3(blocks), dim3(kBinBlock), lds, s, *fe, tiles_x, ntiles_img, per_block, keys, hist);
+  else hipLaunchKernelGGL(be_bin_hist_kernel, dim3(blocks), dim3(kBinBlock), lds, s, *be, tiles_x, ntiles_img, per_block, keys, hist);
+  hipLaunchKernelGGL(scan_bins_kernel, dim3(1), dim3(kBinBlock), 0, s, hist, nbins, tile_start, cursor);
+  hipLaunchKernelGGL(scatter_bins_kernel, dim3(blocks), dim3(kBinBlock), lds, s, keys, xy, per_batch, n, nbins, per_block, cursor,
+                     sxy, sbatch);
+}
+
 // Chunk table on the device: tile t owns the sorted events [tile_start[t], tile_start[t+1]); it is cut into chunks of at
 // most M events.  One workgroup.  Order of the table = order the workgroups start in = longest-processing-time first:
 // all full chunks, then the remainder chunks by falling size (exact rank sort in LDS for up to kRankSortMax tiles,
@@ -132,26 +256,43 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
   }
   const int nfull_total = base_sh;
   if (T <= kRankSortMax) {
-    // exact: position of a remainder = number of remainders that are larger (ties: lower tile first)
-    for (int t = tid; t < T; t += 1024) {
-      int len = tile_start[t + 1] - tile_start[t];
-      if (len < 0) len = 0;
-      rem_sh[t] = len % M;
+    // exact: remainders by falling size (ties: lower tile first) -- bitonic sort in LDS of (remainder << 12 | 4095 - tile)
+    // (a rank sort, every thread against every tile, cost 78 us at 2049 tiles; this is 78 barrier-separated stages)
+    int n2 = 64;
+    while (n2 < T) n2 <<= 1;
+    uint32_t *key_sh = reinterpret_cast<uint32_t *>(rem_sh);
+    for (int t = tid; t < n2; t += 1024) {
+      uint32_t key = 0;
+      if (t < T) {
+        int len = tile_start[t + 1] - tile_start[t];
+        if (len < 0) len = 0;
+        const int rem = len % M;
+        if (rem) key = ((uint32_t)rem << 12) | (uint32_t)(4095 - t);
+      }
+      key_sh[t] = key;
     }
     __syncthreads();
-    int nrem = 0;
-    for (int t = tid; t < T; t += 1024) {
-      const int mine = rem_sh[t];
-      if (mine == 0) continue;
-      int rank = 0;
-      for (int u = 0; u < T; u++) {
-        const int r = rem_sh[u];
-        rank += (r > mine) || (r == mine && u < t);
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < n2; i += 1024) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const uint32_t x = key_sh[i], y = key_sh[ixj];
+            const bool desc = (i & k) == 0;
+            if (desc ? (x < y) : (x > y)) { key_sh[i] = y; key_sh[ixj] = x; }
+          }
+        }
+        __syncthreads();
       }
+    int nrem = 0;
+    for (int p = tid; p < n2; p += 1024) {
+      const uint32_t key = key_sh[p];
+      if (key == 0) continue;
+      const int t = 4095 - (int)(key & 4095u);
       const int beg = tile_start[t], len = tile_start[t + 1] - beg;
-      chunks[nfull_total + rank] = make_chunk(t, beg + (len / M) * M, beg + len);
+      chunks[nfull_total + p] = make_chunk(t, beg + (len / M) * M, beg + len);
+      nrem++;
     }
-    for (int t = tid; t < T; t += 1024) nrem += rem_sh[t] != 0;
     // block-wide sum of nrem
     int incl = nrem;
 #pragma unroll

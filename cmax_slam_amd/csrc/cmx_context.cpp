@@ -244,6 +244,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_sums);
   hipFree(c->d_keys); hipFree(c->d_keys_s); hipFree(c->d_idx); hipFree(c->d_idx_s); hipFree(c->d_sxy); hipFree(c->d_sbatch);
   hipFree(c->d_sort_temp);
+  hipFree(c->d_hist);
   hipFree(c->d_tile_start);
   hipFree(c->d_chunks);
   hipFree(c->d_fallback);

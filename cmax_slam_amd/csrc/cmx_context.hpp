@@ -125,6 +125,8 @@ struct cmx_ctx {
   bool bin_valid = false;
   uint32_t *d_keys = nullptr, *d_keys_s = nullptr, *d_idx = nullptr, *d_idx_s = nullptr, *d_sxy = nullptr, *d_sbatch = nullptr;
   size_t bin_cap = 0;
+  int *d_hist = nullptr;  // counting sort: [histogram (kept all-zero between binnings) | cursor]
+  size_t hist_cap = 0;
   void *d_sort_temp = nullptr;
   size_t sort_temp_cap = 0;
   int *d_tile_start = nullptr;

@@ -178,6 +178,11 @@ int sort_pairs_u32(void *temp, size_t *temp_bytes, const uint32_t *kin, uint32_t
 void launch_apply_perm(const uint32_t *xy, const uint32_t *idx_sorted, int per_batch, int n, uint32_t *sxy,
                        uint32_t *sbatch, hipStream_t s);
 void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int ntiles_plus2, int *tile_start, hipStream_t s);
+// counting sort by destination tile (cmx_binning.hip): the default whenever the key space fits an LDS histogram
+bool count_sort_ok(int nbins);
+void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,
+                       int per_batch, int n, uint32_t *keys, int *hist, int *tile_start, int *cursor, uint32_t *sxy,
+                       uint32_t *sbatch, hipStream_t s);
 // t0 / t1 (optional): events bracketing exactly the kernel(s) of the launch (hipExtLaunchKernelGGL start / stop events,
 // the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);

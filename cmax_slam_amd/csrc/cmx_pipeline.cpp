@@ -64,14 +64,21 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   const int planes_per_tile = fe ? 1 : 2;  // back end: key = 2*tile + (IL_new ? 1 : 0)
   const int ntiles = tiles_x * tiles_y * planes_per_tile;
   int rc;
+  const bool counting = count_sort_ok(ntiles + 1);
   if ((size_t)n > c->bin_cap || !c->d_keys) {
-    uint32_t **ptrs[6] = {&c->d_keys, &c->d_keys_s, &c->d_idx, &c->d_idx_s, &c->d_sxy, &c->d_sbatch};
-    for (auto p : ptrs) {
+    uint32_t **ptrs[6] = {&c->d_keys, &c->d_sxy, &c->d_sbatch, &c->d_keys_s, &c->d_idx, &c->d_idx_s};
+    for (int k = 0; k < 6; k++) {
+      uint32_t **p = ptrs[k];
       if (*p) HIP_TRY(c, hipFree(*p));
       *p = nullptr;
+      if (k >= 3 && counting) continue;  // the (key, index) pair buffers belong to the radix-sort fallback only
       HIP_TRY(c, hipMalloc((void **)p, (size_t)(n > 0 ? n : 1) * sizeof(uint32_t)));
     }
     c->bin_cap = (size_t)(n > 0 ? n : 1);
+  }
+  if (!counting && !c->d_keys_s) {  // a context that switched to a huge panorama after small ones
+    uint32_t **ptrs[3] = {&c->d_keys_s, &c->d_idx, &c->d_idx_s};
+    for (auto p : ptrs) HIP_TRY(c, hipMalloc((void **)p, c->bin_cap * sizeof(uint32_t)));
   }
   if (!c->d_fallback) {
     HIP_TRY(c, hipMalloc((void **)&c->d_fallback, sizeof(unsigned)));
@@ -89,23 +96,33 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   if (rc) return rc;
   if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
   if (n > 0) {
-    if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
-    else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
-    int end_bit = 1;
-    while ((1 << end_bit) <= ntiles) end_bit++;
-    size_t tb = 0;
-    if (sort_pairs_u32(nullptr, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
-      return fail(c, CMX_ERR_HIP, "rocprim radix sort (size query) failed");
-    if (tb > c->sort_temp_cap) {
-      if (c->d_sort_temp) HIP_TRY(c, hipFree(c->d_sort_temp));
-      c->d_sort_temp = nullptr;
-      HIP_TRY(c, hipMalloc(&c->d_sort_temp, tb));
-      c->sort_temp_cap = tb;
+    if (counting) {
+      // counting sort: keys + histogram, scan, scatter (cmx_binning.hip); tile_start comes out of the scan
+      const size_t nb_old = c->hist_cap;
+      rc = ensure(c, c->d_hist, c->hist_cap, (size_t)2 * (ntiles + 2));  // [histogram | cursor]
+      if (rc) return rc;
+      if (c->hist_cap != nb_old) HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, c->hist_cap * sizeof(int), c->stream));
+      launch_count_sort(fe, be, tiles_x, ntiles / planes_per_tile, c->d_xy, c->per_batch, n, c->d_keys, c->d_hist,
+                        c->d_tile_start, c->d_hist + (ntiles + 2), c->d_sxy, c->d_sbatch, c->stream);
+    } else {
+      if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
+      else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
+      int end_bit = 1;
+      while ((1 << end_bit) <= ntiles) end_bit++;
+      size_t tb = 0;
+      if (sort_pairs_u32(nullptr, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+        return fail(c, CMX_ERR_HIP, "rocprim radix sort (size query) failed");
+      if (tb > c->sort_temp_cap) {
+        if (c->d_sort_temp) HIP_TRY(c, hipFree(c->d_sort_temp));
+        c->d_sort_temp = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_sort_temp, tb));
+        c->sort_temp_cap = tb;
+      }
+      if (sort_pairs_u32(c->d_sort_temp, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
+        return fail(c, CMX_ERR_HIP, "rocprim radix sort failed");
+      launch_apply_perm(c->d_xy, c->d_idx_s, c->per_batch, n, c->d_sxy, c->d_sbatch, c->stream);
+      launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
     }
-    if (sort_pairs_u32(c->d_sort_temp, &tb, c->d_keys, c->d_keys_s, c->d_idx, c->d_idx_s, (unsigned)n, end_bit, c->stream) != 0)
-      return fail(c, CMX_ERR_HIP, "rocprim radix sort failed");
-    launch_apply_perm(c->d_xy, c->d_idx_s, c->per_batch, n, c->d_sxy, c->d_sbatch, c->stream);
-    launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
     // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
     launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->stream);
     HIP_TRY(c, hipGetLastError());
