@@ -104,3 +104,23 @@ def test_empty_window_and_empty_map(hip, oracle, w):
                   w.t_next_win_beg_ns)
     c, g = be.eval(np.zeros(w.P))
     assert c == 0.0 and np.all(g == 0.0)
+
+
+def test_panorama_beyond_the_counting_sort(hip, oracle):
+    """8192 x 4096: 2 x 32768 destination tiles, more keys than the counting sort's LDS histogram holds, so the tile
+    sort takes the radix-sort route; same answers as the oracle (cost) and as the splat that needs no sort (gradient)."""
+    w = synth.backend_window(20_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 8192, 4096, 2, 5, 1, 0.2, seed=72)
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be.set_fast_path()
+    be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE, None)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, w.batch, w.sample_rate, w.sigma, oracle.VARIANCE)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, None)
+    d = 0.01 * np.cos(np.arange(w.P))
+    c_ref, _ = ref.eval(d, want_grad=False)
+    c, g = be.eval(d)
+    assert be.stats()["rebins"] == 1
+    assert rel_scalar(c, c_ref) < RTOL
+    be.set_splat_mode(0)  # one global atomic per vote: no tile sort at all
+    c0, g0 = be.eval(d)
+    assert rel_scalar(c0, c_ref) < RTOL and rel_vec(g, g0) < RTOL
