@@ -32,3 +32,24 @@ def test_batch_range_partitions_whole_batches():
             assert a1 == b0 and a0 <= a1
         for a0, a1 in spans[:-1]:
             assert (a0 % B == 0 or a0 == n) and (a1 % B == 0 or a1 == n)
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu():
+    """bench.py's cpu_baseline object (the oracle timed on host cores; the all-cores figure nested beside it) is
+    pure CPU work: its keys and its bookkeeping are checked here on a small packet."""
+    import types
+
+    import bench
+
+    p = synth.frontend_packet(20_000, 120, 90, 100.0, 100.0, 59.5, 44.5, seed=3)
+    args = types.SimpleNamespace(workload="frontend", cpu_seconds=0.4)
+    out = bench.cpu_baseline(args, p, np.array([0.3, -0.5, 0.2]))
+    assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "events/s" and out["value"] > 0
+    assert "full fdf evaluations" in out["sample"]
+    ac = out["allcores"]
+    assert "error" not in ac, ac
+    assert 1 <= ac["cores"] <= ac["usable_cores"] == bench.usable_cores() and ac["value"] > 0
+    assert bench.alg_bytes_per_event("frontend", 0, "splat", True) == 60
+    assert bench.alg_bytes_per_event("frontend", 0, "splat", False) == 156
+    assert bench.alg_bytes_per_event("backend", 4, "splat", False) == 444
+    assert bench.alg_bytes_per_event("backend", 2, "splat", False) == 252
