@@ -254,11 +254,17 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     if (use_lds) {
       BinnedEvents b = binned(c);
       if (use_flags) { b.tflags = c->d_tflags; b.tflags_tiles_x = (c->Wp + kTileX - 1) / kTileX; }
+      if (c->deterministic) {
+        rc = ensure_fixed(c, 2 * np);
+        if (rc) return rc;
+        b.fixed = c->d_fixed;
+      }
       launch_be_splat_lds(a, b, c->stream, sp.t0(), sp.t1());
     } else {
       launch_be_splat(a, deriv, c->stream, sp.t0(), sp.t1());
     }
   }
+  if (use_lds && c->deterministic) launch_fixed_to_float(c->d_fixed, c->d_accum, 2 * np, c->stream);
   c->accum_flagged = use_flags;
   HIP_TRY(c, hipGetLastError());
   c->accum_count = (size_t)(2 + P) * np;

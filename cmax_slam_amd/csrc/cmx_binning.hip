@@ -379,8 +379,36 @@ __device__ __forceinline__ void vote4_global(float *img, int W, int xx, int yy, 
   atomic_add_f32(q + W + 1, dx * dy);
 }
 
+// deterministic mode (CMX_OPT_DETERMINISTIC): everything that reaches global memory is a 64-bit INTEGER add into a
+// fixed-point plane -- integer adds commute, so the planes (and everything computed from them) are the same bits on every
+// run, whatever order the workgroups, the tile sort or the atomics happened in.  fixed_to_float then hands the usual
+// fp32 planes to the image kernels and leaves the fixed-point plane all-zero for the next evaluation.
+__device__ __forceinline__ void vote4_global_fix(fix_t *img, int W, int xx, int yy, float dx, float dy) {
+  fix_t *q = img + (size_t)yy * W + xx;
+  atomicAdd(q, to_fix((1.f - dx) * (1.f - dy)));
+  atomicAdd(q + 1, to_fix(dx * (1.f - dy)));
+  atomicAdd(q + W, to_fix((1.f - dx) * dy));
+  atomicAdd(q + W + 1, to_fix(dx * dy));
+}
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(fix_t *fixed, float *planes, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const fix_t v = fixed[i];
+    if (v != 0ull) {
+      planes[i] = (float)((double)v * kFixInv);
+      fixed[i] = 0ull;
+    }
+  }
+}
+void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fixed, planes, n);
+}
+
 constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -> 12.6 us, 1 -> 13.3, 4 -> 14.1, 8 -> 15.2 per 1M events)
 
+template <bool FIXED>
 __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];
   if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
@@ -416,7 +444,8 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
           vote4_lds(win, lx, ly, w.dx, w.dy);
         } else {
-          vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
+          if (FIXED) vote4_global_fix(b.fixed, a.W, w.xx, w.yy, w.dx, w.dy);
+          else vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
           nfall++;
         }
       }
@@ -428,16 +457,26 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
     for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
       const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
       const fix_t v = win[ly * kBinStride + lx];
-      if (v != 0ull) atomic_add_f32(a.planes + (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx), (float)((double)v * kFixInv));
+      if (v != 0ull) {
+        const size_t at = (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx);
+        if (FIXED) atomicAdd(b.fixed + at, v);
+        else atomic_add_f32(a.planes + at, (float)((double)v * kFixInv));
+      }
     }
   }
 }
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
-  if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
-  else hipLaunchKernelGGL(fe_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  if (b.fixed) {
+    if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+    else hipLaunchKernelGGL(fe_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  } else {
+    if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+    else hipLaunchKernelGGL(fe_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  }
 }
 
+template <bool FIXED>
 __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];  // one plane per chunk: the sort key separates IL_old / IL_new events
   if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
@@ -477,7 +516,8 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {
           vote4_lds(win, lx, ly, w.dx, w.dy);
         } else {
-          vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
+          if (FIXED) vote4_global_fix(b.fixed + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
+          else vote4_global(a.planes + (w.is_old ? 0 : np), a.Wp, w.xx, w.yy, w.dx, w.dy);
           if (b.tflags) {  // the four corners can straddle up to four image tiles
             b.tflags[(w.yy / kTileY) * b.tflags_tiles_x + w.xx / kTileX] = 1;
             b.tflags[(w.yy / kTileY) * b.tflags_tiles_x + (w.xx + 1) / kTileX] = 1;
@@ -492,12 +532,14 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
   if (nfall) atomicAdd(b.fallback, nfall);
   if (has_win) {
     __syncthreads();
-    float *dst = a.planes + (c.plane ? np : 0);
+    const size_t plane_off = c.plane ? np : 0;
     for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
       const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
       const fix_t v = win[ly * kBinStride + lx];
       if (v != 0ull) {
-        atomic_add_f32(dst + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx), (float)((double)v * kFixInv));
+        const size_t at = plane_off + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx);
+        if (FIXED) atomicAdd(b.fixed + at, v);
+        else atomic_add_f32(a.planes + at, (float)((double)v * kFixInv));
         if (b.tflags) b.tflags[((c.wy0 + ly) / kTileY) * b.tflags_tiles_x + (c.wx0 + lx) / kTileX] = 1;
       }
     }
@@ -505,8 +547,13 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
 }
 void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
-  if (t0 || t1) hipExtLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
-  else hipLaunchKernelGGL(be_splat_lds_kernel, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  if (b.fixed) {
+    if (t0 || t1) hipExtLaunchKernelGGL(be_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+    else hipLaunchKernelGGL(be_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  } else {
+    if (t0 || t1) hipExtLaunchKernelGGL(be_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+    else hipLaunchKernelGGL(be_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+  }
 }
 
 }  // namespace cmx

@@ -245,6 +245,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_keys); hipFree(c->d_keys_s); hipFree(c->d_idx); hipFree(c->d_idx_s); hipFree(c->d_sxy); hipFree(c->d_sbatch);
   hipFree(c->d_sort_temp);
   hipFree(c->d_hist);
+  hipFree(c->d_fixed);
   hipFree(c->d_tile_start);
   hipFree(c->d_chunks);
   hipFree(c->d_fallback);
@@ -276,6 +277,10 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_REUSE_IMAGE:
       c->reuse_image = value != 0;
+      return CMX_OK;
+    case CMX_OPT_DETERMINISTIC:
+      c->deterministic = value != 0;
+      c->x_valid = false;  // a resident image of the other mode is not reused
       return CMX_OK;
     case CMX_OPT_SPIN_WAIT:
       c->ticket_wait = value != 0;

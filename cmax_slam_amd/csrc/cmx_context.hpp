@@ -125,6 +125,9 @@ struct cmx_ctx {
   bool bin_valid = false;
   uint32_t *d_keys = nullptr, *d_keys_s = nullptr, *d_idx = nullptr, *d_idx_s = nullptr, *d_sxy = nullptr, *d_sbatch = nullptr;
   size_t bin_cap = 0;
+  bool deterministic = false;            // CMX_OPT_DETERMINISTIC
+  unsigned long long *d_fixed = nullptr;  // its fixed-point vote planes (all-zero between evaluations)
+  size_t fixed_cap = 0;
   int *d_hist = nullptr;  // counting sort: [histogram (kept all-zero between binnings) | cursor]
   size_t hist_cap = 0;
   void *d_sort_temp = nullptr;
@@ -252,6 +255,7 @@ int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast);
 int ensure_accum(cmx_ctx *c, size_t need);
 int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be);
 BinnedEvents binned(const cmx_ctx *c);
+int ensure_fixed(cmx_ctx *c, size_t n);  // deterministic mode: n zeroed fixed-point accumulators
 FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]);
 BeSplatArgs be_args(const cmx_ctx *c);
 bool adjoint_ok(const cmx_ctx *c);

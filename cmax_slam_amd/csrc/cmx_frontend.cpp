@@ -109,9 +109,19 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
     Span sp(c, CMX_T_SPLAT, /*exact=*/true);
     c->last_used_lds = use_lds;
     if (use_lds) c->fallback_pending = true;
-    if (use_lds) launch_fe_splat_lds(a, binned(c), c->stream, sp.t0(), sp.t1());
-    else launch_fe_splat(a, nplanes > 1, c->stream, sp.t0(), sp.t1());
+    if (use_lds) {
+      BinnedEvents b = binned(c);
+      if (c->deterministic) {
+        rc = ensure_fixed(c, np);
+        if (rc) return rc;
+        b.fixed = c->d_fixed;
+      }
+      launch_fe_splat_lds(a, b, c->stream, sp.t0(), sp.t1());
+    } else {
+      launch_fe_splat(a, nplanes > 1, c->stream, sp.t0(), sp.t1());
+    }
   }
+  if (use_lds && c->deterministic) launch_fixed_to_float(c->d_fixed, c->d_accum, np, c->stream);
   HIP_TRY(c, hipGetLastError());
   c->accum_count = nplanes * np;
   c->last_P = nplanes - 1;

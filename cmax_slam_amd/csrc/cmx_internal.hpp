@@ -116,6 +116,7 @@ struct BeGatherArgs {
   double *vparts;          // [nb][parts_per_batch][6]: per-batch partial sums of V (3) and of the border vector U (3)
   int parts_per_batch;     // wave slices a batch can touch
   int slice_shift;         // log2 of the events one wave pass covers: 6 (one event per lane) or 8 (four per lane)
+  int deterministic;       // per-parameter block sums in a fixed order instead of LDS fp64 atomics
 };
 
 struct FinalizeArgs {
@@ -168,6 +169,7 @@ struct BinnedEvents {
   unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
   unsigned char *tflags;   // optional: image-tile occupancy map marked by every vote that reaches global memory
   int tflags_tiles_x;
+  unsigned long long *fixed;  // deterministic mode: 2^-30 fixed-point planes every global vote is added to (else nullptr)
 };
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
@@ -187,6 +189,8 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 // the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// deterministic mode: fixed-point planes -> fp32 planes (non-zero entries only; `planes` is all-zero before), fixed := 0
+void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, hipStream_t s);
 
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,

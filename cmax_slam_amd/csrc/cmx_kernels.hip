@@ -1029,32 +1029,61 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
 
 // Pass 2: one thread per batch: sum its parts, apply the batch's 3x3N spline Jacobian (events of one batch share it),
 // accumulate S1 / S2 per parameter in LDS, one partial row per workgroup ([column][block]).
-template <int N>
+template <int N, bool DET>
 __global__ __launch_bounds__(256) void be_gather_batch_kernel(BeGatherArgs g, int nb) {
   __shared__ double shG[kMaxGradLDS], shG2[kMaxGradLDS];
+  __shared__ double red[8];
   const BeSplatArgs &a = g.ev;
   const int tid = threadIdx.x;
   for (int j = tid; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
   __syncthreads();
-  for (int b = blockIdx.x * 256 + tid; b < nb; b += gridDim.x * 256) {
-    const int first = b * a.per_batch, last = min(a.n, first + a.per_batch) - 1;
-    const int nparts = (last >> g.slice_shift) - (first >> g.slice_shift) + 1;
+  for (int b0 = blockIdx.x * 256; b0 < nb; b0 += gridDim.x * 256) {  // uniform trip count: the DET form has barriers
+    const int b = b0 + tid;
     double V[6] = {0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < nparts; p++) {
-      const double *src = g.vparts + ((size_t)b * g.parts_per_batch + p) * 6;
+    int jbase = -(1 << 28);
+    double c1[3 * N], c2[3 * N];
 #pragma unroll
-      for (int q = 0; q < 6; q++) V[q] += src[q];
-    }
-    const PoseEntry &pe = a.poses[b];
-    const int jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
-    const bool has_u = V[3] != 0.0 || V[4] != 0.0 || V[5] != 0.0;
+    for (int c = 0; c < 3 * N; c++) { c1[c] = 0; c2[c] = 0; }
+    bool has_u = false;
+    if (b < nb) {
+      const int first = b * a.per_batch, last = min(a.n, first + a.per_batch) - 1;
+      const int nparts = (last >> g.slice_shift) - (first >> g.slice_shift) + 1;
+      for (int p = 0; p < nparts; p++) {
+        const double *src = g.vparts + ((size_t)b * g.parts_per_batch + p) * 6;
 #pragma unroll
-    for (int c = 0; c < 3 * N; c++) {
-      const int j = jbase + c;
-      if (j >= 0) {
+        for (int q = 0; q < 6; q++) V[q] += src[q];
+      }
+      const PoseEntry &pe = a.poses[b];
+      jbase = 3 * (pe.idx_cp_beg - a.num_fixed);
+      has_u = V[3] != 0.0 || V[4] != 0.0 || V[5] != 0.0;
+#pragma unroll
+      for (int c = 0; c < 3 * N; c++) {
         const double j0 = (double)pe.Jcp[c], j1 = (double)pe.Jcp[3 * N + c], j2 = (double)pe.Jcp[6 * N + c];
-        atomicAdd(&shG[j], V[0] * j0 + V[1] * j1 + V[2] * j2);
-        if (has_u) atomicAdd(&shG2[j], V[3] * j0 + V[4] * j1 + V[5] * j2);
+        c1[c] = V[0] * j0 + V[1] * j1 + V[2] * j2;
+        if (has_u) c2[c] = V[3] * j0 + V[4] * j1 + V[5] * j2;
+      }
+    }
+    if (!DET) {
+#pragma unroll
+      for (int c = 0; c < 3 * N; c++) {
+        const int j = jbase + c;
+        if (j >= 0) {
+          atomicAdd(&shG[j], c1[c]);
+          if (has_u) atomicAdd(&shG2[j], c2[c]);
+        }
+      }
+    } else {
+      // deterministic mode: one block-wide sum per parameter, lanes / waves / batches always in the same order
+      const bool any_u = __syncthreads_or(has_u ? 1 : 0) != 0;
+      for (int j = 0; j < g.P; j++) {
+        double v1 = 0, v2 = 0;
+#pragma unroll
+        for (int c = 0; c < 3 * N; c++)
+          if (jbase + c == j) { v1 = c1[c]; v2 = c2[c]; }
+        double t1, t2 = 0;
+        if (any_u) block_sum2(v1, v2, red, 4, t1, t2);
+        else t1 = block_sum(v1, red);
+        if (tid == 0) { shG[j] += t1; shG2[j] += t2; }
       }
     }
   }
@@ -1075,8 +1104,13 @@ int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0
   if (a.slice_shift == 8) CMX_LAUNCH(be_gather4_kernel, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, t0, t1, a);
   else CMX_LAUNCH(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, t0, t1, a);
   const int blocks = be_batch_blocks(nb);
-  if (a.ev.order == 2) hipLaunchKernelGGL(be_gather_batch_kernel<2>, dim3(blocks), dim3(256), 0, s, a, nb);
-  else hipLaunchKernelGGL(be_gather_batch_kernel<4>, dim3(blocks), dim3(256), 0, s, a, nb);
+  if (a.deterministic) {
+    if (a.ev.order == 2) hipLaunchKernelGGL((be_gather_batch_kernel<2, true>), dim3(blocks), dim3(256), 0, s, a, nb);
+    else hipLaunchKernelGGL((be_gather_batch_kernel<4, true>), dim3(blocks), dim3(256), 0, s, a, nb);
+  } else {
+    if (a.ev.order == 2) hipLaunchKernelGGL((be_gather_batch_kernel<2, false>), dim3(blocks), dim3(256), 0, s, a, nb);
+    else hipLaunchKernelGGL((be_gather_batch_kernel<4, false>), dim3(blocks), dim3(256), 0, s, a, nb);
+  }
   return blocks;
 }
 

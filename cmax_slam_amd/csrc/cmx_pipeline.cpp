@@ -139,6 +139,14 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   return CMX_OK;
 }
 
+int ensure_fixed(cmx_ctx *c, size_t n) {
+  if (n <= c->fixed_cap && c->d_fixed) return CMX_OK;
+  int rc = ensure(c, c->d_fixed, c->fixed_cap, n);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_fixed, 0, c->fixed_cap * sizeof(unsigned long long), c->stream));
+  return CMX_OK;
+}
+
 BinnedEvents binned(const cmx_ctx *c) {
   BinnedEvents b{};
   b.sxy = c->d_sxy;
@@ -220,6 +228,7 @@ int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip) {
 // large panoramas: compact the tiles that need work (call once a.partials / flags / zero_ptr are final)
 int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
   if (!a.flags_cur || a.nblk <= kTileListMin) return CMX_OK;
+  if (c->deterministic) return CMX_OK;  // the list is compacted through atomics: its order, hence the order of the moment rows, varies
   if ((size_t)a.nblk > c->tile_list_cap || !c->d_tile_list) {
     if (c->d_tile_list) HIP_TRY(c, hipFree(c->d_tile_list));
     if (c->d_tile_count) HIP_TRY(c, hipFree(c->d_tile_count));
@@ -435,7 +444,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       g.itilde = c->d_itilde;
       g.gpartials = c->d_gpartials;
       g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
-      if (c->splat_mode == 1 && c->bin_valid) {  // tile order: the same sorted arrays the LDS splat consumes
+      if (c->splat_mode == 1 && c->bin_valid && !c->deterministic) {  // tile order: the sorted arrays the LDS splat consumes
+        // (deterministic mode: time order -- the order inside a tile depends on the scatter's atomics)
         g.sxy = c->d_sxy;
         g.sbatch = c->d_sbatch;
       }
@@ -451,6 +461,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       g.vparts = c->d_vparts;
       g.parts_per_batch = parts_per_batch;
       g.slice_shift = slice_shift;
+      g.deterministic = c->deterministic ? 1 : 0;
       if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }

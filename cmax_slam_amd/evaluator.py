@@ -94,6 +94,11 @@ class _Evaluator:
         self.set_grad_mode(_lib.GRAD_PLANES)
         self.set_splat_mode(0)
 
+    def set_deterministic(self, on=True):
+        """Bitwise run-to-run reproducible evaluations (CMX_OPT_DETERMINISTIC): integer vote accumulation in global
+        memory, fixed summation orders everywhere; ~10-20 % slower.  Applies to the production path."""
+        self.set_option(_lib.OPT_DETERMINISTIC, 1 if on else 0)
+
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
         self._ck(self._L.cmx_set_stream(self._ctx, C.c_void_p(hip_stream_handle or None)))

@@ -67,6 +67,13 @@ enum {
   CMX_OPT_REUSE_IMAGE = 3, /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
                              the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
                              df at every accepted point; the reference recomputes everything, :58-70) */
+  CMX_OPT_DETERMINISTIC = 5, /* 1: bitwise run-to-run reproducible results (default 0).  With the LDS-privatised splat
+                             (CMX_OPT_SPLAT_MODE 1, adjoint gradient or cost-only) every vote that reaches global memory
+                             becomes a 64-bit integer add into a 2^-30 fixed-point plane -- integer adds commute -- and
+                             one extra pass converts it to the fp32 plane; the front-end gather then walks the events in
+                             time order and large panoramas do not use the compacted tile list, so that every
+                             floating-point sum has a fixed order.  Costs ~10-20 % per evaluation.  The reference-shaped
+                             flow (derivative planes, fp32 atomics) stays order-dependent */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
                              than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
