@@ -56,6 +56,7 @@ class Params:
     backend_min_ev_rate = 10000
     max_update_times = 200
     Y_angle = 0.0
+    deterministic = False           # CMX_OPT_DETERMINISTIC on both contexts: the same bits on every run
 
 
 def run_pipeline(stream, prm=None, use_event_store=True, log=None):
@@ -67,6 +68,9 @@ def run_pipeline(stream, prm=None, use_event_store=True, log=None):
     be = evaluator.BackendEvaluator(stream.W, stream.H, stream.lut, 2 * prm.pano_height, prm.pano_height)
     fe.set_fast_path()
     be.set_fast_path()
+    if prm.deterministic:
+        fe.set_deterministic(True)
+        be.set_deterministic(True)
     store = None
     if use_event_store:
         store = evaluator.EventStore(stream.W, stream.H, n_total)
@@ -256,11 +260,13 @@ def main():
     ap.add_argument("--rate", type=float, default=2e6)
     ap.add_argument("--degree", type=int, default=1, choices=(1, 3))
     ap.add_argument("--host-events", action="store_true", help="re-upload events per packet/window (no EventStore)")
+    ap.add_argument("--deterministic", action="store_true", help="bitwise reproducible evaluations (CMX_OPT_DETERMINISTIC)")
     a = ap.parse_args()
     stream = synth.event_stream(a.rate, a.seconds, 240, 180, 200.0, 200.0, 119.5, 89.5, omega_mean=(0.2, 1.8, 0.3),
                                 omega_amp=(1.0, 0.8, 1.0))
     prm = Params()
     prm.spline_degree = a.degree
+    prm.deterministic = a.deterministic
     t0 = time.perf_counter()
     res = run_pipeline(stream, prm, use_event_store=not a.host_events, log=print)
     wall = time.perf_counter() - t0

@@ -63,3 +63,21 @@ def test_event_store_and_host_upload_agree(hip, stream):
     ma, mb = rp.evaluate_against_truth(stream, a), rp.evaluate_against_truth(stream, b)
     for m in (ma, mb):
         assert m["omega_rmse_steady"] < 0.2 and m["ba_err_deg_rms"] < 1.0, m
+
+
+def test_deterministic_pipeline_repeats_bit_for_bit(hip, stream):
+    """With CMX_OPT_DETERMINISTIC on both contexts the whole chain -- 78 packet solves, the control-pose fits, the window
+    solves on the resident map -- returns the same bits on every run, and also when the packets are uploaded from the
+    host instead of being cut from the device-resident store (same events, same arithmetic)."""
+    import rotation_pipeline as rp
+    prm = rp.Params()
+    prm.deterministic = True
+    a = rp.run_pipeline(stream, prm, use_event_store=True)
+    b = rp.run_pipeline(stream, prm, use_event_store=True)
+    c = rp.run_pipeline(stream, prm, use_event_store=False)
+    for other in (b, c):
+        np.testing.assert_array_equal(a["ang_vel"], other["ang_vel"])
+        np.testing.assert_array_equal(a["IG"], other["IG"])
+        assert [r["final_cost"] for r in a["reports"]] == [r["final_cost"] for r in other["reports"]]
+    m = rp.evaluate_against_truth(stream, a)
+    assert m["omega_rmse_steady"] < 0.2 and m["ba_err_deg_rms"] < 1.0, m
