@@ -128,7 +128,7 @@ struct cmx_ctx {
   bool deterministic = false;            // CMX_OPT_DETERMINISTIC
   unsigned long long *d_fixed = nullptr;  // its fixed-point vote planes (all-zero between evaluations)
   size_t fixed_cap = 0;
-  int *d_hist = nullptr;  // counting sort: [histogram (kept all-zero between binnings) | cursor]
+  int *d_hist = nullptr;  // counting sort scratch: [bin totals | slices x bins prefix table]
   size_t hist_cap = 0;
   void *d_sort_temp = nullptr;
   size_t sort_temp_cap = 0;

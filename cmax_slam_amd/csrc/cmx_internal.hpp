@@ -182,9 +182,10 @@ void launch_apply_perm(const uint32_t *xy, const uint32_t *idx_sorted, int per_b
 void launch_tile_lower_bound(const uint32_t *keys_sorted, int n, int ntiles_plus2, int *tile_start, hipStream_t s);
 // counting sort by destination tile (cmx_binning.hip): the default whenever the key space fits an LDS histogram
 bool count_sort_ok(int nbins);
+size_t count_sort_scratch_ints(int n, int nbins);
 void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,
-                       int per_batch, int n, uint32_t *keys, int *hist, int *tile_start, int *cursor, uint32_t *sxy,
-                       uint32_t *sbatch, hipStream_t s);
+                       int per_batch, int n, uint32_t *keys, int *scratch, int *tile_start, uint32_t *sxy, uint32_t *sbatch,
+                       hipStream_t s);
 // t0 / t1 (optional): events bracketing exactly the kernel(s) of the launch (hipExtLaunchKernelGGL start / stop events,
 // the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);

@@ -97,13 +97,11 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
   if (n > 0) {
     if (counting) {
-      // counting sort: keys + histogram, scan, scatter (cmx_binning.hip); tile_start comes out of the scan
-      const size_t nb_old = c->hist_cap;
-      rc = ensure(c, c->d_hist, c->hist_cap, (size_t)2 * (ntiles + 2));  // [histogram | cursor]
+      // counting sort: keys + per-slice histograms, column prefixes, bin scan, scatter (cmx_binning.hip)
+      rc = ensure(c, c->d_hist, c->hist_cap, count_sort_scratch_ints(n, ntiles + 1));
       if (rc) return rc;
-      if (c->hist_cap != nb_old) HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, c->hist_cap * sizeof(int), c->stream));
       launch_count_sort(fe, be, tiles_x, ntiles / planes_per_tile, c->d_xy, c->per_batch, n, c->d_keys, c->d_hist,
-                        c->d_tile_start, c->d_hist + (ntiles + 2), c->d_sxy, c->d_sbatch, c->stream);
+                        c->d_tile_start, c->d_sxy, c->d_sbatch, c->stream);
     } else {
       if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
       else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
