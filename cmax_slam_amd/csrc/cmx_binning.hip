@@ -236,13 +236,22 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 // falling size classes beyond that) -- with an unsorted tail the back-end splat ran 68 us instead of 52.  Entry
 // `ntiles` is the sentinel tile of events whose vote is not accepted under the binning parameters: no LDS window.
 constexpr int kRankSortMax = 4096;
-__global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x,
+__global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start_g, int ntiles, int planes_per_tile, int tiles_x,
                                                             int margin, int M, Chunk *chunks, int *count) {
   __shared__ int wave_tot[16];
   __shared__ int base_sh;
   __shared__ int rem_sh[kRankSortMax];
+  __shared__ int ts_sh[kRankSortMax + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = ntiles + 1;  // tiles including the sentinel
+  // one workgroup, many dependent reads of the offsets: keep them in LDS when they fit (a global read here is a ~1 us
+  // round trip to another XCD's L2 with nothing to overlap it)
+  const int *tile_start = tile_start_g;
+  if (T + 1 <= kRankSortMax + 2) {
+    for (int t = tid; t <= T; t += 1024) ts_sh[t] = tile_start_g[t];
+    __syncthreads();
+    tile_start = ts_sh;
+  }
   auto make_chunk = [&](int t, int beg, int end) {
     const bool sentinel = (t == ntiles);
     const int tile = t / planes_per_tile, plane = t % planes_per_tile;
@@ -284,19 +293,22 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
   if (T <= kRankSortMax) {
     // exact: remainders by falling size (ties: lower tile first) -- bitonic sort in LDS of (remainder << 12 | 4095 - tile)
     // (a rank sort, every thread against every tile, cost 78 us at 2049 tiles; this is 78 barrier-separated stages)
-    int n2 = 64;
-    while (n2 < T) n2 <<= 1;
+    // only tiles with a remainder take part: compact them first (order irrelevant, they are sorted next)
     uint32_t *key_sh = reinterpret_cast<uint32_t *>(rem_sh);
-    for (int t = tid; t < n2; t += 1024) {
-      uint32_t key = 0;
-      if (t < T) {
-        int len = tile_start[t + 1] - tile_start[t];
-        if (len < 0) len = 0;
-        const int rem = len % M;
-        if (rem) key = ((uint32_t)rem << 12) | (uint32_t)(4095 - t);
-      }
-      key_sh[t] = key;
+    __shared__ int nnz_sh;
+    if (tid == 0) nnz_sh = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+      int len = tile_start[t + 1] - tile_start[t];
+      if (len < 0) len = 0;
+      const int rem = len % M;
+      if (rem) key_sh[atomicAdd(&nnz_sh, 1)] = ((uint32_t)rem << 12) | (uint32_t)(4095 - t);
     }
+    __syncthreads();
+    const int nnz = nnz_sh;
+    int n2 = 64;
+    while (n2 < nnz) n2 <<= 1;
+    for (int t = nnz + tid; t < n2; t += 1024) key_sh[t] = 0u;
     __syncthreads();
     for (int k = 2; k <= n2; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
