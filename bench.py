@@ -197,8 +197,11 @@ def main():
         ev_per_launch = end - beg
         # dominant per-event kernel = the longer of splat / gather (image passes are per-pixel, listed in kernel_ms)
         bpe = alg_bytes_per_event(args.workload, order, dom, adjoint)
-        avg_ms = tim[dom][0] / max(tim[dom][1], 1)  # measured live over the timed region
-        kernel_ms[dom] = avg_ms
+        if tim[dom][1] > 0:
+            avg_ms = tim[dom][0] / tim[dom][1]  # measured live over the timed region
+            kernel_ms[dom] = avg_ms
+        else:  # fewer timed steps than the sampling period: the calibration steps' average stands in
+            avg_ms = kernel_ms[dom]
         achieved = ev_per_launch * bpe / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
