@@ -515,7 +515,7 @@ void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_
 }
 
 template <bool FIXED>
-__global__ __launch_bounds__(256, 4) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
+__global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];  // one plane per chunk: the sort key separates IL_old / IL_new events
   if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
   const Chunk c = b.chunks[blockIdx.x];

@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
 // The same pass with FOUR consecutive events per lane (per_batch % 4 == 0, so a lane's events share one batch): one
 // 16-byte event load and one rotation-table read per lane, the four warps are independent instruction streams, and
 // the segmented wave reduction -- a third of the one-event form's instructions -- is paid once per 256 events.
-__global__ __launch_bounds__(256, 4) void be_gather4_kernel(BeGatherArgs g) {
+__global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
   const BeSplatArgs &a = g.ev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
