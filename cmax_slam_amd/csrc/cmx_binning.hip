@@ -178,17 +178,29 @@ __global__ __launch_bounds__(kBinBlock) void scan_bins_kernel(const int *total, 
   }
   if (tid == kBinBlock - 1) tile_start[nbins] = off;  // the last thread's running offset is the total (empty segments add 0)
 }
+// sb / sdt (front end, optional): the bearing and the batch dt of every event are gathered HERE, once per packet, and
+// stored in sorted order: the per-evaluation kernels then stream them (coalesced) instead of gathering from the
+// bearing table and the dt table with 64 different addresses per wave -- on gfx950 such a divergent load costs a
+// kernel ~3 us per 1M events whatever the cache hit rate (the texture-address path handles one lane's line per clock)
 __global__ __launch_bounds__(kBinBlock) void scatter_bins_kernel(const uint32_t *keys, const uint32_t *xy, int per_batch, int n,
                                                                  int nbins, int per_block, const int *table,
-                                                                 const int *tile_start, uint32_t *sxy, uint32_t *sbatch) {
+                                                                 const int *tile_start, uint32_t *sxy, uint32_t *sbatch,
+                                                                 const double *lut2, int W, const double *batch_dt, double *sb,
+                                                                 double *sdt) {
   const int *row = table + (size_t)blockIdx.x * nbins;
   for (int k = threadIdx.x; k < nbins; k += kBinBlock) hist_sh[k] = tile_start[k] + row[k];  // where this slice's run starts
   __syncthreads();
   const int beg = blockIdx.x * per_block, end = min(n, beg + per_block);
   for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
     const int pos = atomicAdd(&hist_sh[keys[i]], 1);
-    sxy[pos] = xy[i];
-    sbatch[pos] = (uint32_t)i / (uint32_t)per_batch;
+    const uint32_t e = xy[i], bi = (uint32_t)i / (uint32_t)per_batch;
+    sxy[pos] = e;
+    sbatch[pos] = bi;
+    if (sb) {
+      const double2 v = *reinterpret_cast<const double2 *>(lut2 + 2 * ((size_t)((e >> 16) & 0x7fff) * W + (e & 0xffff)));
+      *reinterpret_cast<double2 *>(sb + 2 * (size_t)pos) = v;
+      sdt[pos] = batch_dt[bi];
+    }
   }
 }
 bool count_sort_ok(int nbins) { return nbins <= kCountSortMaxBins; }
@@ -215,7 +227,7 @@ static void allow_big_lds() {  // 16400 bins x 4 B is just above the 64 KB defau
 // keys: n u32 scratch; scratch: count_sort_scratch_ints(n, nbins) ints (contents irrelevant); tile_start: nbins + 1 ints
 void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,
                        int per_batch, int n, uint32_t *keys, int *scratch, int *tile_start, uint32_t *sxy, uint32_t *sbatch,
-                       hipStream_t s) {
+                       double *sb, double *sdt, hipStream_t s) {
   allow_big_lds();
   const int nbins = (fe ? ntiles_img : 2 * ntiles_img) + 1;
   int blocks, per_block;
@@ -226,8 +238,10 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
   else hipLaunchKernelGGL(be_bin_hist_kernel, dim3(blocks), dim3(kBinBlock), lds, s, *be, tiles_x, ntiles_img, per_block, keys, table);
   hipLaunchKernelGGL(column_scan_kernel, dim3((nbins + 255) / 256), dim3(256), 0, s, table, nbins, blocks, total);
   hipLaunchKernelGGL(scan_bins_kernel, dim3(1), dim3(kBinBlock), 0, s, total, nbins, tile_start);
+  const bool streams = fe && sb && sdt && fe->lut2;
   hipLaunchKernelGGL(scatter_bins_kernel, dim3(blocks), dim3(kBinBlock), lds, s, keys, xy, per_batch, n, nbins, per_block, table,
-                     tile_start, sxy, sbatch);
+                     tile_start, sxy, sbatch, streams ? fe->lut2 : nullptr, fe ? fe->W : 0, fe ? fe->batch_dt : nullptr,
+                     streams ? sb : nullptr, streams ? sdt : nullptr);
 }
 
 // Chunk table on the device: tile t owns the sorted events [tile_start[t], tile_start[t+1]); it is cut into chunks of at
@@ -446,7 +460,7 @@ void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, h
 
 constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -> 12.6 us, 1 -> 13.3, 4 -> 14.1, 8 -> 15.2 per 1M events)
 
-template <bool FIXED>
+template <bool FIXED, bool STREAM>
 __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];
   if ((int)blockIdx.x >= *b.nchunks_dev) return;  // the launch is sized by an upper bound of the table's length
@@ -459,20 +473,32 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   }
   unsigned nfall = 0;
   for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * kUnroll) {
-    uint32_t e[kUnroll], bi[kUnroll];
     bool act[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      const int j = j0 + u * 256;
-      act[u] = j < c.end;
-      e[u] = act[u] ? b.sxy[j] : 0u;
-      bi[u] = act[u] ? b.sbatch[j] : 0u;
-    }
     double px[kUnroll], py[kUnroll], pz[kUnroll], dt[kUnroll];
+    if (STREAM) {  // bearing and dt of every sorted event stream in (coalesced): no table gathers in this kernel
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
-      dt[u] = a.batch_dt[bi[u]];
+      for (int u = 0; u < kUnroll; u++) {
+        const int j = j0 + u * 256;
+        act[u] = j < c.end;
+        const int jj = act[u] ? j : c.beg;
+        const double2 v = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)jj);
+        px[u] = v.x; py[u] = v.y; pz[u] = 1.0;
+        dt[u] = b.sdt[jj];
+      }
+    } else {
+      uint32_t e[kUnroll], bi[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        const int j = j0 + u * 256;
+        act[u] = j < c.end;
+        e[u] = act[u] ? b.sxy[j] : 0u;
+        bi[u] = act[u] ? b.sbatch[j] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
+        dt[u] = a.batch_dt[bi[u]];
+      }
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
@@ -503,14 +529,20 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
     }
   }
 }
+template <bool FIXED, bool STREAM>
+static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
+  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(256), 0, s, a, b);
+}
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
+  const bool stream = b.sb && b.sdt;
   if (b.fixed) {
-    if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
-    else hipLaunchKernelGGL(fe_splat_lds_kernel<true>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+    if (stream) launch_fe_splat_lds_t<true, true>(a, b, s, t0, t1);
+    else launch_fe_splat_lds_t<true, false>(a, b, s, t0, t1);
   } else {
-    if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
-    else hipLaunchKernelGGL(fe_splat_lds_kernel<false>, dim3(b.nchunks), dim3(256), 0, s, a, b);
+    if (stream) launch_fe_splat_lds_t<false, true>(a, b, s, t0, t1);
+    else launch_fe_splat_lds_t<false, false>(a, b, s, t0, t1);
   }
 }
 

@@ -245,6 +245,8 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_keys); hipFree(c->d_keys_s); hipFree(c->d_idx); hipFree(c->d_idx_s); hipFree(c->d_sxy); hipFree(c->d_sbatch);
   hipFree(c->d_sort_temp);
   hipFree(c->d_hist);
+  hipFree(c->d_sb);
+  hipFree(c->d_sdt);
   hipFree(c->d_fixed);
   hipFree(c->d_tile_start);
   hipFree(c->d_chunks);

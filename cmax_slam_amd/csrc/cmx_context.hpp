@@ -128,6 +128,9 @@ struct cmx_ctx {
   bool deterministic = false;            // CMX_OPT_DETERMINISTIC
   unsigned long long *d_fixed = nullptr;  // its fixed-point vote planes (all-zero between evaluations)
   size_t fixed_cap = 0;
+  double *d_sb = nullptr, *d_sdt = nullptr;  // front end: bearing (x, y) and dt of every tile-sorted event
+  size_t sb_cap = 0, sdt_cap = 0;
+  bool streams_valid = false;
   int *d_hist = nullptr;  // counting sort scratch: [bin totals | slices x bins prefix table]
   size_t hist_cap = 0;
   void *d_sort_temp = nullptr;

@@ -102,6 +102,7 @@ struct FeGatherArgs {
   double *gpartials;       // [nblocks][3]
   const uint32_t *sxy;     // optional: events in destination-tile order (better LUT / Itilde locality) ...
   const uint32_t *sbatch;  // ... with their batch indices; null = time order
+  const double *sb, *sdt;  // optional, with sxy: per-event bearing (x, y) and dt in the same order (see BinnedEvents)
   const float *cx, *cy;    // G^T 1 factors (W and H floats) when itilde holds G^T B (mu-free form); null: itilde = G^T(B-mu)
   int r;                   // blur radius (defines the border band where cx, cy differ from 1)
 };
@@ -169,6 +170,8 @@ struct BinnedEvents {
   unsigned *fallback;      // events that left their window and took the global-atomic path (device counter)
   unsigned char *tflags;   // optional: image-tile occupancy map marked by every vote that reaches global memory
   int tflags_tiles_x;
+  const double *sb;        // front end, optional: bearing (x, y) of each sorted event (16 B, z == 1) ...
+  const double *sdt;       // ... and its batch's dt: coalesced streams instead of two divergent table gathers per event
   unsigned long long *fixed;  // deterministic mode: 2^-30 fixed-point planes every global vote is added to (else nullptr)
 };
 
@@ -185,7 +188,7 @@ bool count_sort_ok(int nbins);
 size_t count_sort_scratch_ints(int n, int nbins);
 void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,
                        int per_batch, int n, uint32_t *keys, int *scratch, int *tile_start, uint32_t *sxy, uint32_t *sbatch,
-                       hipStream_t s);
+                       double *sb, double *sdt, hipStream_t s);
 // t0 / t1 (optional): events bracketing exactly the kernel(s) of the launch (hipExtLaunchKernelGGL start / stop events,
 // the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);

@@ -834,24 +834,36 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
   const int stride = 256;
   for (int i0 = blk_beg + threadIdx.x; i0 < blk_end; i0 += stride * U) {
-    uint32_t e[U];
     double dt[U], px[U], py[U], pz[U];
     bool act[U];
+    if (g.sb) {  // tile order with per-event bearing / dt streams (coalesced): the only gathers left are the Jt reads
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * stride;
-      act[u] = i < blk_end;
-      if (g.sxy) {
-        e[u] = act[u] ? g.sxy[i] : 0u;
-        dt[u] = act[u] ? a.batch_dt[g.sbatch[i]] : 0.0;
-      } else {
-        e[u] = act[u] ? a.xy[i] : 0u;
-        dt[u] = act[u] ? a.batch_dt[i / a.per_batch] : 0.0;
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * stride;
+        act[u] = i < blk_end;
+        const int ii = act[u] ? i : blk_beg;
+        const double2 v = *reinterpret_cast<const double2 *>(g.sb + 2 * (size_t)ii);
+        px[u] = v.x; py[u] = v.y; pz[u] = 1.0;
+        dt[u] = g.sdt[ii];
       }
-    }
+    } else {
+      uint32_t e[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * stride;
+        act[u] = i < blk_end;
+        if (g.sxy) {
+          e[u] = act[u] ? g.sxy[i] : 0u;
+          dt[u] = act[u] ? a.batch_dt[g.sbatch[i]] : 0.0;
+        } else {
+          e[u] = act[u] ? a.xy[i] : 0u;
+          dt[u] = act[u] ? a.batch_dt[i / a.per_batch] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {

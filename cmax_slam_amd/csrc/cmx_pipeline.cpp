@@ -100,9 +100,19 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       // counting sort: keys + per-slice histograms, column prefixes, bin scan, scatter (cmx_binning.hip)
       rc = ensure(c, c->d_hist, c->hist_cap, count_sort_scratch_ints(n, ntiles + 1));
       if (rc) return rc;
+      c->streams_valid = false;
+      if (fe && c->d_lut2) {  // front end: the sorted order also carries every event's bearing and dt
+        rc = ensure(c, c->d_sb, c->sb_cap, (size_t)2 * n);
+        if (rc) return rc;
+        rc = ensure(c, c->d_sdt, c->sdt_cap, (size_t)n);
+        if (rc) return rc;
+        c->streams_valid = true;
+      }
       launch_count_sort(fe, be, tiles_x, ntiles / planes_per_tile, c->d_xy, c->per_batch, n, c->d_keys, c->d_hist,
-                        c->d_tile_start, c->d_sxy, c->d_sbatch, c->stream);
+                        c->d_tile_start, c->d_sxy, c->d_sbatch, c->streams_valid ? c->d_sb : nullptr,
+                        c->streams_valid ? c->d_sdt : nullptr, c->stream);
     } else {
+      c->streams_valid = false;
       if (fe) launch_fe_bin_keys(*fe, tiles_x, ntiles, c->d_keys, c->d_idx, c->stream);
       else launch_be_bin_keys(*be, tiles_x, ntiles / 2, c->d_keys, c->d_idx, c->stream);
       int end_bit = 1;
@@ -153,6 +163,7 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.nchunks = c->nchunks;
   b.nchunks_dev = c->d_nchunks;
   b.fallback = c->d_fallback;
+  if (c->kind == KIND_FE && c->streams_valid) { b.sb = c->d_sb; b.sdt = c->d_sdt; }
   return b;
 }
 
@@ -446,6 +457,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         // (deterministic mode: time order -- the order inside a tile depends on the scatter's atomics)
         g.sxy = c->d_sxy;
         g.sbatch = c->d_sbatch;
+        if (c->streams_valid) { g.sb = c->d_sb; g.sdt = c->d_sdt; }
       }
       if (c->n_packed > 0) launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
