@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBinBlock) void scatter_bins_kernel(const uint32_t 
     if (sb) {
       const double2 v = *reinterpret_cast<const double2 *>(lut2 + 2 * ((size_t)((e >> 16) & 0x7fff) * W + (e & 0xffff)));
       *reinterpret_cast<double2 *>(sb + 2 * (size_t)pos) = v;
-      sdt[pos] = batch_dt[bi];
+      if (sdt) sdt[pos] = batch_dt[bi];
     }
   }
 }
@@ -238,10 +238,11 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
   else hipLaunchKernelGGL(be_bin_hist_kernel, dim3(blocks), dim3(kBinBlock), lds, s, *be, tiles_x, ntiles_img, per_block, keys, table);
   hipLaunchKernelGGL(column_scan_kernel, dim3((nbins + 255) / 256), dim3(256), 0, s, table, nbins, blocks, total);
   hipLaunchKernelGGL(scan_bins_kernel, dim3(1), dim3(kBinBlock), 0, s, total, nbins, tile_start);
-  const bool streams = fe && sb && sdt && fe->lut2;
+  const double *lut2 = fe ? fe->lut2 : be->lut2;
+  const bool streams = sb && lut2 && (be || sdt);
   hipLaunchKernelGGL(scatter_bins_kernel, dim3(blocks), dim3(kBinBlock), lds, s, keys, xy, per_batch, n, nbins, per_block, table,
-                     tile_start, sxy, sbatch, streams ? fe->lut2 : nullptr, fe ? fe->W : 0, fe ? fe->batch_dt : nullptr,
-                     streams ? sb : nullptr, streams ? sdt : nullptr);
+                     tile_start, sxy, sbatch, streams ? lut2 : nullptr, fe ? fe->W : be->W, fe ? fe->batch_dt : nullptr,
+                     streams ? sb : nullptr, (streams && fe) ? sdt : nullptr);
 }
 
 // Chunk table on the device: tile t owns the sorted events [tile_start[t], tile_start[t+1]); it is cut into chunks of at
@@ -573,7 +574,13 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
     double b0[U], b1[U], b2[U], R[U][9];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
+      if (b.sb) {
+        const int jj = act[u] ? j0 + u * 256 : c.beg;
+        const double2 v = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)jj);
+        b0[u] = v.x; b1[u] = v.y; b2[u] = 1.0;
+      } else {
+        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
+      }
       const double *Rp = a.poseR[bi[u]].R;
 #pragma unroll
       for (int k = 0; k < 9; k++) R[u][k] = Rp[k];

@@ -101,11 +101,13 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       rc = ensure(c, c->d_hist, c->hist_cap, count_sort_scratch_ints(n, ntiles + 1));
       if (rc) return rc;
       c->streams_valid = false;
-      if (fe && c->d_lut2) {  // front end: the sorted order also carries every event's bearing and dt
+      if (c->d_lut2) {  // the sorted order also carries every event's bearing (front end: and its dt)
         rc = ensure(c, c->d_sb, c->sb_cap, (size_t)2 * n);
         if (rc) return rc;
-        rc = ensure(c, c->d_sdt, c->sdt_cap, (size_t)n);
-        if (rc) return rc;
+        if (fe) {
+          rc = ensure(c, c->d_sdt, c->sdt_cap, (size_t)n);
+          if (rc) return rc;
+        }
         c->streams_valid = true;
       }
       launch_count_sort(fe, be, tiles_x, ntiles / planes_per_tile, c->d_xy, c->per_batch, n, c->d_keys, c->d_hist,
@@ -163,7 +165,7 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.nchunks = c->nchunks;
   b.nchunks_dev = c->d_nchunks;
   b.fallback = c->d_fallback;
-  if (c->kind == KIND_FE && c->streams_valid) { b.sb = c->d_sb; b.sdt = c->d_sdt; }
+  if (c->streams_valid) { b.sb = c->d_sb; b.sdt = c->kind == KIND_FE ? c->d_sdt : nullptr; }
   return b;
 }
 
