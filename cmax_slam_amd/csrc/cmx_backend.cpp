@@ -187,6 +187,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   c->per_batch = per_batch;
   c->nb = nb;
   c->have_data = true;
+  c->tb_valid = false;
   c->bin_valid = false;
   return CMX_OK;
 }

@@ -246,6 +246,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_sort_temp);
   hipFree(c->d_hist);
   hipFree(c->d_sb);
+  hipFree(c->d_tb);
   hipFree(c->d_sdt);
   hipFree(c->d_fixed);
   hipFree(c->d_tile_start);

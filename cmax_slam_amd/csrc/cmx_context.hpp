@@ -131,6 +131,9 @@ struct cmx_ctx {
   double *d_sb = nullptr, *d_sdt = nullptr;  // front end: bearing (x, y) and dt of every tile-sorted event
   size_t sb_cap = 0, sdt_cap = 0;
   bool streams_valid = false;
+  double *d_tb = nullptr;  // back end: bearing (x, y) of every event in time order (gather stream)
+  size_t tb_cap = 0;
+  bool tb_valid = false;
   int *d_hist = nullptr;  // counting sort scratch: [bin totals | slices x bins prefix table]
   size_t hist_cap = 0;
   void *d_sort_temp = nullptr;

@@ -118,6 +118,8 @@ struct BeGatherArgs {
   int parts_per_batch;     // wave slices a batch can touch
   int slice_shift;         // log2 of the events one wave pass covers: 6 (one event per lane) or 8 (four per lane)
   int deterministic;       // per-parameter block sums in a fixed order instead of LDS fp64 atomics
+  const double *tb;        // optional: bearing (x, y) of every event in TIME order (16 B, z == 1): coalesced stream for the
+                           // four-events-per-lane pass instead of four divergent bearing-table gathers per lane
 };
 
 struct FinalizeArgs {
@@ -194,6 +196,8 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // deterministic mode: fixed-point planes -> fp32 planes (non-zero entries only; `planes` is all-zero before), fixed := 0
+// bearing (x, y) of every event in time order (back-end gather stream)
+void launch_bearing_stream(const uint32_t *xy, const double *lut2, int W, int n, double *tb, hipStream_t s);
 void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, hipStream_t s);
 
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);

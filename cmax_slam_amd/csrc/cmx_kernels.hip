@@ -993,9 +993,17 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
 #pragma unroll
       for (int k = 0; k < 9; k++) R[k] = a.poseR[batch].R[k];
       double b0[4], b1[4], b2[4];
+      if (g.tb && i0 + 3 < a.n) {  // 64 contiguous bytes per lane from the time-ordered bearing stream
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
+        for (int u = 0; u < 4; u++) {
+          const double2 v = *reinterpret_cast<const double2 *>(g.tb + 2 * (size_t)(i0 + u));
+          b0[u] = v.x; b1[u] = v.y; b2[u] = 1.0;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -1104,6 +1112,20 @@ __global__ __launch_bounds__(256) void be_gather_batch_kernel(BeGatherArgs g, in
     g.gpartials[(size_t)j * gridDim.x + blockIdx.x] = shG[j];
     g.gpartials[(size_t)(g.P + j) * gridDim.x + blockIdx.x] = shG2[j];
   }
+}
+
+__global__ __launch_bounds__(256) void bearing_stream_kernel(const uint32_t *xy, const double *lut2, int W, int n, double *tb) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t e = xy[i];
+    *reinterpret_cast<double2 *>(tb + 2 * (size_t)i) =
+        *reinterpret_cast<const double2 *>(lut2 + 2 * ((size_t)((e >> 16) & 0x7fff) * W + (e & 0xffff)));
+  }
+}
+void launch_bearing_stream(const uint32_t *xy, const double *lut2, int W, int n, double *tb, hipStream_t s) {
+  if (n <= 0) return;
+  int blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bearing_stream_kernel, dim3(blocks), dim3(256), 0, s, xy, lut2, W, n, tb);
 }
 
 int be_batch_blocks(int nb) {

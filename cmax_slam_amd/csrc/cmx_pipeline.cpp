@@ -474,6 +474,15 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       g.parts_per_batch = parts_per_batch;
       g.slice_shift = slice_shift;
       g.deterministic = c->deterministic ? 1 : 0;
+      if (c->d_lut2 && slice_shift == 8 && c->n_packed > 0) {  // once per window: the events' bearings in time order
+        if (!c->tb_valid) {
+          int rc2 = ensure(c, c->d_tb, c->tb_cap, (size_t)2 * c->n_packed);
+          if (rc2) return rc2;
+          launch_bearing_stream(c->d_xy, c->d_lut2, c->W, c->n_packed, c->d_tb, c->stream);
+          c->tb_valid = true;
+        }
+        g.tb = c->d_tb;
+      }
       if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     }
