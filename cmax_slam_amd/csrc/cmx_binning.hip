@@ -4,10 +4,12 @@
 // Why: on gfx950 every device-scope fp32 atomic executes memory-side (the 8 XCD L2s are not coherent): one 32-byte
 // fabric transaction per vote, ~18.7 G/s (profiles/r01a_*).  Motion-compensated events pile onto a few edge
 // pixels, so a workgroup that owns a small image window can absorb thousands of votes per pixel in LDS
-// (ds_add_f32) and emit ONE global atomic per touched pixel.  Events are sorted by the 32x32 tile their vote lands
+// (64-bit fixed-point ds_add, see below) and emit ONE global atomic per touched pixel.  Events are sorted by the 32x32 tile their vote lands
 // in under the parameters of the first evaluation; during the solve the parameters move a little, so each
 // workgroup's LDS window is the tile plus a 16-pixel margin, and any vote that still leaves the window takes the
 // plain global-atomic path -- the result is exact for any parameters, only the speed depends on the binning.
+// The sort is a counting sort (below); the (key, index) radix-sort kernels at the top of the file are its fallback for
+// panoramas with more than 16 400 destination-tile keys.  The sorted order also carries per-event bearing / dt streams.
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
