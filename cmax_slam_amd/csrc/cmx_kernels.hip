@@ -816,9 +816,11 @@ int gather_blocks(int n) {
   const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~130 VGPRs: 3 blocks/CU is its occupancy)
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
-// front end: one workgroup per kFeGatherPerBlock events up to the cap (tools/sweep_fe_gather.sh, with two events in
-// flight per thread: 512 -> 11.6 us, 1024 -> 11.9 us, 2048 -> 15.3 us per 1M events)
-constexpr int kFeGatherPerBlock = 512, kFeGatherCap = 4096;
+// front end: one workgroup per kFeGatherPerBlock events up to the cap.  Swept on MI355X with the bearing / dt streams
+// (tools/sweep_fe_gather2.sh, two events in flight per thread): the kernel alone is indifferent between 512 and 1024
+// events (10.9-11.3 us), 2048 -> 12.2 us, 3072 -> 16 us; the evaluation prefers 1024 (47.2 us against 49.2 us at 512)
+// because finalize then sums half as many partial rows
+constexpr int kFeGatherPerBlock = 1024, kFeGatherCap = 2048;
 int fe_gather_blocks(int n) {
   int blocks = (n + kFeGatherPerBlock - 1) / kFeGatherPerBlock;
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
