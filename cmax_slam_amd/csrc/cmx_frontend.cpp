@@ -83,6 +83,7 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   c->per_batch = event_batch_size;
   c->nb = nb;
   c->have_data = true;
+  c->tb_valid = false;
   c->bin_valid = false;
   return CMX_OK;
 }

@@ -103,6 +103,7 @@ struct FeGatherArgs {
   const uint32_t *sxy;     // optional: events in destination-tile order (better LUT / Itilde locality) ...
   const uint32_t *sbatch;  // ... with their batch indices; null = time order
   const double *sb, *sdt;  // optional, with sxy: per-event bearing (x, y) and dt in the same order (see BinnedEvents)
+  const double *tb;        // optional, time order (sxy == null): per-event bearing (x, y) stream
   const float *cx, *cy;    // G^T 1 factors (W and H floats) when itilde holds G^T B (mu-free form); null: itilde = G^T(B-mu)
   int r;                   // blur radius (defines the border band where cx, cy differ from 1)
 };

@@ -849,6 +849,17 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
         dt[u] = g.sdt[ii];
       }
     } else {
+      if (g.tb && !g.sxy) {  // time order with the bearing stream (deterministic mode)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int i = i0 + u * stride;
+          act[u] = i < blk_end;
+          const int ii = act[u] ? i : blk_beg;
+          const double2 v = *reinterpret_cast<const double2 *>(g.tb + 2 * (size_t)ii);
+          px[u] = v.x; py[u] = v.y; pz[u] = 1.0;
+          dt[u] = a.batch_dt[ii / a.per_batch];
+        }
+      } else {
       uint32_t e[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -865,6 +876,7 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), px[u], py[u], pz[u]);
+      }
       }
     }
 #pragma unroll

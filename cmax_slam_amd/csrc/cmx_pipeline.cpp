@@ -461,6 +461,15 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         g.sbatch = c->d_sbatch;
         if (c->streams_valid) { g.sb = c->d_sb; g.sdt = c->d_sdt; }
       }
+      if (!g.sxy && c->d_lut2 && c->n_packed > 0) {  // time-ordered gather: the events' bearings as a stream, once per packet
+        if (!c->tb_valid) {
+          int rc2 = ensure(c, c->d_tb, c->tb_cap, (size_t)2 * c->n_packed);
+          if (rc2) return rc2;
+          launch_bearing_stream(c->d_xy, c->d_lut2, c->W, c->n_packed, c->d_tb, c->stream);
+          c->tb_valid = true;
+        }
+        g.tb = c->d_tb;
+      }
       if (c->n_packed > 0) launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
     } else {
