@@ -4,7 +4,10 @@
 #include "cmx_context.hpp"
 
 int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lut, int Wp, int Hp) {
-  if (Wp < 4 || Hp < 4 || Wp > 65535 || Hp > 65535) { if (out) *out = nullptr; return CMX_ERR_INVALID_ARG; }
+  if (Wp < 4 || Hp < 4 || Wp > 65535 || Hp > 65535 || (long long)Wp * Hp > kMaxPixels) {
+    if (out) *out = nullptr;
+    return CMX_ERR_INVALID_ARG;
+  }
   int rc = create_common(out, KIND_BE, device, W, H, lut);
   if (rc) return rc;
   cmx_ctx *c = *out;
@@ -160,7 +163,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   if (IG == CMX_KEEP_MAP) {
     c->ig_nonzero = true;  // resident map: contents unknown to the host; the alpha kernel counts the non-zeros itself
   } else if (IG) {
-    HIP_TRY(c, hipMemcpy(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(c->d_IG, IG, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
     std::atomic<bool> nz(false);
     parallel_ranges((int64_t)np, [&](int64_t a0, int64_t a1) {
       for (int64_t i = a0; i < a1 && !nz.load(std::memory_order_relaxed); i++)
@@ -168,10 +171,10 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     });
     c->ig_nonzero = nz.load();
   } else {
-    HIP_TRY(c, hipMemset(c->d_IG, 0, np * sizeof(float)));
+    HIP_TRY(c, hipMemsetAsync(c->d_IG, 0, np * sizeof(float), c->stream));
     c->ig_nonzero = false;
   }
-  HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
+  HIP_TRY(c, hipMemsetAsync(c->d_alpha, 0, sizeof(double), c->stream));  // on the context's (non-blocking) stream: ordered before its kernels
   c->h_result[kAlphaSlot] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
   HIP_TRY(c, hipStreamSynchronize(c->stream));

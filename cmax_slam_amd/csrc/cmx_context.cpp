@@ -118,6 +118,7 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   if (!out) return CMX_ERR_INVALID_ARG;
   *out = nullptr;
   if (W <= 0 || H <= 0 || W > 32767 || H > 32767 || !lut) return CMX_ERR_INVALID_ARG;
+  if ((long long)W * H > kMaxPixels) return CMX_ERR_INVALID_ARG;  // kernels index pixels with 32-bit ints
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CMX_ERR_HIP;  // no CPU fallback
   if (device < 0 || device >= ndev) return CMX_ERR_INVALID_ARG;
@@ -272,14 +273,17 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_GRAD_MODE:
       if (value != CMX_GRAD_PLANES && value != CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "bad grad mode %d", value);
       c->grad_mode = value;
+      c->x_valid = false;  // the resident pose table may have been built without Jacobians: never reuse across a mode switch
       return CMX_OK;
     case CMX_OPT_SPLAT_MODE:
       if (value != 0 && value != 1) return fail(c, CMX_ERR_INVALID_ARG, "bad splat mode %d", value);
       c->splat_mode = value;
       c->bin_valid = false;
+      c->x_valid = false;
       return CMX_OK;
     case CMX_OPT_REUSE_IMAGE:
       c->reuse_image = value != 0;
+      c->x_valid = false;  // (the pose table of a cost-only evaluation carries Jacobians only when reuse was on)
       return CMX_OK;
     case CMX_OPT_DETERMINISTIC:
       c->deterministic = value != 0;

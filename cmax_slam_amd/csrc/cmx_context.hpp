@@ -26,6 +26,7 @@
 using namespace cmx;  // internal header of one library: the parameter blocks of cmx_internal.hpp are used unqualified
 
 enum { KIND_FE = 1, KIND_BE = 2 };
+constexpr long long kMaxPixels = 1LL << 29;  // per plane (sensor or panorama): pixel loops use 32-bit ints, up to 3 planes interleaved
 constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
 
 struct TimedSpan { int cls; hipEvent_t a, b; };

@@ -67,6 +67,9 @@ int cmx_events_drop_before(cmx_events *e, int64_t global_index) {
     if (hipMemcpy(e->d_xy[other], e->d_xy[e->cur] + k, keep * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
         hipMemcpy(e->d_t[other], e->d_t[e->cur] + k, keep * sizeof(int64_t), hipMemcpyDeviceToDevice) != hipSuccess)
       return efail(e, CMX_ERR_HIP, "compaction failed");
+    // a device-to-device hipMemcpy may return before the copy has run, and the contexts that cut packets / windows from
+    // the store use non-blocking streams: make the compaction complete before the buffers are flipped
+    if (hipDeviceSynchronize() != hipSuccess) return efail(e, CMX_ERR_HIP, "compaction failed");
   }
   e->h_t.erase(e->h_t.begin(), e->h_t.begin() + (ptrdiff_t)k);
   e->cur = other;

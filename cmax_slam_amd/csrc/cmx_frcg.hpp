@@ -6,7 +6,8 @@
 // GSL's multimin/conjugate_fr.c + directional_minimize.c (take_step / intermediate_point / minimize),
 // keeping its call pattern (f-only trial points, df at accepted points) because that pattern is what the
 // evaluator is tuned for.  PARITY UNPINNED against GSL itself; the stopping rules of the reference's driver
-// loops are restated in cmx_solver.cpp.
+// loops are restated in cmx_solver.cpp.  A second, independently written restatement (oracle/frcg.py, Python) is run
+// against this one call for call in tests/test_frcg_independent.py.
 #pragma once
 #include <math.h>
 #include <stddef.h>
@@ -96,10 +97,23 @@ class FrcgMinimizer {
     return FRCG_SUCCESS;
   }
 
+  // gsl_blas_dnrm2 as GSL's own CBLAS computes it (cblas/source_nrm2_r.h): running scale + scaled sum of squares
   static double nrm2(const std::vector<double> &v) {
-    double s = 0;
-    for (double e : v) s += e * e;
-    return sqrt(s);
+    if (v.empty()) return 0.0;
+    if (v.size() == 1) return fabs(v[0]);
+    double scale = 0.0, ssq = 1.0;
+    for (double e : v) {
+      if (e != 0.0) {
+        const double ax = fabs(e);
+        if (scale < ax) {
+          ssq = 1.0 + ssq * (scale / ax) * (scale / ax);
+          scale = ax;
+        } else {
+          ssq += (ax / scale) * (ax / scale);
+        }
+      }
+    }
+    return scale * sqrt(ssq);
   }
 
   std::vector<double> x, gradient, dx;
@@ -187,7 +201,7 @@ class FrcgMinimizer {
         if (stepm < stepb) stepa = stepm;
         else stepc = stepm;
         continue;
-      } else {  // fm <= fb
+      } else if (fm <= fb) {
         old2 = old1;
         old1 = fabs(u - stepm);
         w = v; v = u; u = stepm;
@@ -205,6 +219,8 @@ class FrcgMinimizer {
         if (stepm < stepb) { stepc = stepb; fc = fb; stepb = stepm; fb = fm; }
         else { stepa = stepb; fa = fb; stepb = stepm; fb = fm; }
         continue;
+      } else {
+        return;  // fm is NaN (a failed evaluation): GSL's if / else-if pair takes neither branch and falls out of the function
       }
     }
   }
