@@ -149,6 +149,8 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
   memset(c->h_result, 0, c->result_cap * sizeof(double));
+  HIP_TRY(c, hipMalloc((void **)&c->d_tail_counters, kTailCounterWords * sizeof(unsigned)));
+  HIP_TRY(c, hipMemset(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned)));
   return CMX_OK;
 }
 
@@ -260,6 +262,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
+  hipFree(c->d_tail_counters);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
   comm_release(c);
@@ -291,6 +294,9 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_SPIN_WAIT:
       c->ticket_wait = value != 0;
+      return CMX_OK;
+    case CMX_OPT_TAIL_FINALIZE:
+      c->tail_finalize = value != 0;
       return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
@@ -330,7 +336,7 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
 int cmx_timing_enable(cmx_ctx *c, int on) {
   if (!c) return CMX_ERR_INVALID_ARG;
   c->timing = (on & 0xff) != 0;
-  c->timing_mask = on & 0xff;
+  c->timing_mask = on & 0xff;  // CMX_T_COUNT <= 8 classes
   c->timing_every = (on >> 8) > 0 ? (on >> 8) : 1;  // bits 8..: sample every n-th evaluation only
   c->timing_tick = 0;
   return CMX_OK;

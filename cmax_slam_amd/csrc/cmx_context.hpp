@@ -160,6 +160,8 @@ struct cmx_ctx {
   int ticket_nout = 0;                   // result words that launch writes
   bool ticket_wait = true;
   size_t result_cap = 0;
+  bool tail_finalize = true;          // CMX_OPT_TAIL_FINALIZE
+  unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
 
   // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
   ncclComm_t comm = nullptr;
@@ -267,6 +269,7 @@ FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]);
 BeSplatArgs be_args(const cmx_ctx *c);
 bool adjoint_ok(const cmx_ctx *c);
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce);
+bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail);  // true: the next launch carries the finalize (no separate launch)
 int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip);
 int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach);
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd);

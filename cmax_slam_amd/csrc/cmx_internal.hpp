@@ -52,6 +52,40 @@ struct BeSplatArgs {
   float *planes;  // [2 + P][Hp][Wp]: IL_old, IL_new, derivative planes
 };
 
+struct FinalizeArgs {
+  int P, nblk, measure;
+  double npix;
+  const double *partials;  // [2+2P][nblk]
+  double *sums;            // [2+2P] device scratch
+  double *result;          // mapped host: [0]=contrast, [1]=mean, [2..2+P) = gradient
+  // adjoint mode: gradient = (2/N) * sum over blocks of gpartials[b][k]
+  const double *gpartials;
+  int gblocks, gP;
+  unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
+  int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
+  const unsigned *nvalid;  // direct mode: device count of valid entries per row (tile work list); null = nblk
+  int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
+  unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
+};
+// tail of the mapped result buffer (doubles / u64 bit patterns)
+constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nout) and result[kFallbackSlot], ^ ticket*kTicketMix
+constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
+constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
+constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
+constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
+
+
+// Tail finalize (cmx_kernels.hip, tail_arrive): the LAST kernel of an evaluation -- image_moments (cost-only),
+// fe_gather / be_gather_batch (adjoint gradient) -- runs the finalize step in its last-arriving workgroup, so an
+// evaluation ends without the one-workgroup finalize launch and the kernel boundary in front of it.
+constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
+constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
+constexpr int kTailCounterWords = (kTailShards + 1) * kTailStride;
+struct TailArgs {
+  unsigned *counters;  // all-zero between launches (the last arrivers reset what they completed); null = no tail finalize
+  FinalizeArgs fin;
+};
+
 struct ImgArgs {
   int W, H, r;
   float taps[2 * kMaxRadius + 1];
@@ -78,6 +112,7 @@ struct ImgArgs {
   // the image kernels walk that list with a bounded grid instead of launching one workgroup per panorama tile
   const unsigned *tile_list;
   const unsigned *tile_count;
+  TailArgs tail;        // image_moments only (cost-only evaluations, P == 0): finalize in the last-arriving workgroup
 };
 constexpr int kTileListMin = 2048, kTileListGrid = 1024;
 // reach: pixels of filter support beyond the tile (r for the moments pass, 2r for the adjoint pass)
@@ -106,6 +141,7 @@ struct FeGatherArgs {
   const double *tb;        // optional, time order (sxy == null): per-event bearing (x, y) stream
   const float *cx, *cy;    // G^T 1 factors (W and H floats) when itilde holds G^T B (mu-free form); null: itilde = G^T(B-mu)
   int r;                   // blur radius (defines the border band where cx, cy differ from 1)
+  TailArgs tail;           // finalize in the last-arriving workgroup (counters == null: separate finalize launch)
 };
 
 struct BeGatherArgs {
@@ -121,29 +157,8 @@ struct BeGatherArgs {
   int deterministic;       // per-parameter block sums in a fixed order instead of LDS fp64 atomics
   const double *tb;        // optional: bearing (x, y) of every event in TIME order (16 B, z == 1): coalesced stream for the
                            // four-events-per-lane pass instead of four divergent bearing-table gathers per lane
+  TailArgs tail;           // be_gather_batch: finalize in the last-arriving workgroup (counters == null: separate launch)
 };
-
-struct FinalizeArgs {
-  int P, nblk, measure;
-  double npix;
-  const double *partials;  // [2+2P][nblk]
-  double *sums;            // [2+2P] device scratch
-  double *result;          // mapped host: [0]=contrast, [1]=mean, [2..2+P) = gradient
-  // adjoint mode: gradient = (2/N) * sum over blocks of gpartials[b][k]
-  const double *gpartials;
-  int gblocks, gP;
-  unsigned *fallback;      // LDS-splat fallback counter: copied to result[4094] and reset (may be null)
-  int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
-  const unsigned *nvalid;  // direct mode: device count of valid entries per row (tile work list); null = nblk
-  int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
-  unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
-};
-// tail of the mapped result buffer (doubles / u64 bit patterns)
-constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nout) and result[kFallbackSlot], ^ ticket*kTicketMix
-constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
-constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
-constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
-constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
 struct AlphaArgs {
   const float *igp, *il_old, *il_new;

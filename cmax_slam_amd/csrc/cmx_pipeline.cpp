@@ -210,12 +210,27 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
   return c->grad_mode == CMX_GRAD_ADJOINT && c->imgW > 2 * c->radius + 1 && c->imgH > 2 * c->radius + 1;
 }
 
-// every evaluation ends in exactly one finalize launch; it carries the ticket sync_and_collect() waits for
+// every evaluation ends in exactly one finalize -- its own launch (here) or the tail of the evaluation's last kernel
+// (arm_tail) -- which carries the ticket sync_and_collect() waits for
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
   f.ticket = ++c->ticket_issued;
   c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  Span sp(c, CMX_T_FINAL);
   if (with_reduce) launch_finalize(f, c->stream);
   else launch_finalize_only(f, c->stream);
+}
+
+// Tail finalize (CMX_OPT_TAIL_FINALIZE): hand the finalize to the launch that is about to be issued.  Only the forms whose
+// inputs are per-workgroup partial tables of that very launch or results of earlier launches qualify (f.direct, no
+// reduce_partials pass in between).
+bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail) {
+  tail.counters = nullptr;
+  if (!c->tail_finalize || !c->d_tail_counters || !f.direct || f.measure == 2) return false;
+  f.ticket = ++c->ticket_issued;
+  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  tail.counters = c->d_tail_counters;
+  tail.fin = f;
+  return true;
 }
 
 // ping-pong partner clearing + tile-occupancy flags of an image pass (see ImgArgs)
@@ -330,28 +345,28 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
+  FinalizeArgs f{};
+  f.P = P;
+  f.nblk = a.nblk;
+  f.measure = c->measure;
+  f.npix = (double)np;
+  f.partials = c->d_partials;
+  f.sums = c->d_sums;
+  f.result = c->d_result;
+  f.fallback = c->d_fallback;
+  bool tailed = false;
   {
     Span sp(c, CMX_T_IMAGE);
     rc = maybe_tile_list(c, a, c->radius);
     if (rc) return rc;
-    launch_image_moments(a, c->stream);
-    FinalizeArgs f{};
-    f.P = P;
-    f.nblk = a.nblk;
-    f.measure = c->measure;
-    f.npix = (double)np;
-    f.partials = c->d_partials;
-    f.sums = c->d_sums;
-    f.result = c->d_result;
-    f.fallback = c->d_fallback;
     if (P == 0 && (a.nblk <= 2048 || a.tile_list)) {
       f.direct = 1;
       f.nvalid = a.tile_count;  // list path: partial rows are compact, one entry per listed tile
-      issue_finalize(c, f, false);
-    } else {
-      issue_finalize(c, f, true);
+      if (!out_blur0 && !out_blurd) tailed = arm_tail(c, f, a.tail);  // the last-arriving workgroup finalizes
     }
+    launch_image_moments(a, c->stream);
   }
+  if (!tailed) issue_finalize(c, f, /*with_reduce=*/!f.direct);
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }
@@ -447,6 +462,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     launch_image_adjoint(ia, c->stream);
     if (!direct) launch_reduce_partials(f, c->stream);
   }
+  bool tailed = false;  // the gather launch carries the finalize
   {
     Span sp(c, CMX_T_GATHER, /*exact=*/true);
     if (c->kind == KIND_FE) {
@@ -470,8 +486,12 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         }
         g.tb = c->d_tb;
       }
-      if (c->n_packed > 0) launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
-      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+      if (c->n_packed > 0) {
+        if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
+      } else {
+        HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+      }
     } else {
       BeGatherArgs g{};
       g.ev = be_args(c);
@@ -492,8 +512,12 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         }
         g.tb = c->d_tb;
       }
-      if (c->n_packed > 0 && P > 0) launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
-      else HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+      if (c->n_packed > 0 && P > 0) {
+        if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
+      } else {
+        HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
+      }
     }
     if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
   }
@@ -501,7 +525,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
-  issue_finalize(c, f, false);
+  if (!tailed) issue_finalize(c, f, false);
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }
@@ -529,7 +553,19 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!done) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (ends_in_finalize && c->ticket_issued) {
+      // the stream is idle: the finalize (its own launch, or the tail of the last kernel) must have delivered its ticket
+      const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result);
+      if (w[kTicketSlot] != c->ticket_issued) {
+        const unsigned long long got = w[kTicketSlot];
+        if (c->d_tail_counters) (void)hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream);
+        return fail(c, CMX_ERR_HIP, "evaluation ended without its finalize step (ticket %llu, expected %llu)", got,
+                    (unsigned long long)c->ticket_issued);
+      }
+    }
+  }
   if (!c->nchunks_exact && c->bin_valid && c->d_nchunks) {  // once per binning: launch exactly the chunks that exist
     int nch = 0;
     if (hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && nch >= 0 && nch <= c->nchunks) c->nchunks = nch;

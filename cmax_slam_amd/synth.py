@@ -172,9 +172,13 @@ class BackendWindow:
 
 
 def backend_window(N, W, H, fx, fy, cx, cy, Wp, Hp, order, K, num_fixed, T, dt_knots=0.05, seed=SEED0, noise=0.10,
-                   n_arcs=200, knot_sigma=0.02, init_sigma=0.01, win_stride=None):
+                   n_arcs=200, knot_sigma=0.02, init_sigma=0.01, win_stride=None, slab=None):
     """One back-end BA window: events over [t0, t0+T), a smooth random SO(3) spline with K knots
-    (cumulative exp(N(0, knot_sigma^2 I))) and a perturbed start."""
+    (cumulative exp(N(0, knot_sigma^2 I))) and a perturbed start.
+
+    slab = (r, n): only the N events of time slab r of n, i.e. with t in [r T/n, (r+1) T/n) -- same trajectory, scene and
+    window description as the other slabs, events drawn from a slab-specific stream.  Concatenating the n slabs gives
+    one time-sorted window of n*N events: a rank of a sharded run generates its own slab only (config 4)."""
     rng = np.random.default_rng(seed)
     dt_ns = int(round(dt_knots * 1e9))
     start_ns = T0_NS
@@ -195,6 +199,12 @@ def backend_window(N, W, H, fx, fy, cx, cy, Wp, Hp, order, K, num_fixed, T, dt_k
     cone = 1.15 * np.arctan(np.hypot(W / 2 / fx, H / 2 / fy))
     scene = _Scene(rng, n_arcs, axes, cone)
     n_sig_total = int(round(N * (1 - noise)))
+    t_lo, t_span = 0.0, T
+    if slab is not None:
+        r, n_slabs = slab
+        assert 0 <= r < n_slabs
+        t_lo, t_span = T * r / n_slabs, T / n_slabs
+        rng = np.random.default_rng([seed, 7919 + r])  # events only: everything above came from the window's own stream
     # camera orientation on a 5 us grid (generation only; 5e-6 rad at 1 rad/s, far below a pixel)
     grid_ns = 5_000
     n_grid = int(T * 1e9) // grid_ns + 2
@@ -206,7 +216,7 @@ def backend_window(N, W, H, fx, fy, cx, cy, Wp, Hp, order, K, num_fixed, T, dt_k
     while need > 0:
         m = min(int(need * 1.8) + 1024, 4_000_000)
         pts = scene.sample(rng, m)
-        t = rng.random(m) * T
+        t = t_lo + rng.random(m) * t_span
         tn = start_ns + np.floor(t * 1e9).astype(np.int64)
         Rt = grid_R[(tn - start_ns + grid_ns // 2) // grid_ns]
         p_cam = np.einsum("nji,nj->ni", Rt, pts)  # e_ray_w = R * e_ray_cam  (event_pano_warper.cpp:269)
@@ -219,7 +229,7 @@ def backend_window(N, W, H, fx, fy, cx, cy, Wp, Hp, order, K, num_fixed, T, dt_k
     n_noise = N - len(x)
     x = np.concatenate([x, rng.integers(0, W, n_noise)])
     y = np.concatenate([y, rng.integers(0, H, n_noise)])
-    tn = np.concatenate([tn, start_ns + np.floor(rng.random(n_noise) * T * 1e9).astype(np.int64)])
+    tn = np.concatenate([tn, start_ns + np.floor((t_lo + rng.random(n_noise) * t_span) * 1e9).astype(np.int64)])
     o = np.argsort(tn, kind="stable")
     stride = T / 2 if win_stride is None else win_stride
     return BackendWindow(W, H, fx, fy, cx, cy, Wp, Hp, order, x[o].astype(np.uint16), y[o].astype(np.uint16), tn[o],
@@ -243,6 +253,26 @@ def config2(N=1_000_000, seed=SEED0 + 2):
 def config3(N=5_000_000, seed=SEED0 + 3, Wp=1024, Hp=1024):
     """Back-end BA: cubic, K=10 (3 fixed => P=21), 5M events, 1024x1024 panorama."""
     return backend_window(N, 640, 480, Wp=Wp, Hp=Hp, order=4, K=10, num_fixed=3, T=0.35, seed=seed, **HANDHELD_K)
+
+
+def config4_slab(rank, world=8, per_gpu=5_000_000, seed=SEED0 + 4, Wp=1024, Hp=1024):
+    """Back-end BA sliding window sharded over `world` GPUs (40M events over 8): the window of config 3 with
+    world*per_gpu events, as `world` time slabs of per_gpu events each; rank r generates (and owns) slab r.  per_gpu is a
+    multiple of the batch size, so slab boundaries are batch boundaries and the concatenation of the slabs has exactly the
+    batches the single-GPU evaluation of the whole window has (dist.batch_range hands rank r precisely slab r)."""
+    return backend_window(per_gpu, 640, 480, Wp=Wp, Hp=Hp, order=4, K=10, num_fixed=3, T=0.35, seed=seed,
+                          slab=(rank, world), **HANDHELD_K)
+
+
+def concat_slabs(slabs):
+    """The whole window of a list of time slabs (in rank order)."""
+    import copy
+    w = copy.copy(slabs[0])
+    w.x = np.concatenate([s.x for s in slabs])
+    w.y = np.concatenate([s.y for s in slabs])
+    w.t_ns = np.concatenate([s.t_ns for s in slabs])
+    assert np.all(np.diff(w.t_ns) >= 0)
+    return w
 
 
 def config5(N=20_000_000, seed=SEED0 + 5, Wp=4096, Hp=2048):

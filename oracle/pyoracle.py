@@ -44,7 +44,7 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
     # make is incremental: a stale library after a source edit is rebuilt, an up-to-date one costs milliseconds
-    subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so", "liboracle_mt.so"])
+    subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so", "liboracle_mt.so", "liboracle_f64.so"])
     if os.path.isdir("/root/reference/thirdparty/basalt-headers"):
         ref = os.path.join(_HERE, "_ref", "libbasalt_ref.so")
         if force or not os.path.exists(ref):
@@ -430,3 +430,84 @@ def equirect_project(Wp, Hp, P, jac=True):
     J = np.zeros(6, np.float32)
     lib().orc_equirect_project(Wp, Hp, _dp(P), _dp(px), _fp(J) if jac else None)
     return px, (J.reshape(2, 3) if jac else None)
+
+
+# ----------------------------------------------------------------------------- exact (all-fp64) arbiter
+_EXACT = None
+
+
+def exact_lib():
+    """liboracle_f64.so: the oracle's sources with float := double (oracle/exact_f64.c)."""
+    global _EXACT
+    if _EXACT is None:
+        so = os.path.join(_HERE, "liboracle_f64.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_f64.so"])
+        _EXACT = C.CDLL(so)
+    return _EXACT
+
+
+class _BeState64(C.Structure):
+    _fields_ = [("IL_old", c_dp), ("IL_new", c_dp), ("IL", c_dp), ("IG", c_dp), ("IGp", c_dp), ("alpha", C.c_double),
+                ("first_iter", C.c_int)]
+
+
+class BackendExact:
+    """Backend's eval() in exact (fp64) arithmetic; same constructor / set_window arguments."""
+
+    def __init__(self, W, H, lut, Wp, Hp, order, batch=100, sample_rate=1, sigma=1.0, measure=VARIANCE):
+        self.lut = _c(lut, np.float64).reshape(-1)
+        self.W, self.H, self.Wp, self.Hp, self.order = W, H, Wp, Hp, order
+        self.batch, self.sample_rate, self.sigma, self.measure = batch, sample_rate, sigma, measure
+        self.bufs = [np.zeros(Wp * Hp) for _ in range(5)]
+        self.state = _BeState64(*[_dp(b) for b in self.bufs], 0.0, 1)
+
+    def set_window(self, x, y, t_ns, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, IG=None):
+        self.x, self.y, self.t = _c(x, np.uint16), _c(y, np.uint16), _c(t_ns, np.int64)
+        self.knots = _c(knots_xyzw, np.float64).reshape(-1, 4).copy()
+        self.K, self.num_fixed = self.knots.shape[0], num_fixed
+        self.cfg = BeCfg(self.W, self.H, _dp(self.lut), self.Wp, self.Hp, self.batch, self.sample_rate, self.sigma,
+                         self.measure, self.order, self.K, int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns))
+        self.bufs[3][:] = 0 if IG is None else np.asarray(IG, np.float64).reshape(-1)
+        self.state.first_iter = 1
+        self.state.alpha = 0.0
+
+    @property
+    def alpha(self):
+        return self.state.alpha
+
+    def eval(self, drotv, want_grad=True):
+        d = _c(drotv, np.float64).reshape(-1)
+        P = 3 * (self.K - self.num_fixed)
+        c = C.c_double()
+        g = np.zeros(max(P, 1))
+        rc = exact_lib().orc_be_eval(C.byref(self.cfg), C.byref(self.state), C.c_int64(len(self.x)),
+                                     self.x.ctypes.data_as(c_u16p), self.y.ctypes.data_as(c_u16p),
+                                     self.t.ctypes.data_as(c_i64p), _dp(self.knots), _dp(d), C.byref(c),
+                                     _dp(g) if want_grad else None, None)
+        if rc:
+            raise ValueError("exact back-end failed rc=%d" % rc)
+        return c.value, (g[:P] if want_grad else None)
+
+
+class FrontendExact:
+    """Frontend's eval() in exact (fp64) arithmetic."""
+
+    def __init__(self, W, H, lut, fx, fy, cx, cy, batch=100, sigma=1.0, measure=VARIANCE):
+        self.lut = _c(lut, np.float64).reshape(-1)
+        self.cfg = FeCfg(W, H, _dp(self.lut), fx, fy, cx, cy, batch, sigma, measure)
+
+    def set_packet(self, x, y, t_ns, t_ref_ns):
+        self.x, self.y, self.t = _c(x, np.uint16), _c(y, np.uint16), _c(t_ns, np.int64)
+        self.t_ref = int(t_ref_ns)
+
+    def eval(self, omega, want_grad=True):
+        om = _c(omega, np.float64)
+        c = C.c_double()
+        g = np.zeros(3)
+        rc = exact_lib().orc_fe_eval(C.byref(self.cfg), C.c_int64(len(self.x)), self.x.ctypes.data_as(c_u16p),
+                                     self.y.ctypes.data_as(c_u16p), self.t.ctypes.data_as(c_i64p), C.c_int64(self.t_ref),
+                                     _dp(om), C.byref(c), _dp(g) if want_grad else None)
+        if rc:
+            raise ValueError("exact front-end failed rc=%d" % rc)
+        return c.value, (g if want_grad else None)

@@ -1,0 +1,148 @@
+"""-m gpu: the two BASELINE.json configurations that had no test at their own workload:
+
+  config 1  ecrot_synth front end: 100 000 synthetic events, 240x180 DAVIS intrinsics, one angular-velocity window
+            (the reference's own CPU-runnable case) -- HIP vs the CPU oracle at the full size, both GPU paths;
+  config 4  back-end BA sliding window, 40M events (8 x 5M), cubic 10-knot spline, 1024x1024 panorama -- on ONE GPU:
+            the whole window against the CPU oracle, the production path against the reference-shaped path, the eight
+            batch-range shards (exactly what dist.batch_range hands the ranks of the 8-GPU run) accumulating to the whole,
+            and one shard against the oracle on its own.
+"""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import _lib, dist, synth
+from util import RTOL, rel_img, rel_scalar, rel_vec
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ config 1
+@pytest.fixture(scope="module")
+def c1():
+    p = synth.config1()
+    assert (len(p.x), p.W, p.H, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma) == (100_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 100, 1.0)
+    return p
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_config1_full_size_parity(hip, oracle, c1, fast):
+    p = c1
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    if fast:
+        fe.set_fast_path()
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in (np.zeros(3), np.array([0.3, -0.5, 0.2]), p.omega_true, np.array([-2.0, 1.5, 3.0])):
+        c_ref, g_ref = ref.eval(om)
+        c, g = fe.eval(om)
+        assert rel_scalar(c, c_ref) < RTOL, (om, c, c_ref)
+        assert rel_vec(g, g_ref) < RTOL, (om, g, g_ref)
+        assert rel_scalar(fe.eval(om, False)[0], c_ref) < RTOL
+    om = np.array([0.3, -0.5, 0.2])
+    iwe, d = fe.computeImageOfWarpedEvents(om, want_deriv=True)
+    iwe_ref, d_ref = ref.iwe(om, deriv=True)
+    assert rel_img(iwe, iwe_ref) < RTOL and rel_img(d, d_ref) < RTOL
+    assert rel_img(fe.computeImageOfWarpedEvents(om, blur=False), ref.iwe(om, blur=False)) < RTOL
+
+
+def test_config1_solve_from_zero(hip, oracle, c1):
+    """ecrot_synth's single angular-velocity window: the FR-CG solve from omega = 0 over the HIP evaluator lands where
+    the same driver lands over the oracle (and both near the true motion)."""
+    from cmax_slam_amd import solver
+    p = c1
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe.set_fast_path()
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+
+    def fdf(x, wg):
+        c, g = ref.eval(x, wg)
+        return -c, (-g if wg else None)
+    x_ref, rep_ref = solver.frcg_minimize(fdf, np.zeros(3), **solver.FRONTEND)
+    x, rep = fe.setupProblemAndOptimize(np.zeros(3))
+    assert rep["initial_cost"] == pytest.approx(rep_ref["initial_cost"], rel=1e-6)
+    # The driver's loose stopping rules (tolfun 1e-4) turn 1e-8 differences of the sums into different stopping points
+    # (DESIGN.md section 10), so the two solves are compared by what they reach, not iterate by iterate:
+    assert abs(rep["final_cost"] - rep_ref["final_cost"]) < 2e-3 * abs(rep_ref["final_cost"]), (rep, rep_ref)
+    assert np.abs(x - x_ref).max() < 0.05, (x, x_ref)
+    assert np.abs(x[:2] - p.omega_true[:2]).max() < 0.05 and np.abs(x_ref[:2] - p.omega_true[:2]).max() < 0.05
+    assert rep["status"] in (0, -2) and 2 <= rep["iterations"] <= 50
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+WORLD, PER_GPU = 8, 5_000_000
+
+
+@pytest.fixture(scope="module")
+def c4():
+    slabs = [synth.config4_slab(r, WORLD, PER_GPU) for r in range(WORLD)]
+    return slabs, synth.concat_slabs(slabs)
+
+
+def _set(be, w, x=None, y=None, t=None):
+    x, y, t = (w.x, w.y, w.t_ns) if x is None else (x, y, t)
+    be.set_window(x, y, t, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE)
+
+
+def test_config4_whole_window_on_one_gpu(hip, oracle, c4):
+    slabs, w = c4
+    assert len(w.x) == 40_000_000 and (w.Wp, w.Hp, w.order, w.K, w.num_fixed, w.P) == (1024, 1024, 4, 10, 3, 21)
+    d = np.random.default_rng(41).normal(0, 0.004, w.P)
+    fast = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    fast.set_fast_path()
+    fast.set_option(_lib.OPT_REUSE_IMAGE, 0)
+    _set(fast, w)
+    c, g = fast.eval(d)
+    il_old, il_new = fast.get_plane(_lib.PLANE_IL_OLD), fast.get_plane(_lib.PLANE_IL_NEW)
+    # (1) the CPU oracle on all 40M events (seconds per evaluation: 22 planes of 1024^2)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, w.batch, w.sample_rate, w.sigma, oracle.VARIANCE)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    c_ref, g_ref = ref.eval(d)
+    assert rel_scalar(c, c_ref) < RTOL, (c, c_ref)
+    assert rel_vec(g, g_ref) < RTOL, (g, g_ref)
+    assert rel_img(il_old, ref.IL_old) < RTOL and rel_img(il_new, ref.IL_new) < RTOL
+    assert rel_scalar(fast.eval(d, False)[0], c_ref) < RTOL
+    # (2) the reference-shaped GPU path (derivative planes, one global atomic per vote)
+    slow = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    _set(slow, w)
+    c2, g2 = slow.eval(d)
+    slow.close()
+    assert rel_scalar(c2, c_ref) < RTOL and rel_vec(g2, g_ref) < RTOL
+    # (3) the eight batch-range shards of the 8-GPU run accumulate to the whole window
+    acc_old, acc_new = np.zeros_like(il_old, dtype=np.float64), np.zeros_like(il_new, dtype=np.float64)
+    h = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    h.set_fast_path()
+    for r in range(WORLD):
+        beg, end = dist.batch_range(len(w.x), w.batch, r, WORLD)
+        assert (beg, end) == (r * PER_GPU, (r + 1) * PER_GPU)   # a rank's shard is exactly its time slab
+        assert np.array_equal(w.x[beg:end], slabs[r].x) and np.array_equal(w.t_ns[beg:end], slabs[r].t_ns)
+        _set(h, w, w.x[beg:end], w.y[beg:end], w.t_ns[beg:end])
+        h.accumulate(d, False)
+        acc_old += h.get_plane(_lib.PLANE_IL_OLD)
+        acc_new += h.get_plane(_lib.PLANE_IL_NEW)
+    assert rel_img(acc_old, il_old) < RTOL and rel_img(acc_new, il_new) < RTOL
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_config4_one_rank_shard_vs_oracle(hip, oracle, c4, rank):
+    """What ONE rank of the 8-GPU run computes before the exchange (its partial planes) and what it would return if it
+    were alone (contrast + gradient of its 5M events), against the oracle on the same shard."""
+    slabs, w = c4
+    s = slabs[rank]
+    d = np.random.default_rng(42 + rank).normal(0, 0.004, w.P)
+    be = hip.BackendEvaluator(s.W, s.H, s.lut, s.Wp, s.Hp)
+    be.set_fast_path()
+    _set(be, s)
+    ref = oracle.Backend(s.W, s.H, s.lut, s.Wp, s.Hp, s.order, s.batch, s.sample_rate, s.sigma, oracle.VARIANCE)
+    ref.set_window(s.x, s.y, s.t_ns, s.knots_init, s.start_ns, s.dt_ns, s.num_fixed, s.t_next_win_beg_ns)
+    c_ref, g_ref = ref.eval(d)
+    c, g = be.eval(d)
+    assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
+    assert rel_img(be.get_plane(_lib.PLANE_IL_OLD), ref.IL_old) < RTOL
+    assert rel_img(be.get_plane(_lib.PLANE_IL_NEW), ref.IL_new) < RTOL
+    # a rank's events only reach the derivative planes of the control poses its time range supports
+    touched = np.abs(g_ref) > 0
+    assert touched.sum() < w.P if rank in (0, 7) else touched.any()

@@ -53,3 +53,20 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     assert bench.alg_bytes_per_event("frontend", 0, "splat", False) == 156
     assert bench.alg_bytes_per_event("backend", 4, "splat", False) == 444
     assert bench.alg_bytes_per_event("backend", 2, "splat", False) == 252
+
+
+def test_config4_slabs_concatenate_into_one_window_and_match_batch_range():
+    from cmax_slam_amd import dist
+    world, per = 4, 3000
+    slabs = [synth.config4_slab(r, world, per) for r in range(world)]
+    w = synth.concat_slabs(slabs)
+    assert len(w.x) == world * per and np.all(np.diff(w.t_ns) >= 0)
+    for r in range(world):
+        assert dist.batch_range(len(w.x), w.batch, r, world) == (r * per, (r + 1) * per)
+        assert np.array_equal(slabs[r].knots_init, slabs[0].knots_init)      # one trajectory, one window description
+        assert slabs[r].t_next_win_beg_ns == slabs[0].t_next_win_beg_ns
+        T = 0.35e9
+        assert slabs[r].t_ns.min() >= w.start_ns + int(T * r / world) and slabs[r].t_ns.max() < w.start_ns + T * (r + 1) / world + 1
+    # without slabs the generator is unchanged (the committed regression vectors depend on it)
+    a, b = synth.config3(2000), synth.config3(2000)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.t_ns, b.t_ns)
