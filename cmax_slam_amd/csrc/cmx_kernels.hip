@@ -339,6 +339,8 @@ struct alignas(16) FinSmem {  // a multiple of 16 bytes: static LDS in front of 
   double shp[16];
   double outv[2 + 3 * kMaxKnots];  // results are staged here and written to the mapped host buffer by ONE wave,
                                    // contiguously: scattered lane writes over PCIe cost ~0.5 us each
+  double cols[2 * 3 * kMaxKnots];  // per-column sums of the gather partial table: S1 (gP) then S2 (gP)
+  double colw[16][8];              // per-wave partial column sums (many-rows form)
   double shfall;
   unsigned long long shchk;
   int is_last;
@@ -414,26 +416,72 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
       const double eD = a.sums[2 + 2 * k] / N, eID = a.sums[3 + 2 * k] / N;
       sm.outv[2 + k] = (a.measure == 1) ? 2.0 * eID : 2.0 * (eID - mu * eD);
     }
-    // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP)
-    for (int k = wave; k < a.gP; k += NW) {
-      double s = 0, s2 = 0;
-      const double *r1 = a.gpartials + (size_t)k * a.gblocks;
-      const double *r2 = a.gpartials + (size_t)(a.gP + k) * a.gblocks;
-      int b = lane;
-      for (; b + 192 < a.gblocks; b += 256) {  // 4 (x2) independent loads per lane in flight
-        const double v0 = ld_sc1(r1 + b), v1 = ld_sc1(r1 + b + 64), v2 = ld_sc1(r1 + b + 128), v3 = ld_sc1(r1 + b + 192);
-        double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (a.mu_free) { w0 = ld_sc1(r2 + b); w1 = ld_sc1(r2 + b + 64); w2 = ld_sc1(r2 + b + 128); w3 = ld_sc1(r2 + b + 192); }
-        s += (v0 + v1) + (v2 + v3);
-        s2 += (w0 + w1) + (w2 + w3);
+    // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP).
+    // ONE workgroup reads tables other CUs wrote: every load is a ~1-2 us round trip to memory / a remote L2, so what
+    // matters is how many are in flight.  Many rows, few columns (front end: ~1000 x 6): all threads stride over the rows
+    // with one accumulator per column -- every thread's loads go out in one round.  Few rows, many columns (back end:
+    // ~200 x 42): each wave takes whole columns, four at a time.
+    const int ncol = a.mu_free ? 2 * a.gP : a.gP;
+    if (a.gP > 0 && ncol <= 8) {
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b0 = 0; b0 < a.gblocks; b0 += 2 * NT) {
+        // branch-free: every load of the round is issued before the first use (a predicated load inside the accumulation
+        // made the compiler wait for each one: 16 serial ~1 us round trips)
+        double v[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b = b0 + u * NT + t;
+          const int bb = b < a.gblocks ? b : 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[u][j] = ld_sc1(a.gpartials + (size_t)(j < ncol ? j : 0) * a.gblocks + bb);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const bool ok = b0 + u * NT + t < a.gblocks;
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[j] += (ok && j < ncol) ? v[u][j] : 0.0;
+        }
       }
-      for (; b < a.gblocks; b += 64) {
-        s += ld_sc1(r1 + b);
-        if (a.mu_free) s2 += ld_sc1(r2 + b);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const double w = wave_sum(acc[j]);
+        if (lane == 0) sm.colw[wave][j] = w;
       }
-      s = wave_sum(s);
-      s2 = wave_sum(s2);
-      if (lane == 0) sm.outv[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
+      __syncthreads();
+      if (t < ncol) {
+        double w = 0;
+        for (int q = 0; q < NW; q++) w += sm.colw[q][t];
+        sm.cols[t] = w;
+      }
+    } else {
+      for (int k0 = wave; k0 < ncol; k0 += 4 * NW) {  // this wave's columns k0, k0 + NW, k0 + 2 NW, k0 + 3 NW
+        double acc[4] = {0, 0, 0, 0};
+        const double *r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = a.gpartials + (size_t)min(k0 + j * NW, ncol - 1) * a.gblocks;
+        int b = lane;
+        for (; b + 192 < a.gblocks; b += 256) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const double v0 = ld_sc1(r[j] + b), v1 = ld_sc1(r[j] + b + 64), v2 = ld_sc1(r[j] + b + 128), v3 = ld_sc1(r[j] + b + 192);
+            acc[j] += (v0 + v1) + (v2 + v3);
+          }
+        }
+        for (; b < a.gblocks; b += 64) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] += ld_sc1(r[j] + b);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double v = wave_sum(acc[j]);
+          if (lane == 0 && k0 + j * NW < ncol) sm.cols[k0 + j * NW] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = t; k < a.gP; k += NT) {
+      const double s = sm.cols[k], s2 = a.mu_free ? sm.cols[a.gP + k] : 0.0;
+      sm.outv[2 + k] = 2.0 * (s - ((a.mu_free && a.measure != 1) ? mu * s2 : 0.0)) / N;
     }
   }
   __syncthreads();
@@ -455,7 +503,9 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   if (t <= nout) atomicXor(&sm.shchk, bits);
   __syncthreads();
   if (t == 0) {
-    volatile unsigned long long *slots = reinterpret_cast<volatile unsigned long long *>(a.result);
+    // plain stores, no wait between them: the host accepts a snapshot only when ticket AND checksum match what it read, so
+    // the order in which these words cross PCIe does not matter (volatile stores made the compiler drain each one)
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(a.result);
     slots[kChecksumSlot] = sm.shchk ^ (a.ticket * kTicketMix);
     slots[kTicketSlot] = a.ticket;
   }
@@ -492,7 +542,9 @@ __device__ __forceinline__ bool tail_arrive(const TailArgs &tl, int nblocks, int
         last = 1;
       }
     }
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale lines of the partial tables
+    // no acquire fence (buffer_inv, ~1.7 us): everything the finalize reads from THIS launch was stored write-through and
+    // is loaded with sc1 (L1-bypassing, agent-scope) loads -- Guideline 16: "sc1 loads may replace the acquire only when
+    // the producer stored sc1"; data of earlier launches is ordered by the kernel boundary
     sm.is_last = last;
   }
   __syncthreads();

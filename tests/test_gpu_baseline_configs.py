@@ -67,7 +67,8 @@ def test_config1_solve_from_zero(hip, oracle, c1):
     # (DESIGN.md section 10), so the two solves are compared by what they reach, not iterate by iterate:
     assert abs(rep["final_cost"] - rep_ref["final_cost"]) < 2e-3 * abs(rep_ref["final_cost"]), (rep, rep_ref)
     assert np.abs(x - x_ref).max() < 0.05, (x, x_ref)
-    assert np.abs(x[:2] - p.omega_true[:2]).max() < 0.05 and np.abs(x_ref[:2] - p.omega_true[:2]).max() < 0.05
+    # (the stagnation rule stops this 0.05 s window ~0.2 rad/s short of the true motion -- over the oracle just the same)
+    assert np.abs(x[:2] - p.omega_true[:2]).max() < 0.3 and np.abs(x_ref[:2] - p.omega_true[:2]).max() < 0.3   # (roll is weakly observable)
     assert rep["status"] in (0, -2) and 2 <= rep["iterations"] <= 50
 
 
