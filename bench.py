@@ -1,15 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X event-warping path (BASELINE.json metric).
 
-A "step" is one full cost+gradient evaluation (what local_contrast_fdf does once: warp + splat every event of
-the packet, blur, variance and its analytic gradient) over one batch of synthetic input:
-  N = 1 : BASELINE config 2 -- 1M synthetic events, 640x480 IWE, front-end CMax, on one MI355X.
-  N > 1 : the same problem scaled to N x 1M events over the same 0.05 s packet, sharded by contiguous event-batch
-          ranges, one process per GPU, RCCL all-reduce of the partial planes between splat and blur (weak scaling).
-`value` = events warped by all ranks per second, inputs resident in HBM before the timed region.
+A "step" is one full cost+gradient evaluation (what local_contrast_fdf / global_contrast_fdf do once: warp + splat every
+event, blur, contrast and its analytic gradient) over one batch of synthetic input resident in HBM.  The timed loop
+cycles the parameters through points of a RECORDED solve trajectory, so the destination-tile sort of the first
+evaluation sees the drift a real solve produces (votes leaving their LDS windows, re-sorts).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend|backend] [--no-cpu-baseline]
-Rank 0 prints ONE JSON line.
+  N = 1 (default) : `value` = BASELINE config 2 -- 1M synthetic events, 640x480 IWE, front-end CMax, one MI355X.
+                    Nested in the same JSON line: "backend" = BASELINE config 3 (5M events, cubic 10-knot spline,
+                    1024x1024 panorama) measured the same way.
+  N > 1 (torchrun): `value` = BASELINE config 4 -- back-end BA window, 5M events PER GPU (40M on 8), sharded by contiguous
+                    event-batch ranges, one process per GPU, RCCL all-reduce of the partial panoramas between splat and
+                    blur and of the 2P partial gradient sums after the gather (weak scaling).  Nested: "config5" = 20M
+                    events / 8 per GPU, 1280x720 sensor, 4096x2048 map.  --workload frontend keeps round 1's front-end
+                    variant (N x 1M events over one packet).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|frontend|backend] [--no-backend] [--no-cpu-baseline]
+Rank 0 prints ONE JSON line.  Every number is measured in this run except `roofline.traffic` / `kernels[].pmc_bytes`,
+which are read from profiles/pmc_traffic.json (rocprofv3 --pmc passes of this same command, see profiles/README.md).
 """
 import argparse
 import json
@@ -23,269 +31,358 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "warped-events/sec/GPU (1M ev, 640x480 IWE) + CMax iters/sec"
 
 
-def alg_bytes_per_event(workload, order, kernel, adjoint):
-    """ALGORITHMIC bytes per warped event:
-    splat : 4 B packed coords + 24 B fp64 LUT gather + 4 px x (4 B read + 4 B write) per image the event votes into
-            (1 image with the adjoint gradient; 1 + 3 / 1 + 3n with derivative planes);
-    gather: 4 B + 24 B + 4 px x 4 B read of Itilde (adjoint gradient only)."""
-    if kernel == "gather":
-        return 4 + 24 + 4 * 4
-    imgs = 1
-    if not adjoint:
-        imgs += 3 if workload == "frontend" else 3 * order
-    return 4 + 24 + imgs * 4 * 8
+# ---------------------------------------------------------------------------------------------- byte models
+def byte_models(kind, order, n_events, npix, nb, P, adjoint, nnz_pixels):
+    """Per kernel class and per launch: (algorithmic bytes, HBM-mandatory bytes).
 
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="frontend", choices=["frontend", "backend"])
-    ap.add_argument("--events", type=int, default=None, help="events per GPU (default: config's own)")
-    ap.add_argument("--mode", default="fast", choices=["fast", "faithful"],
-                    help="fast = adjoint gradient + LDS-privatised splat (production path); faithful = derivative planes + "
-                         "one global atomic per vote (the reference's data flow)")
-    ap.add_argument("--comm", default="native", choices=["native", "torch"],
-                    help="N>1 exchange: native = RCCL communicator inside the evaluator (all-reduces issued from C++ on the "
-                         "context's stream); torch = torch.distributed.all_reduce on evaluator-owned torch tensors")
-    ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check-parity", action="store_true", help="also at N=1: re-evaluate on a fresh evaluator and report the difference (always on for N>1)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-
-    import torch
-    import torch.distributed as dist
-    from cmax_slam_amd import _lib, evaluator, synth
-    from cmax_slam_amd.dist import ShardedEvaluator, attach_torch_accum, batch_range
-
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    adjoint = args.mode == "fast"
-    # ------------------------------------------------------------------ synthetic workload (seeded)
-    if args.workload == "frontend":
-        per_gpu = args.events or 1_000_000
-        p = synth.config2(per_gpu * world)
-        beg, end = batch_range(len(p.x), p.batch, rank, world)
-        ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=local_rank)
-        ev.set_packet(p.x[beg:end], p.y[beg:end], p.t_ns[beg:end], p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma,
-                      _lib.VARIANCE)
-        x0 = np.array([0.3, -0.5, 0.2])  # a mid-solve angular velocity (omega_true = 0.6,-0.9,0.4)
-        order = 0
-        name = "cmax_slam front-end fdf: %d synthetic events/GPU, 640x480 IWE, batch 100, sigma 1, variance" % per_gpu
-        n_total, img = len(p.x), "%dx%d" % (p.W, p.H)
-        workload_obj = p
-    else:
-        per_gpu = args.events or 5_000_000
-        w = synth.config3(per_gpu * world)
-        beg, end = batch_range(len(w.x), w.batch, rank, world)
-        ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=local_rank)
-        ev.set_window(w.x[beg:end], w.y[beg:end], w.t_ns[beg:end], w.order, w.knots_init, w.start_ns, w.dt_ns,
-                      w.num_fixed, w.t_next_win_beg_ns, w.batch, w.sample_rate, w.sigma, _lib.VARIANCE)
-        x0 = np.zeros(w.P)
-        order = w.order
-        name = "cmax_slam back-end BA fdf: %d synthetic events/GPU, cubic 10-knot SO(3) spline (P=21), 1024x1024 pano" % per_gpu
-        n_total, img = len(w.x), "%dx%d" % (w.Wp, w.Hp)
-        workload_obj = w
+    ALGORITHMIC = SURVEY.md section 8(d): per warped event 4 B coordinates + 24 B fp64 bearing + 4 px x (4 B read + 4 B
+    write) per image voted into; the gather pass 4 + 24 + 4 px x 4 B; image passes W*H*4 B per plane touch.
+    HBM-MANDATORY = the bytes that have to cross the memory interface at least once per launch given the data layout
+    actually used: the coalesced per-event streams, one read / write of every plane a kernel
+    consumes / produces, one 4-byte write per non-zero IWE pixel for the LDS-window flush.  Vote read-modify-writes live
+    in LDS and table gathers hit L2, so they are not in it.  `frac` (mandatory bytes / time / peak) can therefore never exceed 1."""
+    fe = kind == "frontend"
+    imgs = 1 if adjoint else (1 + (3 if fe else 3 * order))
+    planes_in = 1 if fe else 2
+    m = {}
+    m["splat"] = (n_events * (4 + 24 + imgs * 32),
+                  n_events * 24 + nnz_pixels * 4 + (0 if fe else nb * 72))
+    #   front end: bearing 16 B + dt 8 B per event (streams in tile order); back end: packed event 4 B + batch index 4 B +
+    #   bearing 16 B per event, the 72-byte rotation of every batch once
     if adjoint:
-        ev.set_fast_path()       # the library's default, set explicitly
+        m["gather"] = (n_events * (4 + 24 + 16),
+                       n_events * (24 if fe else 20) + npix * 4 + (0 if fe else nb * 72 + nb * 48))
+        m["image"] = (npix * 4 * (planes_in + 1 + planes_in), npix * 4 * (planes_in + 1 + planes_in))
+        #   read the vote plane(s), write Jt, clear the ping-pong partner's plane(s)
     else:
-        ev.set_reference_path()  # derivative planes + one global atomic per vote
-    # every timed step is a FULL evaluation: the df-after-f image reuse (on by default, used by the solver) is off here
-    ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+        m["image"] = (npix * 4 * 6 * (1 + P), npix * 4 * (planes_in + P))
+    m["image_f"] = (npix * 4 * 2 * planes_in, npix * 4 * 2 * planes_in)  # cost-only: read the plane(s), clear the partner
+    if not fe:
+        m["pose"] = (nb * (8 + 72 + 152), nb * (8 + 72 + 152))
+        m["batch"] = (nb * (48 + 152), nb * (48 + 152))
+    m["final"] = (0, 0)
+    return m
 
-    comm_used = "none"
-    if world > 1:
-        if args.comm == "native":
+
+def whole_eval_bytes_8d(kind, order, n_events, npix, P):
+    """SURVEY.md section 8(d)'s whole-evaluation figure for one fdf of the REFERENCE's data flow: N * B_ev + planes * W*H*4*6."""
+    per_ev = {"frontend": 156, "backend2": 252, "backend4": 444}["frontend" if kind == "frontend" else "backend%d" % order]
+    return n_events * per_ev + (1 + P) * npix * 4 * 6
+
+
+# ---------------------------------------------------------------------------------------------- measurement core
+class Runner:
+    """One evaluator + its exchange path; knows how to run an fdf / cost-only step at a given parameter vector."""
+
+    def __init__(self, ev, world, comm_mode, device, torch, dist, force=False):
+        self.ev, self.world, self.torch, self.dist, self.device = ev, world, torch, dist, device
+        self.comm_used = "none"
+        self.sh = self.stream = None
+        if world > 1 or force:  # force: the sharded code path with a 1-rank communicator (--force-sharded, a dry run)
+            self._attach(comm_mode)
+
+    def _attach(self, comm_mode):
+        torch, dist, ev = self.torch, self.dist, self.ev
+        from cmax_slam_amd.dist import ShardedEvaluator, attach_torch_accum
+        rank = dist.get_rank()
+        mode = comm_mode
+        if mode == "native":
             try:
-                idt = torch.zeros(128, dtype=torch.uint8, device=device)
+                idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
                 if rank == 0:
                     idt.copy_(torch.frombuffer(bytearray(ev.comm_unique_id()), dtype=torch.uint8))
                 dist.broadcast(idt, src=0)
-                ev.comm_attach(bytes(idt.cpu().numpy().tobytes()), rank, world)
-                comm_used = "native RCCL communicator inside the evaluator"
+                ev.comm_attach(bytes(idt.cpu().numpy().tobytes()), rank, self.world)
+                self.comm_used = "native RCCL communicator inside the evaluator"
             except Exception as e:  # keep the run alive: fall back to torch.distributed on evaluator-owned tensors
-                comm_used = "torch.distributed (native attach failed: %s)" % e
-                args.comm = "torch"
-            # all ranks must take the same exchange path: one failed attach moves everybody to the torch path
-            ok = torch.tensor([1 if args.comm == "native" else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and args.comm == "native":
+                self.comm_used = "torch.distributed (native attach failed: %s)" % e
+                mode = "torch"
+            ok = torch.tensor([1 if mode == "native" else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks must take the same exchange path
+            if int(ok.item()) == 0 and mode == "native":
                 ev.comm_detach()
-                comm_used = "torch.distributed (native attach failed on another rank)"
-                args.comm = "torch"
-        if args.comm == "torch":
-            accum, gsum, stream = attach_torch_accum(ev, device)
-            sh = ShardedEvaluator(ev, accum, gsum)
-            if comm_used == "none":
-                comm_used = "torch.distributed.all_reduce (RCCL) in place on the evaluator's planes"
-            def step():
-                with torch.cuda.stream(stream):
-                    return sh.eval(x0, True)
-        else:
-            def step():
-                return ev.eval(x0, True)
-    else:
-        def step():
-            return ev.eval(x0, True)
+                self.comm_used = "torch.distributed (native attach failed on another rank)"
+                mode = "torch"
+        if mode == "torch":
+            accum, gsum, self.stream = attach_torch_accum(ev, self.device)
+            self.sh = ShardedEvaluator(ev, accum, gsum)
+            if self.comm_used == "none":
+                self.comm_used = "torch.distributed.all_reduce (RCCL) in place on the evaluator's planes"
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(self, x, want_grad=True):
+        if self.sh is not None:
+            with self.torch.cuda.stream(self.stream):
+                return self.sh.eval(x, want_grad)
+        return self.ev.eval(x, want_grad)
 
-    for _ in range(args.warmup):
-        step()
-    # calibration (untimed): HIP events around every kernel class -> per-class durations, pick the dominant
-    # per-event kernel; the timed region then records events around that kernel only (2 event records per step)
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def record_trajectory(ev, x0, kind, params, max_points=8):
+    """Evaluation points of one real FR-CG solve (the restated driver over THIS evaluator, python callbacks, untimed),
+    thinned to <= max_points spread over the solve: first point, accepted iterates, trial points, last point."""
+    from cmax_slam_amd import solver
+    pts = []
+
+    def fdf(x, wg):
+        pts.append(np.array(x, dtype=np.float64))
+        c, g = ev.eval(x, wg)
+        return -c, (-g if wg else None)
+    solver.frcg_minimize(fdf, x0, **params)
+    uniq = []
+    for p in pts:
+        if not any(np.array_equal(p, q) for q in uniq):
+            uniq.append(p)
+    if len(uniq) > max_points:
+        idx = np.unique(np.round(np.linspace(0, len(uniq) - 1, max_points)).astype(int))
+        uniq = [uniq[i] for i in idx]
+    return uniq
+
+
+def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb, P, adjoint, pmc_prefix):
+    """Warm-up, per-kernel calibration (HIP events carried by every kernel class), then the timed region (EXACTLY `steps`
+    fdf evaluations between two fences, dominant kernel timed live on every 4th), then the cost-only loop."""
+    ev = run.ev
+    npts = len(points)
+    for i in range(warmup):
+        run.step(points[i % npts], True)
+    # ---- calibration (untimed): every kernel class, fdf then cost-only
+    ncal = max(2 * npts, 8)
     ev.timing_enable(True)
     ev.timing_get()
-    for _ in range(max(3, args.warmup // 2)):
-        step()
-    torch.cuda.synchronize()
-    tim_all = ev.timing_get()
-    kernel_ms = {k: (v[0] / v[1]) for k, v in tim_all.items() if v[1]}
-    dom = max((k for k in ("splat", "gather") if k in kernel_ms), key=lambda k: kernel_ms[k])
-    # HIP events carried by the dominant kernel itself on the stream it is launched on, every 4th timed step (an
-    # event-carrying launch costs ~1.5 us; the other three quarters of the steps run exactly as in production)
+    for i in range(ncal):
+        run.step(points[i % npts], True)
+    run.torch.cuda.synchronize()
+    cal = ev.timing_get()
+    for i in range(ncal):
+        run.step(points[i % npts], False)
+    run.torch.cuda.synchronize()
+    cal_f = ev.timing_get()
+    kernel_ms = {k: v[0] / v[1] for k, v in cal.items() if v[1] and k not in ("zero",)}
+    kernel_ms_f = {k: v[0] / v[1] for k, v in cal_f.items() if v[1] and k not in ("zero",)}
+    per_eval = {k: v[1] / ncal for k, v in cal.items() if v[1]}
+    compute = [k for k in kernel_ms if k != "comm"]
+    dom = max(compute, key=lambda k: kernel_ms[k])
+    # ---- timed region
     ev.timing_enable([dom], every=4)
-    fence()
+    run.fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        c, g = step()
-    fence()
+    for i in range(steps):
+        c, g = run.step(points[i % npts], True)
+    run.fence()
     elapsed = time.perf_counter() - t0
     tim = ev.timing_get()
     ev.timing_enable(False)
-    # extra (not `value`): the cost-only evaluation local_contrast_f performs, timed the same way
-    def step_f():
-        if world > 1 and args.comm == "torch":
-            with torch.cuda.stream(stream):
-                return sh.eval(x0, False)
-        return ev.eval(x0, False)
-    for _ in range(3):
-        step_f()
-    fence()
+    stats = ev.stats()
+    for i in range(3):
+        run.step(points[i % npts], False)
+    run.fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_f()
-    fence()
+    for i in range(steps):
+        run.step(points[i % npts], False)
+    run.fence()
     elapsed_f = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed, elapsed_f], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if run.world > 1:
+        t = run.torch.tensor([elapsed, elapsed_f], dtype=run.torch.float64, device=run.device)
+        run.dist.all_reduce(t, op=run.dist.ReduceOp.MAX)
         elapsed, elapsed_f = float(t[0].item()), float(t[1].item())
+    if tim[dom][1] > 0:
+        kernel_ms[dom] = tim[dom][0] / tim[dom][1]  # measured live inside the timed region
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_total * args.steps / elapsed
-        ev_per_launch = end - beg
-        # dominant per-event kernel = the longer of splat / gather (image passes are per-pixel, listed in kernel_ms)
-        bpe = alg_bytes_per_event(args.workload, order, dom, adjoint)
-        if tim[dom][1] > 0:
-            avg_ms = tim[dom][0] / tim[dom][1]  # measured live over the timed region
-            kernel_ms[dom] = avg_ms
-        else:  # fewer timed steps than the sampling period: the calibration steps' average stands in
-            avg_ms = kernel_ms[dom]
-        achieved = ev_per_launch * bpe / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("%s_%s_%s" % (args.workload, args.mode, dom))
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "warped-events/sec/GPU (1M ev, 640x480 IWE) + CMax iters/sec",
-            "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 warp / f32 accumulate", "data": "synthetic",
-            "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)",
-                       "mode": args.mode + (" (adjoint gradient, LDS-privatised splat)" if adjoint else
-                                            " (derivative planes, global atomics)"), "parallelism": ("events sharded by batch range x%d, all-reduce of partial planes + partial gradient sums; %s"
-                                       % (world, comm_used)) if world > 1 else "single GPU"},
-            "per_gpu_value": value / world,
-            "cost_only": {"value": n_total * args.steps / elapsed_f, "unit": "events/s", "ms_per_step": elapsed_f / args.steps * 1e3},
-            "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_event": bpe, "events_per_launch": int(ev_per_launch), "avg_launch_ms": avg_ms},
-            "contrast": c,
-        }
-        if world > 1 and "comm" in kernel_ms:
-            # RCCL collectives of one evaluation as seen by rank 0 on its stream (calibration steps, every span timed):
-            # the exchange itself plus the wait for the slowest rank
-            n_comm = tim_all["comm"][1] / max(tim_all[dom][1], 1)
-            out["comm"] = {"ms_per_step": kernel_ms["comm"] * n_comm, "collectives_per_step": n_comm,
-                           "share_of_step": kernel_ms["comm"] * n_comm / ms_per_step}
-        if world > 1 or args.check_parity:
-            # parity of the sharded evaluation with the whole problem on ONE GPU (rank 0, untimed, after the timed region)
-            try:
-                out["parity_vs_1gpu"] = parity_vs_single_gpu(args, evaluator, _lib, workload_obj, x0, adjoint, local_rank, c, g)
-            except Exception as e:
-                out["parity_vs_1gpu"] = {"error": str(e)}
-        if world == 1 and args.solves > 0:
-            out["cmax"] = cmax_solves(args, ev, workload_obj, _lib)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, workload_obj, x0)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    # ---- per-kernel roofline table
+    nnz = getattr(run, "nnz_pixels", 0)
+    models = byte_models(kind, order, n_local, npix, nb, P, adjoint, nnz)
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pass
+    kernels = []
+    for k in sorted(kernel_ms, key=lambda k: -kernel_ms[k]):
+        if k == "comm":
+            continue
+        alg, mand = models.get(k, (0, 0))
+        ms = kernel_ms[k]
+        row = {"kernel": k, "ms": ms, "launches_per_eval": per_eval.get(k, 1.0), "alg_bytes": alg,
+               "hbm_mandatory_bytes": mand, "pmc_bytes": pmc.get("%s_%s" % (pmc_prefix, k)),
+               "frac": mand / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+               "ratio_8d_bytes_to_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+        if row["pmc_bytes"]:
+            row["frac_pmc"] = row["pmc_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        kernels.append(row)
+    ms_step = elapsed / steps * 1e3
+    dom_alg, dom_mand = models.get(dom, (0, 0))
+    dms = kernel_ms[dom]
+    # the honest per-launch figure: mandatory bytes (<= algorithmic) over the live duration; `frac` <= 1 by construction
+    achieved = dom_mand / (dms * 1e-3) / 1e9
+    mand_eval = sum(models.get(k, (0, 0))[1] * per_eval.get(k, 1.0) for k in kernel_ms if k != "comm")
+    out = {
+        "ms_per_step": ms_step,
+        "value": n_total * steps / elapsed,
+        "cost_only": {"value": n_total * steps / elapsed_f, "unit": "events/s", "ms_per_step": elapsed_f / steps * 1e3,
+                      "kernel_ms": kernel_ms_f},
+        "kernel_ms": kernel_ms,
+        "kernels": kernels,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)),
+                     "model": "hbm-mandatory bytes per launch (coalesced per-event streams + one pass over each plane + one 4-byte "
+                              "write per non-zero IWE pixel) / live kernel duration",
+                     "bytes_per_launch": dom_mand, "avg_launch_ms": dms, "events_per_launch": int(n_local),
+                     "alg_bytes_per_launch_8d": dom_alg, "ratio_8d_bytes_to_peak": dom_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "ratio_8d_bytes_to_peak uses SURVEY 8(d)'s algorithmic bytes (vote read-modify-writes counted as memory "
+                             "traffic although they stay in LDS): it is not an HBM fraction and may exceed 1 for large launches"},
+        "whole_evaluation": {
+            "ms": ms_step,
+            "sum_of_kernels_ms": sum(kernel_ms[k] * per_eval.get(k, 1.0) for k in kernel_ms if k != "comm"),
+            "hbm_mandatory_bytes": mand_eval,
+            "frac": mand_eval / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "alg_bytes_8d_reference_flow": whole_eval_bytes_8d(kind, order, n_local, npix, P),
+            "ratio_8d_bytes_to_peak": whole_eval_bytes_8d(kind, order, n_local, npix, P) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "ratio_8d_bytes_to_peak prices the REFERENCE's data flow (1+P planes scattered, blurred, reduced) at this run's time: the "
+                    "adjoint gradient never moves most of those bytes; frac is what this implementation must move"},
+        "trajectory_points": npts, "rebins": stats["rebins"], "fallback_frac_last": stats["fallback_frac"],
+        "contrast": c,
+    }
+    if "comm" in kernel_ms:
+        n_comm = cal["comm"][1] / ncal
+        out["comm"] = {"ms_per_step": kernel_ms["comm"] * n_comm, "collectives_per_step": n_comm,
+                       "share_of_step": kernel_ms["comm"] * n_comm / ms_step,
+                       "note": "RCCL collectives as seen on rank 0's stream in the calibration steps: the exchange plus the wait "
+                               "for the slowest rank"}
+    out["_last"] = (c, g)
+    return out
 
 
-def parity_vs_single_gpu(args, evaluator, _lib, obj, x0, adjoint, device, c_sharded, g_sharded):
-    """The same N x per-GPU events evaluated by one evaluator without a communicator on rank 0's GPU; relative
-    differences of contrast and gradient against what the sharded evaluation returned (fp32 vote order only)."""
-    if args.workload == "frontend":
-        one = evaluator.FrontendEvaluator(obj.W, obj.H, obj.lut, device=device)
-        one.set_packet(obj.x, obj.y, obj.t_ns, obj.t_ref_ns, obj.fx, obj.fy, obj.cx, obj.cy, obj.batch, obj.sigma, _lib.VARIANCE)
+# ---------------------------------------------------------------------------------------------- workloads
+def frontend_workload(args, ctx, per_gpu):
+    from cmax_slam_amd import _lib, evaluator, solver, synth
+    from cmax_slam_amd.dist import batch_range
+    rank, world, dev = ctx["rank"], ctx["world"], ctx["local_rank"]
+    p = synth.config2(per_gpu * world)
+    beg, end = batch_range(len(p.x), p.batch, rank, world)
+    ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=dev)
+    ev.set_packet(p.x[beg:end], p.y[beg:end], p.t_ns[beg:end], p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    adjoint = args.mode == "fast"
+    (ev.set_fast_path if adjoint else ev.set_reference_path)()
+    run = Runner(ev, world, args.comm, ctx["device"], ctx["torch"], ctx["dist"], force=ctx["sharded"])
+    if not ctx["sharded"]:
+        points = record_trajectory(ev, np.zeros(3), "frontend", solver.FRONTEND)
+    else:  # sharded: the trajectory of the whole problem is not available per rank; a line through the solve's range
+        points = [np.array([0.6, -0.9, 0.4]) * s for s in (0.0, 0.35, 0.7, 0.9, 1.0)]
+    ev.set_option(_lib.OPT_REUSE_IMAGE, 0)  # every timed step is a FULL evaluation (the df-after-f reuse is for solves)
+    iwe = ev.computeImageOfWarpedEvents(points[-1], blur=False)
+    run.nnz_pixels = int(np.count_nonzero(iwe))
+    m = measure(run, points, args.steps, args.warmup, "frontend", 0, end - beg, len(p.x), p.W * p.H, 0, 3, adjoint,
+                "frontend_%s" % args.mode)
+    name = "BASELINE config 2: front-end fdf, %d synthetic events/GPU, 640x480 IWE, batch 100, sigma 1, variance" % per_gpu
+    return ev, run, p, m, name, "%dx%d" % (p.W, p.H), points
+
+
+def prior_map_config5(ctx):
+    """Config 5's non-zero global map (alpha != 0): IL_old of a neighbouring window, scaled, computed once on rank 0 by the
+    evaluator itself and broadcast, so that every rank (and the one-GPU parity evaluator) holds the same bits."""
+    from cmax_slam_amd import _lib, evaluator, synth
+    torch, dist = ctx["torch"], ctx["dist"]
+    Wp, Hp = 4096, 2048
+    t = torch.zeros(Hp * Wp, dtype=torch.float32, device=ctx["device"])
+    if ctx["rank"] == 0:
+        prev = synth.config5(N=300_000, seed=synth.SEED0 + 55)
+        be = evaluator.BackendEvaluator(prev.W, prev.H, prev.lut, prev.Wp, prev.Hp, device=ctx["local_rank"])
+        be.set_window(prev.x, prev.y, prev.t_ns, prev.order, prev.knots_init, prev.start_ns, prev.dt_ns, prev.num_fixed,
+                      prev.t_next_win_beg_ns, prev.batch, prev.sample_rate, prev.sigma, _lib.VARIANCE)
+        be.eval(np.zeros(prev.P), False)
+        t.copy_(torch.from_numpy(np.ascontiguousarray(be.get_plane(_lib.PLANE_IL_OLD) * 2.5).reshape(-1)))
+        be.close()
+    if ctx["sharded"] and dist.is_initialized():
+        dist.broadcast(t, src=0)
+    return t.cpu().numpy().reshape(Hp, Wp)
+
+
+def backend_workload(args, ctx, which, per_gpu, steps):
+    """which = 'config3' (single window, N=1), 'config4' (time slab per rank), 'config5' (time slab per rank)."""
+    from cmax_slam_amd import _lib, evaluator, solver, synth
+    rank, world, dev = ctx["rank"], ctx["world"], ctx["local_rank"]
+    IG = None
+    if which == "config3":
+        w = synth.config3(per_gpu)
+    elif which == "config4":
+        w = synth.config4_slab(rank, world, per_gpu)
     else:
-        one = evaluator.BackendEvaluator(obj.W, obj.H, obj.lut, obj.Wp, obj.Hp, device=device)
-        one.set_window(obj.x, obj.y, obj.t_ns, obj.order, obj.knots_init, obj.start_ns, obj.dt_ns, obj.num_fixed,
-                       obj.t_next_win_beg_ns, obj.batch, obj.sample_rate, obj.sigma, _lib.VARIANCE)
-    if adjoint:
-        one.set_fast_path()
-    else:
-        one.set_reference_path()
-    c1, g1 = one.eval(x0, True)
+        w = synth.config5_slab(rank, world, per_gpu)
+        IG = prior_map_config5(ctx)
+    w.IG = IG
+    ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=dev)
+    ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE, IG)
+    adjoint = args.mode == "fast"
+    (ev.set_fast_path if adjoint else ev.set_reference_path)()
+    run = Runner(ev, world, args.comm, ctx["device"], ctx["torch"], ctx["dist"], force=ctx["sharded"])
+    if not ctx["sharded"]:
+        points = record_trajectory(ev, np.zeros(w.P), "backend", solver.BACKEND)
+    else:  # every rank must evaluate the same points: a seeded walk of the size of a solve's steps
+        rng = np.random.default_rng(77)
+        points = [np.zeros(w.P)] + [rng.normal(0, 0.004, w.P) * s for s in (0.3, 0.6, 0.9, 1.0)]
+    ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+    ev.accumulate(points[-1], False)
+    run.nnz_pixels = int(np.count_nonzero(ev.get_plane(_lib.PLANE_IL_OLD)) + np.count_nonzero(ev.get_plane(_lib.PLANE_IL_NEW)))
+    n_local = len(w.x)
+    nb = (n_local - 1 + w.batch - 1) // w.batch
+    m = measure(run, points, steps, args.warmup, "backend", w.order, n_local, n_local * world, w.Wp * w.Hp, nb, w.P, adjoint,
+                "backend_%s" % args.mode)
+    desc = {"config3": "BASELINE config 3: back-end BA fdf, %d synthetic events, cubic 10-knot SO(3) spline (P=21), 1024x1024 pano",
+            "config4": "BASELINE config 4: back-end BA sliding window fdf, %d synthetic events/GPU (time slab per rank), cubic 10-knot "
+                       "spline (P=21), 1024x1024 pano",
+            "config5": "BASELINE config 5: back-end fdf, %d synthetic events/GPU (time slab per rank), 1280x720 sensor, linear K=5 "
+                       "(P=15), 4096x2048 map"}[which] % per_gpu
+    return ev, run, w, m, desc, "%dx%d" % (w.Wp, w.Hp), points
+
+
+def parity_vs_one_gpu(ctx, kind, obj, x_first, x, c_sharded, g_sharded, args):
+    """The whole problem (all ranks' events, gathered over the process group) evaluated by ONE evaluator without a
+    communicator on rank 0; relative differences of contrast and gradient against the sharded evaluation."""
+    from cmax_slam_amd import _lib, evaluator
+    torch, dist, world, rank, device = ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["device"]
+
+    def gather(a, dt):
+        t = torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(device)
+        outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, outs, dst=0)
+        return np.concatenate([o.cpu().numpy() for o in outs]) if rank == 0 else None
+    xs, ys, ts = gather(obj.x, np.int32), gather(obj.y, np.int32), gather(obj.t_ns, np.int64)
+    if rank != 0:
+        return None
+    one = evaluator.BackendEvaluator(obj.W, obj.H, obj.lut, obj.Wp, obj.Hp, device=ctx["local_rank"])
+    one.set_window(xs.astype(np.uint16), ys.astype(np.uint16), ts, obj.order, obj.knots_init, obj.start_ns, obj.dt_ns, obj.num_fixed,
+                   obj.t_next_win_beg_ns, obj.batch, obj.sample_rate, obj.sigma, _lib.VARIANCE, getattr(obj, "IG", None))
+    (one.set_fast_path if args.mode == "fast" else one.set_reference_path)()
+    one.eval(x_first, False)  # alpha is fixed by the FIRST evaluation of a window (event_pano_warper.cpp:201-210): same point
+    c1, g1 = one.eval(x, True)
     one.close()
     g1, gs = np.asarray(g1), np.asarray(g_sharded)
     return {"contrast_rel": abs(c_sharded - c1) / abs(c1), "grad_rel_inf": float(np.abs(gs - g1).max() / np.abs(g1).max()),
-            "tolerance": 1e-5}
+            "tolerance": 1e-5, "events_total": int(len(xs))}
 
 
-def cmax_solves(args, ev, obj, _lib):
+def cmax_solves(n_solves, ev, kind, _lib):
     """CMax iterations per second: full FR-CG solves (the reference's driver loop, host C++) from the reference's own
     start (front end: omega = 0; back end: zero increments on the perturbed knots), image reuse on as in production."""
     ev.set_option(_lib.OPT_REUSE_IMAGE, 1)
     iters = evals = 0
     t0 = time.perf_counter()
-    for _ in range(args.solves):
-        if args.workload == "frontend":
-            x, rep = ev.setupProblemAndOptimize(np.zeros(3))
-        else:
-            x, rep = ev.setupProblemAndOptimize()
+    for _ in range(n_solves):
+        x, rep = ev.setupProblemAndOptimize(np.zeros(3)) if kind == "frontend" else ev.setupProblemAndOptimize()
         iters += rep["iterations"]
         evals += rep["n_f"] + rep["n_df"]
     el = time.perf_counter() - t0
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
-    return {"iters_per_s": iters / el, "evals_per_s": evals / el, "solves": args.solves, "iters_per_solve": iters / args.solves,
-            "ms_per_solve": el / args.solves * 1e3, "final_cost": rep["final_cost"], "solution": [float(v) for v in x[:6]]}
+    return {"iters_per_s": iters / el, "evals_per_s": evals / el, "solves": n_solves, "iters_per_solve": iters / n_solves,
+            "ms_per_solve": el / n_solves * 1e3, "final_cost": rep["final_cost"], "solution": [float(v) for v in x[:6]]}
 
 
 def host_cpu():
@@ -313,12 +410,12 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, obj, x0):
-    """The CPU oracle ("port": plain-C restatement of the reference path, 1 thread like the reference) timed on
-    this box's host cores on the same workload; bounded to ~args.cpu_seconds of CPU work."""
+def cpu_baseline(kind, obj, x0, seconds):
+    """The CPU oracle ("port": plain-C restatement of the reference path, 1 thread like the reference) timed on this box's
+    host cores on the same workload; bounded to ~`seconds` of CPU work."""
     from oracle import pyoracle as po
     po.build()
-    if args.workload == "frontend":
+    if kind == "frontend":
         ref = po.Frontend(obj.W, obj.H, obj.lut, obj.fx, obj.fy, obj.cx, obj.cy, obj.batch, obj.sigma, po.VARIANCE)
         ref.set_packet(obj.x, obj.y, obj.t_ns, obj.t_ref_ns)
     else:
@@ -330,7 +427,7 @@ def cpu_baseline(args, obj, x0):
         ref.eval(x0, True)
         n += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or n >= 2000:
+        if el > seconds or n >= 2000:
             break
     out = {"value": len(obj.x) * n / el, "unit": "events/s", "cores": 1, "kind": "port",
            "sample": "%d full fdf evaluations of the same %d-event workload (%.1f s), single thread like the reference"
@@ -340,9 +437,7 @@ def cpu_baseline(args, obj, x0):
     # NOT the reference -- cmax_slam runs each path on one thread -- and not `cpu_baseline.value`.
     try:
         cores = usable_cores()
-        # thread-private images cost a T-way reduction (front end 4.9 MB, back end 92 MB per thread), so the best thread
-        # count is found, not assumed: one evaluation each at cores, cores/2, ... (scratch bounded to ~3 GB)
-        cap = cores if args.workload == "frontend" else max(1, min(cores, 32))
+        cap = cores if kind == "frontend" else max(1, min(cores, 32))
         best_t, best_ms, t_try = 1, None, cap
         while t_try >= 2:
             ref.eval_allcores(x0, True, t_try)  # warm: thread pool + scratch pages
@@ -354,21 +449,162 @@ def cpu_baseline(args, obj, x0):
             elif ms > 2 * best_ms:
                 break
             t_try //= 2
-        threads = best_t
         m, t0 = 0, time.perf_counter()
         while True:
-            ref.eval_allcores(x0, True, threads)
+            ref.eval_allcores(x0, True, best_t)
             m += 1
             el2 = time.perf_counter() - t0
-            if el2 > max(2.0, args.cpu_seconds / 4) or m >= 2000:
+            if el2 > max(2.0, seconds / 4) or m >= 2000:
                 break
-        out["allcores"] = {"value": len(obj.x) * m / el2, "unit": "events/s", "cores": threads, "kind": "port + OpenMP",
+        out["allcores"] = {"value": len(obj.x) * m / el2, "unit": "events/s", "cores": best_t, "kind": "port + OpenMP",
                            "note": "not the reference (single-threaded): thread-private images + reduction; thread count = "
                                    "the fastest of usable_cores / 2^k",
                            "ms_per_step": el2 / m * 1e3, "usable_cores": cores}
     except Exception as e:  # a missing libgomp must not cost the headline line
         out["allcores"] = {"error": str(e)}
     return out
+
+
+def line(m, world, args, name, n_total, img, comm_used, mode_desc):
+    out = {
+        "metric": METRIC, "value": m["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 warp / f32 accumulate", "data": "synthetic",
+        "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)", "mode": mode_desc,
+                   "parameters": "cycled through %d points of a recorded FR-CG solve" % m["trajectory_points"],
+                   "parallelism": ("events sharded by contiguous batch range (time slab) x%d, all-reduce of the partial planes + partial "
+                                   "gradient sums; %s" % (world, comm_used)) if world > 1 else "single GPU"},
+        "per_gpu_value": m["value"] / world,
+    }
+    for k in ("cost_only", "kernel_ms", "kernels", "roofline", "whole_evaluation", "comm", "rebins", "fallback_frac_last", "contrast"):
+        if k in m:
+            out[k] = m[k]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps-backend", type=int, default=None, help="timed steps of the nested back-end leg at N=1 (default: --steps)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "frontend", "backend"],
+                    help="auto: N=1 -> front end (config 2) with the back end (config 3) nested; N>1 -> back end config 4 with "
+                         "config 5 nested.  frontend / backend force one family (N=1 backend = config 3 as the headline)")
+    ap.add_argument("--events", type=int, default=None, help="events per GPU (default: the config's own)")
+    ap.add_argument("--mode", default="fast", choices=["fast", "faithful"],
+                    help="fast = adjoint gradient + LDS-privatised splat (production path); faithful = derivative planes + "
+                         "one global atomic per vote (the reference's data flow)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"])
+    ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-backend", action="store_true", help="N=1: skip the nested config-3 leg")
+    ap.add_argument("--no-config5", action="store_true", help="N>1: skip the nested config-5 leg")
+    ap.add_argument("--no-parity", action="store_true", help="N>1: skip the parity check against one GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="dry run of the N>1 code path (time slabs, communicator, parity gather) with whatever world size is launched")
+    args = ap.parse_args()
+    if args.steps_backend is None:
+        args.steps_backend = args.steps
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from cmax_slam_amd import _lib
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    ctx = dict(rank=rank, world=world, local_rank=local_rank, device=device, torch=torch, dist=dist, sharded=sharded)
+    mode_desc = args.mode + (" (adjoint gradient, LDS-privatised splat)" if args.mode == "fast" else " (derivative planes, global atomics)")
+    family = args.workload
+    if family == "auto":
+        family = "backend" if sharded else "frontend"
+
+    out = None
+    if family == "frontend":
+        ev, run, p, m, name, img, pts = frontend_workload(args, ctx, args.events or 1_000_000)
+        if rank == 0:
+            out = line(m, world, args, name, len(p.x), img, run.comm_used, mode_desc)
+            if world == 1 and args.solves > 0:
+                out["cmax"] = cmax_solves(args.solves, ev, "frontend", _lib)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline("frontend", p, pts[len(pts) // 2], args.cpu_seconds)
+        ev.close()
+        if world == 1 and args.workload == "auto" and not args.no_backend:
+            ev, run, w, mb, name_b, img_b, pts_b = backend_workload(args, ctx, "config3", 5_000_000, args.steps_backend)
+            be = {"config": {"workload": name_b, "events_total": len(w.x), "image": img_b, "mode": mode_desc},
+                  "value": mb["value"], "unit": "events/s", "ms_per_step": mb["ms_per_step"], "steps": args.steps_backend}
+            for k in ("cost_only", "kernel_ms", "kernels", "roofline", "whole_evaluation", "rebins", "fallback_frac_last"):
+                be[k] = mb[k]
+            if args.solves > 0:
+                be["cmax"] = cmax_solves(max(1, args.solves // 2), ev, "backend", _lib)
+            if not args.no_cpu_baseline:
+                be["cpu_baseline"] = cpu_baseline("backend", w, pts_b[len(pts_b) // 2], max(3.0, args.cpu_seconds / 3))
+            out["backend"] = be
+            ev.close()
+    else:
+        which = "config4" if sharded else "config3"
+        per_gpu = args.events or 5_000_000
+        ev, run, w, m, name, img, pts = backend_workload(args, ctx, which, per_gpu, args.steps)
+        c, g = m.pop("_last")
+        par = None
+        if sharded and not args.no_parity:
+            try:
+                par = parity_vs_one_gpu(ctx, "backend", w, pts[0], pts[(args.steps - 1) % len(pts)], c, g, args)
+            except Exception as e:
+                par = {"error": str(e)}
+        if rank == 0:
+            out = line(m, world, args, name, len(w.x) * world, img, run.comm_used, mode_desc)
+            if par is not None:
+                out["parity_vs_1gpu"] = par
+            if not sharded and args.solves > 0:
+                out["cmax"] = cmax_solves(args.solves, ev, "backend", _lib)
+            if not sharded and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline("backend", w, pts[len(pts) // 2], args.cpu_seconds)
+        ev.close()
+        if sharded and not args.no_config5:
+            try:
+                ev, run, w5, m5, name5, img5, pts5 = backend_workload(args, ctx, "config5", (args.events or 20_000_000 // 8), args.steps)
+                c5, g5 = m5.pop("_last")
+                par5 = None
+                if not args.no_parity:
+                    try:
+                        par5 = parity_vs_one_gpu(ctx, "backend", w5, pts5[0], pts5[(args.steps - 1) % len(pts5)], c5, g5, args)
+                    except Exception as e:
+                        par5 = {"error": str(e)}
+                if rank == 0:
+                    o5 = line(m5, world, args, name5, len(w5.x) * world, img5, run.comm_used, mode_desc)
+                    if par5 is not None:
+                        o5["parity_vs_1gpu"] = par5
+                    out["config5"] = {k: v for k, v in o5.items() if k not in ("metric", "higher_is_better", "vs_baseline", "dtype", "data")}
+                ev.close()
+            except Exception as e:
+                if rank == 0:
+                    out["config5"] = {"error": str(e)}
+    if sharded:
+        dist.destroy_process_group()
+    if rank == 0:
+        out.pop("_last", None)
+        try:  # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the LAST line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

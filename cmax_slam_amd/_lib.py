@@ -15,8 +15,8 @@ VARIANCE, MEAN_SQUARE, GRADIENT_MAGNITUDE = 0, 1, 2
 GRAD_PLANES, GRAD_ADJOINT = 0, 1
 OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE = 1, 2, 3, 4, 5, 6
 PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
-T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COMM, T_FINAL, T_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
-T_NAMES = ("splat", "image", "pose", "gather", "zero", "comm", "final")
+T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COMM, T_FINAL, T_BATCH, T_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
+T_NAMES = ("splat", "image", "pose", "gather", "zero", "comm", "final", "batch")
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)

@@ -223,9 +223,9 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     c->h_spline->knots[i] = q;
   }
   {
-    Span sp(c, CMX_T_POSE);
+    Span sp(c, CMX_T_POSE, /*exact=*/true);
     launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poseR, c->d_poses,
-                         c->stream);
+                         c->stream, sp.t0(), sp.t1());
   }
   rc = begin_accum(c, 2 + P, np, P == 0 && adjoint_ok(c) && c->splat_mode == 1);
   if (rc) return rc;

@@ -117,6 +117,8 @@ struct cmx_ctx {
   unsigned *d_tile_list = nullptr, *d_tile_count = nullptr;  // compacted work list of the image passes (large panoramas)
   size_t tile_list_cap = 0;
   int tile_count_sel = 0;
+  bool adj_direct = false;                   // shape of the moment partials the last adjoint image pass produced
+  const unsigned *adj_tile_count = nullptr;  // (run_adjoint phase 1 -> phase 2)
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
   int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
   int64_t reuse_hits = 0;

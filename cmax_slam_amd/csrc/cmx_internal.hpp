@@ -129,7 +129,7 @@ struct ImgAdjArgs {
 size_t image_adjoint_lds_bytes(int r);
 int image_adjoint_tiles_x(int W);
 int image_adjoint_tiles(int W, int H);
-void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s);
+void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 struct FeGatherArgs {
   FeSplatArgs ev;          // same event / camera description as the splat
@@ -218,17 +218,18 @@ void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, h
 
 void launch_fe_splat(const FeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,
-                          PoseR *outR, PoseEntry *out, hipStream_t s);
+                          PoseR *outR, PoseEntry *out, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-void launch_image_moments(const ImgArgs &a, hipStream_t s);
-void launch_finalize(const FinalizeArgs &a, hipStream_t s);
+void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
-void launch_finalize_only(const FinalizeArgs &a, hipStream_t s);
+void launch_finalize_only(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the number of blocks (rows of gpartials)
-int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the rows of gpartials (batch-kernel blocks)
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, hipEvent_t b0 = nullptr,
+                     hipEvent_t b1 = nullptr);  // returns the rows of gpartials (batch-kernel blocks)
 int be_batch_blocks(int nb);
 int gather_blocks(int n);
 int fe_gather_blocks(int n);

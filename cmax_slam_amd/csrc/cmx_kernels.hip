@@ -116,27 +116,27 @@ __global__ __launch_bounds__(64) void be_pose_table_pre_kernel(const SplineArgsP
 }
 
 void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, int nb, int order, bool want_j,
-                          PoseR *outR, PoseEntry *out, hipStream_t s) {
+                          PoseR *outR, PoseEntry *out, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (nb <= 0) return;
   const dim3 g((nb + 63) / 64), b(64);
   if (spline.K <= kMaxKnotsPre) {
     SplineArgsPre pre;
     spline_precompute(spline, pre);
     if (order == 2) {
-      if (want_j) hipLaunchKernelGGL((be_pose_table_pre_kernel<2, true>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
-      else hipLaunchKernelGGL((be_pose_table_pre_kernel<2, false>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<2, true>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      else CMX_LAUNCH((be_pose_table_pre_kernel<2, false>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
     } else {
-      if (want_j) hipLaunchKernelGGL((be_pose_table_pre_kernel<4, true>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
-      else hipLaunchKernelGGL((be_pose_table_pre_kernel<4, false>), g, b, 0, s, pre, d_batch_t, nb, outR, out);
+      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<4, true>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      else CMX_LAUNCH((be_pose_table_pre_kernel<4, false>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
     }
     return;
   }
   if (order == 2) {
-    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<2, true>), g, b, 0, s, spline, d_batch_t, nb, outR, out);
-    else hipLaunchKernelGGL((be_pose_table_kernel<2, false>), g, b, 0, s, spline, d_batch_t, nb, outR, out);
+    if (want_j) CMX_LAUNCH((be_pose_table_kernel<2, true>), g, b, 0, s, t0, t1, spline, d_batch_t, nb, outR, out);
+    else CMX_LAUNCH((be_pose_table_kernel<2, false>), g, b, 0, s, t0, t1, spline, d_batch_t, nb, outR, out);
   } else {
-    if (want_j) hipLaunchKernelGGL((be_pose_table_kernel<4, true>), g, b, 0, s, spline, d_batch_t, nb, outR, out);
-    else hipLaunchKernelGGL((be_pose_table_kernel<4, false>), g, b, 0, s, spline, d_batch_t, nb, outR, out);
+    if (want_j) CMX_LAUNCH((be_pose_table_kernel<4, true>), g, b, 0, s, t0, t1, spline, d_batch_t, nb, outR, out);
+    else CMX_LAUNCH((be_pose_table_kernel<4, false>), g, b, 0, s, t0, t1, spline, d_batch_t, nb, outR, out);
   }
 }
 
@@ -698,17 +698,17 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<kImgThreads>(a.tail.fin, fin_sm);
 }
 
-void launch_image_moments(const ImgArgs &a, hipStream_t s) {
+void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int groups = a.P > 0 ? (a.P + kPlaneGroup - 1) / kPlaneGroup : 1;
   const size_t lds = image_lds_bytes(a.r);
   if (a.tile_list) {
     const dim3 g(min(a.nblk, kTileListGrid), 1, groups);
-    if (a.r == 4) hipLaunchKernelGGL((image_moments_kernel<4, true>), g, dim3(kImgThreads), lds, s, a);
-    else hipLaunchKernelGGL((image_moments_kernel<-1, true>), g, dim3(kImgThreads), lds, s, a);
+    if (a.r == 4) CMX_LAUNCH((image_moments_kernel<4, true>), g, dim3(kImgThreads), lds, s, t0, t1, a);
+    else CMX_LAUNCH((image_moments_kernel<-1, true>), g, dim3(kImgThreads), lds, s, t0, t1, a);
   } else {
     const dim3 g(a.nblk, 1, groups);
-    if (a.r == 4) hipLaunchKernelGGL((image_moments_kernel<4, false>), g, dim3(kImgThreads), lds, s, a);
-    else hipLaunchKernelGGL((image_moments_kernel<-1, false>), g, dim3(kImgThreads), lds, s, a);
+    if (a.r == 4) CMX_LAUNCH((image_moments_kernel<4, false>), g, dim3(kImgThreads), lds, s, t0, t1, a);
+    else CMX_LAUNCH((image_moments_kernel<-1, false>), g, dim3(kImgThreads), lds, s, t0, t1, a);
   }
 }
 
@@ -739,12 +739,12 @@ void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 + 2 * a.P), dim3(256), 0, s, a);
 }
-void launch_finalize_only(const FinalizeArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, a);
+void launch_finalize_only(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+  CMX_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, t0, t1, a);
 }
-void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
+void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   launch_reduce_partials(a, s);
-  launch_finalize_only(a, s);
+  launch_finalize_only(a, s, t0, t1);
 }
 
 // ---------------------------------------------------------------------------------------------- fused image + adjoint
@@ -904,16 +904,16 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   }  // work loop
 }
 
-void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s) {
+void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const size_t lds = image_adjoint_lds_bytes(a.img.r);
   if (a.img.tile_list) {
     const dim3 g(min(a.img.nblk, kTileListGrid));
-    if (a.img.r == 4) hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, a);
-    else hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, a);
+    if (a.img.r == 4) CMX_LAUNCH((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, t0, t1, a);
+    else CMX_LAUNCH((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, true>), g, dim3(kAdjThreads), lds, s, t0, t1, a);
   } else {
     const dim3 g(a.img.nblk);
-    if (a.img.r == 4) hipLaunchKernelGGL((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, a);
-    else hipLaunchKernelGGL((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, a);
+    if (a.img.r == 4) CMX_LAUNCH((image_adjoint_kernel<4, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, t0, t1, a);
+    else CMX_LAUNCH((image_adjoint_kernel<-1, kAdjTX, kAdjTY, kAdjThreads, false>), g, dim3(kAdjThreads), lds, s, t0, t1, a);
   }
 }
 
@@ -1289,17 +1289,17 @@ int be_batch_blocks(int nb) {
   return blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
 }
 
-int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  // (t0, t1) bracket the per-event kernel; the per-batch pass that follows is not part of that span
+int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1, hipEvent_t b0, hipEvent_t b1) {
+  // (t0, t1) bracket the per-event kernel, (b0, b1) the per-batch pass that follows
   if (a.slice_shift == 8) CMX_LAUNCH(be_gather4_kernel, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, t0, t1, a);
   else CMX_LAUNCH(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, t0, t1, a);
   const int blocks = be_batch_blocks(nb);
   if (a.deterministic) {
-    if (a.ev.order == 2) hipLaunchKernelGGL((be_gather_batch_kernel<2, true>), dim3(blocks), dim3(256), 0, s, a, nb);
-    else hipLaunchKernelGGL((be_gather_batch_kernel<4, true>), dim3(blocks), dim3(256), 0, s, a, nb);
+    if (a.ev.order == 2) CMX_LAUNCH((be_gather_batch_kernel<2, true>), dim3(blocks), dim3(256), 0, s, b0, b1, a, nb);
+    else CMX_LAUNCH((be_gather_batch_kernel<4, true>), dim3(blocks), dim3(256), 0, s, b0, b1, a, nb);
   } else {
-    if (a.ev.order == 2) hipLaunchKernelGGL((be_gather_batch_kernel<2, false>), dim3(blocks), dim3(256), 0, s, a, nb);
-    else hipLaunchKernelGGL((be_gather_batch_kernel<4, false>), dim3(blocks), dim3(256), 0, s, a, nb);
+    if (a.ev.order == 2) CMX_LAUNCH((be_gather_batch_kernel<2, false>), dim3(blocks), dim3(256), 0, s, b0, b1, a, nb);
+    else CMX_LAUNCH((be_gather_batch_kernel<4, false>), dim3(blocks), dim3(256), 0, s, b0, b1, a, nb);
   }
   return blocks;
 }

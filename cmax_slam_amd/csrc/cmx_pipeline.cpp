@@ -215,9 +215,9 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
   f.ticket = ++c->ticket_issued;
   c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
-  Span sp(c, CMX_T_FINAL);
-  if (with_reduce) launch_finalize(f, c->stream);
-  else launch_finalize_only(f, c->stream);
+  Span sp(c, CMX_T_FINAL, /*exact=*/true);
+  if (with_reduce) launch_finalize(f, c->stream, sp.t0(), sp.t1());
+  else launch_finalize_only(f, c->stream, sp.t0(), sp.t1());
 }
 
 // Tail finalize (CMX_OPT_TAIL_FINALIZE): hand the finalize to the launch that is about to be issued.  Only the forms whose
@@ -332,8 +332,8 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)(1 + P) * sa.nblk);
     if (rc) return rc;
     sa.partials = c->d_gpartials;
-    Span sp(c, CMX_T_IMAGE);
-    launch_image_moments(a, c->stream);
+    Span sp(c, CMX_T_IMAGE, /*exact=*/true);
+    launch_image_moments(a, c->stream, sp.t0(), sp.t1());
     launch_sobel_moments(sa, c->stream);
     FinalizeArgs f{};
     f.P = 0; f.nblk = a.nblk; f.measure = 2; f.npix = (double)np;
@@ -356,7 +356,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   f.fallback = c->d_fallback;
   bool tailed = false;
   {
-    Span sp(c, CMX_T_IMAGE);
+    Span sp(c, CMX_T_IMAGE, /*exact=*/true);
     rc = maybe_tile_list(c, a, c->radius);
     if (rc) return rc;
     if (P == 0 && (a.nblk <= 2048 || a.tile_list)) {
@@ -364,7 +364,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
       f.nvalid = a.tile_count;  // list path: partial rows are compact, one entry per listed tile
       if (!out_blur0 && !out_blurd) tailed = arm_tail(c, f, a.tail);  // the last-arriving workgroup finalizes
     }
-    launch_image_moments(a, c->stream);
+    launch_image_moments(a, c->stream, sp.t0(), sp.t1());
   }
   if (!tailed) issue_finalize(c, f, /*with_reduce=*/!f.direct);
   HIP_TRY(c, hipGetLastError());
@@ -439,7 +439,14 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     rc = maybe_tile_list(c, a, 2 * c->radius);
     if (rc) return rc;
   }
-  const bool direct = a.nblk <= 2048 || a.tile_list;  // few entries: finalize sums the per-tile moments itself
+  bool direct = a.nblk <= 2048 || a.tile_list;  // few entries: finalize sums the per-tile moments itself
+  if (phase == 2) {  // split call: the image pass ran in finish_begin -- its partial rows have the shape decided there
+    direct = c->adj_direct;
+    a.tile_count = c->adj_tile_count;
+  } else {
+    c->adj_direct = direct;
+    c->adj_tile_count = a.tile_count;
+  }
   f.direct = direct ? 1 : 0;
   f.nvalid = a.tile_count;
   f.mu_free = 1;
@@ -458,8 +465,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     return CMX_OK;
   }
   {
-    Span sp(c, CMX_T_IMAGE);
-    launch_image_adjoint(ia, c->stream);
+    Span sp(c, CMX_T_IMAGE, /*exact=*/true);
+    launch_image_adjoint(ia, c->stream, sp.t0(), sp.t1());
     if (!direct) launch_reduce_partials(f, c->stream);
   }
   bool tailed = false;  // the gather launch carries the finalize
@@ -514,7 +521,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       }
       if (c->n_packed > 0 && P > 0) {
         if (phase == 0) tailed = arm_tail(c, f, g.tail);
-        launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1());
+        Span sb(c, CMX_T_BATCH, /*exact=*/true);
+        launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), sb.t0(), sb.t1());
       } else {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
       }

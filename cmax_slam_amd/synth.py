@@ -264,6 +264,12 @@ def config4_slab(rank, world=8, per_gpu=5_000_000, seed=SEED0 + 4, Wp=1024, Hp=1
                           slab=(rank, world), **HANDHELD_K)
 
 
+def config5_slab(rank, world=8, per_gpu=2_500_000, seed=SEED0 + 5, Wp=4096, Hp=2048):
+    """Config 5 (1280x720 sensor, linear K=5, 0 fixed => P=15, 4096x2048 map) as `world` time slabs of per_gpu events."""
+    return backend_window(per_gpu, 1280, 720, 1000.0, 1000.0, 639.5, 359.5, Wp=Wp, Hp=Hp, order=2, K=5, num_fixed=0, T=0.2,
+                          seed=seed, slab=(rank, world))
+
+
 def concat_slabs(slabs):
     """The whole window of a list of time slabs (in rank order)."""
     import copy

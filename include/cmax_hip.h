@@ -297,13 +297,15 @@ int cmx_bearing_lut(int W, int H, const double K[9], const double D[5], const do
 /* ------------------------------------------------------------------ timing hooks ------------------------
  * HIP-event timing of the dominant kernels on the context's stream (bench.py's roofline leg).
  * cmx_timing_enable(ctx, mask) makes every evaluation record events around the kernel classes whose bit is set
- * (bit CMX_T_SPLAT, ...; 0x7f = all, 0 = off); mask | (n << 8) samples every n-th evaluation only.  The per-event
+ * (bit CMX_T_SPLAT, ...; 0xff = all, 0 = off); mask | (n << 8) samples every n-th evaluation only.  The per-event
  * kernels (splat, gather) carry their events on the kernel itself (hipExtLaunchKernelGGL start / stop: the dispatch's
  * own timestamps, the same rocprofv3 reports); the other classes are bracketed on the stream (CMX_T_COMM: the RCCL collectives of an attached communicator,
  * i.e. including the wait for the slowest rank);
  * cmx_timing_get returns accumulated milliseconds and launch counts per kernel class, then resets. */
-enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COMM = 5, CMX_T_FINAL = 6, CMX_T_COUNT = 7 };
-/* CMX_T_FINAL: the separate finalize launch (absent when CMX_OPT_TAIL_FINALIZE folds it into the last kernel) */
+enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T_ZERO = 4, CMX_T_COMM = 5, CMX_T_FINAL = 6, CMX_T_BATCH = 7, CMX_T_COUNT = 8 };
+/* CMX_T_FINAL: the separate finalize launch (absent when CMX_OPT_TAIL_FINALIZE folds it into the last kernel);
+ * CMX_T_BATCH: the back end's per-batch pass of the gradient gather.  Every class except CMX_T_ZERO / CMX_T_COMM is timed
+ * through events carried by its (main) kernel: the dispatch's own begin / end timestamps, what rocprofv3 reports. */
 /* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5..7] reserved */
 int cmx_get_stats(cmx_ctx *ctx, double stats[8]);

@@ -210,6 +210,31 @@ def test_touched_rows_exchange_on_a_large_panorama_world1(hip):
     assert abs(r1["final_cost"] - r0["final_cost"]) < 1e-3 * abs(r0["final_cost"])
 
 
+def test_split_phase_finish_on_a_tile_list_panorama_world1(hip):
+    """4096x2048 (8192 image tiles > 2048): the image passes walk the compacted tile list and their moment rows are
+    compact; the split-phase finish (finish_begin / all-reduce / finish_end, what an attached communicator runs) must
+    finalize from those same rows.  One rank: results equal the plain evaluation, including a non-zero global map."""
+    w = synth.backend_window(80_000, 320, 240, 260.0, 260.0, 159.5, 119.5, 4096, 2048, 2, 5, 0, 0.2, seed=46)
+    IG = np.zeros((w.Hp, w.Wp), np.float32)
+    IG[900:960, 1900:2200] = 1.2
+    plain = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    shard = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    for ev in (plain, shard):
+        ev.set_fast_path()
+        ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
+                      w.batch, w.sample_rate, w.sigma, 0, IG)
+    shard.comm_attach(shard.comm_unique_id(), 0, 1)
+    rng = np.random.default_rng(8)
+    for i, d in enumerate([np.zeros(w.P), rng.normal(0, 0.01, w.P), rng.normal(0, 0.01, w.P), np.zeros(w.P)]):
+        want = i != 2
+        c0, g0 = plain.eval(d, want)
+        c1, g1 = shard.eval(d, want)
+        assert rel_scalar(c1, c0) < 1e-7, (i, c0, c1)
+        if want:
+            assert rel_vec(g1, g0) < 1e-6, i
+    assert rel_scalar(shard.alpha, plain.alpha) < 1e-7 and plain.alpha > 0
+
+
 def _lib_plane(name):
     from cmax_slam_amd import _lib
     return getattr(_lib, "PLANE_" + name)
