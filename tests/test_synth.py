@@ -37,22 +37,25 @@ def test_batch_range_partitions_whole_batches():
 def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     """bench.py's cpu_baseline object (the oracle timed on host cores; the all-cores figure nested beside it) is
     pure CPU work: its keys and its bookkeeping are checked here on a small packet."""
-    import types
-
     import bench
 
     p = synth.frontend_packet(20_000, 120, 90, 100.0, 100.0, 59.5, 44.5, seed=3)
-    args = types.SimpleNamespace(workload="frontend", cpu_seconds=0.4)
-    out = bench.cpu_baseline(args, p, np.array([0.3, -0.5, 0.2]))
+    out = bench.cpu_baseline("frontend", p, np.array([0.3, -0.5, 0.2]), 0.4)
     assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "events/s" and out["value"] > 0
     assert "full fdf evaluations" in out["sample"]
     ac = out["allcores"]
     assert "error" not in ac, ac
     assert 1 <= ac["cores"] <= ac["usable_cores"] == bench.usable_cores() and ac["value"] > 0
-    assert bench.alg_bytes_per_event("frontend", 0, "splat", True) == 60
-    assert bench.alg_bytes_per_event("frontend", 0, "splat", False) == 156
-    assert bench.alg_bytes_per_event("backend", 4, "splat", False) == 444
-    assert bench.alg_bytes_per_event("backend", 2, "splat", False) == 252
+    # the byte models behind the roofline objects: SURVEY 8(d)'s algorithmic bytes, and mandatory bytes <= algorithmic
+    for kind, order, P in (("frontend", 0, 3), ("backend", 2, 15), ("backend", 4, 21)):
+        m = bench.byte_models(kind, order, 1_000_000, 640 * 480, 10_000, P, True, 50_000)
+        assert m["splat"][0] == 1_000_000 * 60 and m["gather"][0] == 1_000_000 * 44
+        assert all(mand <= alg for alg, mand in m.values())
+    assert bench.byte_models("frontend", 0, 1, 1, 0, 3, False, 0)["splat"][0] == 156
+    assert bench.byte_models("backend", 4, 1, 1, 1, 21, False, 0)["splat"][0] == 444
+    assert bench.byte_models("backend", 2, 1, 1, 1, 15, False, 0)["splat"][0] == 252
+    assert bench.whole_eval_bytes_8d("frontend", 0, 1_000_000, 640 * 480, 3) == 185_491_200   # SURVEY 8(d): 185.5 MB / eval
+    assert abs(bench.whole_eval_bytes_8d("backend", 4, 5_000_000, 1024 * 1024, 21) - 2.77e9) < 0.01e9
 
 
 def test_config4_slabs_concatenate_into_one_window_and_match_batch_range():
