@@ -13,6 +13,9 @@ SO_PATH = os.path.join(_HERE, "libcmaxhip.so")
 OK, ERR_INVALID_ARG, ERR_EVENT_RANGE, ERR_HIP, ERR_SPLINE_RANGE, ERR_STATE, ERR_TIME_ORDER = range(7)
 VARIANCE, MEAN_SQUARE, GRADIENT_MAGNITUDE = 0, 1, 2
 GRAD_PLANES, GRAD_ADJOINT = 0, 1
+DT_U8, DT_F32, DT_F64 = 0, 1, 2
+OP_SUM, OP_MAX = 0, 1
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE = 1, 2, 3, 4, 5, 6
 PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
 T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COMM, T_FINAL, T_BATCH, T_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -79,6 +82,7 @@ SYMBOLS = {
     "cmx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cmx_comm_attach": (C.c_int, [ctx_p, C.c_char_p, C.c_int, C.c_int]),
     "cmx_comm_detach": (C.c_int, [ctx_p]),
+    "cmx_comm_attach_custom": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "cmx_frontend_solve": (C.c_int, [ctx_p, c_dp, C.c_void_p]),
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,

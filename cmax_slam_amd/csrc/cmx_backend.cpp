@@ -179,6 +179,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   HIP_TRY(c, hipMemsetAsync(c->d_alpha, 0, sizeof(double), c->stream));  // on the context's (non-blocking) stream: ordered before its kernels
   c->h_result[kAlphaSlot] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
+  comm_reset_band(c);       // sharded large panoramas: the first exchange of a window covers the whole plane
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (nb && d_raw) {
     long long e[2] = {0, 0};
@@ -230,14 +231,17 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   rc = begin_accum(c, 2 + P, np, P == 0 && adjoint_ok(c) && c->splat_mode == 1);
   if (rc) return rc;
   BeSplatArgs a = be_args(c);
-  const bool use_lds = c->splat_mode == 1 && !deriv && c->n_packed > 0;
+  const bool lds_mode = c->splat_mode == 1 && !deriv;  // what this call would use for any number of events
+  const bool use_lds = lds_mode && c->n_packed > 0;
   if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
     rc = do_binning(c, nullptr, &a);
     if (rc) return rc;
   }
   // tile occupancy: only for the LDS splat into this context's own ping-pong buffers (with a communicator attached the
-  // flags are all-reduced with the planes, finish_sharded; planes owned by the caller are exchanged by the caller)
-  const bool use_flags = use_lds && c->pingpong_planes > 0 && !c->accum_external;
+  // flags are all-reduced with the planes, finish_sharded; planes owned by the caller are exchanged by the caller).
+  // Deliberately NOT a function of n_packed: a rank whose shard is empty keeps all-zero flags and takes part in the
+  // same collectives as every other rank (cmx_comm.cpp).
+  const bool use_flags = lds_mode && c->pingpong_planes > 0 && !c->accum_external;
   if (use_flags) {
     const size_t tiles = (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY);
     if (tiles > c->tflags_cap || !c->d_tflags || !c->d_tflags_alt || !c->d_igp_flags) {
@@ -345,7 +349,7 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
-  const bool sharded = c && c->comm;
+  const bool sharded = c && c->sharded();
   if (c && c->kind == KIND_BE && drotv && can_reuse(c, drotv, 3 * (c->K - c->num_fixed), grad != nullptr)) {
     c->last_adjoint = true;
     c->reuse_hits++;

@@ -36,42 +36,66 @@ RcclApi &rccl() {
   }();
   return api;
 }
-int comm_allreduce(cmx_ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op = ncclSum) {
-  if (!c->comm || count == 0) return CMX_OK;
+int comm_allreduce(cmx_ctx *c, void *buf, size_t count, int dt /* CMX_DT_* */, int op = CMX_OP_SUM) {
+  if (!c->sharded() || count == 0) return CMX_OK;
   Span sp(c, CMX_T_COMM);  // on the stream: the collective itself plus the wait for the slowest rank
-  const ncclResult_t r = rccl().AllReduce(buf, buf, count, dt, op, c->comm, c->stream);
+  if (c->comm_fn) {
+    const int r = c->comm_fn(c->comm_user, buf, count, dt, op, (void *)c->stream);
+    if (r != 0) return fail(c, CMX_ERR_HIP, "caller-supplied all-reduce failed with status %d", r);
+    return CMX_OK;
+  }
+  const ncclDataType_t ndt = dt == CMX_DT_U8 ? ncclUint8 : (dt == CMX_DT_F32 ? ncclFloat : ncclDouble);
+  const ncclResult_t r = rccl().AllReduce(buf, buf, count, ndt, op == CMX_OP_MAX ? ncclMax : ncclSum, c->comm, c->stream);
   if (r != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(r));
   return CMX_OK;
 }
 
-// Large panoramas: the ranks' votes cover a few tile rows of a mostly empty map.  All-reduce (max) the tile-occupancy
-// flags (a few KB), read them back, and sum only the band of rows any rank touched -- 64 MB per evaluation become
-// ~16 MB at 4096x2048 (BASELINE config 5).  Every rank derives the band from the same reduced flags, so the collectives
-// match by construction.  Returns 1 if it handled the exchange, 0 if the caller should exchange the planes whole.
+// Exchange of the partial planes between splat and blur.
+// Which collectives are issued depends on RANK-INVARIANT state only -- context kind, plane size, what the accumulate call
+// produced (a function of the options and of the call itself), the row band every rank derived from the same all-reduced
+// flags -- never on a rank's own event count: mismatched collectives are undefined behaviour in RCCL.
+//
+// Large panoramas (planes of 8 MB and more): the ranks' votes cover a few tile rows of a mostly empty map.  The
+// tile-occupancy flags (a few KB) are all-reduced with max; band_kernel reduces them to the first / last touched tile
+// row and writes that to mapped host memory; the planes are then summed over the band of rows the PREVIOUS evaluation
+// found, widened by kBandMargin tile rows (the whole plane while no band is known) -- 64 MB per evaluation become ~16 MB
+// at 4096x2048 (BASELINE config 5) with no host synchronisation between splat and blur.  band_kernel also reports whether
+// a touched row lay outside the band that was exchanged; settle_band() then completes the evaluation (rare: the
+// parameters moved the votes by more than two tile rows between two evaluations).
 constexpr size_t kSparseExchangeMinPlaneBytes = (size_t)8 << 20;
-static int exchange_touched_rows(cmx_ctx *c, int *handled) {
-  *handled = 0;
+constexpr int kBandMargin = 2;
+static int allreduce_rows(cmx_ctx *c, int tile_row0, int tile_row1 /* exclusive */) {
   const size_t np = (size_t)c->Wp * c->Hp;
-  if (c->kind != KIND_BE || !c->accum_flagged || !c->d_tflags || np * sizeof(float) < kSparseExchangeMinPlaneBytes ||
-      c->accum_count != 2 * np)
-    return CMX_OK;
-  const int tiles_x = (c->Wp + kTileX - 1) / kTileX, tiles_y = (c->Hp + kTileY - 1) / kTileY;
-  int rc = comm_allreduce(c, c->d_tflags, (size_t)tiles_x * tiles_y, ncclUint8, ncclMax);
-  if (rc) return rc;
-  std::vector<unsigned char> flags((size_t)tiles_x * tiles_y);
-  HIP_TRY(c, hipMemcpyAsync(flags.data(), c->d_tflags, flags.size(), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  int r0 = tiles_y, r1 = -1;
-  for (int ty = 0; ty < tiles_y; ty++)
-    for (int tx = 0; tx < tiles_x; tx++)
-      if (flags[(size_t)ty * tiles_x + tx]) { r0 = ty < r0 ? ty : r0; r1 = ty > r1 ? ty : r1; break; }
-  *handled = 1;
-  if (r1 < r0) return CMX_OK;  // nobody voted anywhere
-  const size_t row0 = (size_t)r0 * kTileY, row1 = std::min((size_t)(r1 + 1) * kTileY, (size_t)c->Hp);
+  const size_t row0 = (size_t)tile_row0 * kTileY, row1 = std::min((size_t)tile_row1 * kTileY, (size_t)c->Hp);
+  if (row1 <= row0) return CMX_OK;
   for (int plane = 0; plane < 2; plane++) {
-    rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, ncclFloat);
+    int rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, CMX_DT_F32);
     if (rc) return rc;
   }
+  return CMX_OK;
+}
+static int exchange_planes(cmx_ctx *c) {
+  const size_t np = (size_t)c->Wp * c->Hp;
+  c->band_pending = false;
+  const bool sparse = c->kind == KIND_BE && c->accum_flagged && c->d_tflags && np * sizeof(float) >= kSparseExchangeMinPlaneBytes &&
+                      c->accum_count == 2 * np;
+  if (!sparse) {
+    int rc = comm_allreduce(c, c->d_accum, c->accum_count, CMX_DT_F32);  // sum of the ranks' partial planes
+    c->accum_flagged = false;  // the planes now hold other ranks' votes this rank's occupancy flags know nothing about
+    return rc;
+  }
+  const int tiles_x = (c->Wp + kTileX - 1) / kTileX, tiles_y = (c->Hp + kTileY - 1) / kTileY;
+  int rc = comm_allreduce(c, c->d_tflags, (size_t)tiles_x * tiles_y, CMX_DT_U8, CMX_OP_MAX);
+  if (rc) return rc;
+  int lo = c->band_lo, hi = c->band_hi;
+  if (hi < lo) { lo = 0; hi = tiles_y - 1; }  // no band known yet (first evaluation of a window): the whole plane
+  launch_band(c->d_tflags, tiles_x, tiles_y, lo, hi, c->d_result + kBandSlot, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  rc = allreduce_rows(c, lo, hi + 1);
+  if (rc) return rc;
+  c->band_pending = true;
+  c->band_used_lo = lo;
+  c->band_used_hi = hi;
   return CMX_OK;
 }
 
@@ -80,28 +104,55 @@ static int exchange_touched_rows(cmx_ctx *c, int *handled) {
 void comm_release(cmx_ctx *c) {
   if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
   c->comm = nullptr;
+  c->comm_fn = nullptr;
+}
+void comm_reset_band(cmx_ctx *c) {
+  c->band_lo = 0;
+  c->band_hi = -1;
+  c->band_pending = false;
 }
 
-// evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
-int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad) {
-  int rc = CMX_OK;
-  if (exchange_planes) {
-    int handled = 0;
-    rc = exchange_touched_rows(c, &handled);
-    if (rc) return rc;
-    if (!handled) {
-      rc = comm_allreduce(c, c->d_accum, c->accum_count, ncclFloat);  // sum of the ranks' partial planes
-      c->accum_flagged = false;  // the planes now hold other ranks' votes this rank's occupancy flags know nothing about
-    }
-    if (rc) return rc;
-  }
-  rc = finish_begin(c, kind, grad != nullptr);
+static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad) {
+  int rc = finish_begin(c, kind, grad != nullptr);
   if (rc) return rc;
   if (c->pending_P > 0) {
-    rc = comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, ncclDouble);  // adjoint mode: S1,S2 partial sums
+    rc = comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, CMX_DT_F64);  // adjoint mode: S1,S2 partial sums
     if (rc) return rc;
   }
   return finish_end(c, kind, contrast, grad);
+}
+
+// evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
+int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double *grad) {
+  int rc = CMX_OK;
+  if (exchange) {
+    rc = exchange_planes(c);
+    if (rc) return rc;
+  }
+  rc = finish_exchanged(c, kind, contrast, grad);
+  if (rc || !exchange || !c->band_pending) return rc;
+  // the results are on the host, and with them what band_kernel found (written by an earlier kernel of the same stream)
+  c->band_pending = false;
+  const int tiles_y = (c->Hp + kTileY - 1) / kTileY;
+  const int r0 = (int)c->h_result[kBandSlot], r1 = (int)c->h_result[kBandSlot + 1];
+  const bool miss = c->h_result[kBandSlot + 2] != 0.0;
+  if (r1 >= r0) {
+    c->band_lo = std::max(0, r0 - kBandMargin);
+    c->band_hi = std::min(tiles_y - 1, r1 + kBandMargin);
+  } else {
+    comm_reset_band(c);  // nobody voted anywhere
+  }
+  if (miss) {
+    // every rank read the same three numbers (they derive from the all-reduced flags), so every rank is here: the rows
+    // outside the exchanged band still hold partial sums -- exchange them and finish once more on the complete planes
+    c->band_misses++;
+    rc = allreduce_rows(c, 0, c->band_used_lo);
+    if (rc) return rc;
+    rc = allreduce_rows(c, c->band_used_hi + 1, tiles_y);
+    if (rc) return rc;
+    rc = finish_exchanged(c, kind, contrast, grad);
+  }
+  return rc;
 }
 
 // ---- native RCCL communicator (one process per GPU; the launcher distributes the 128-byte id)
@@ -121,6 +172,8 @@ int cmx_comm_attach(cmx_ctx *c, const char id[CMX_COMM_ID_BYTES], int rank, int 
   int rc = bind_device(c);
   if (rc) return rc;
   if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
+  c->comm_fn = nullptr;
+  comm_reset_band(c);
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
@@ -136,8 +189,21 @@ int cmx_comm_detach(cmx_ctx *c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
   c->comm = nullptr;
+  c->comm_fn = nullptr;
+  c->comm_user = nullptr;
   c->comm_size = 1;
   c->comm_rank = 0;
+  comm_reset_band(c);
+  return CMX_OK;
+}
+int cmx_comm_attach_custom(cmx_ctx *c, cmx_allreduce_fn fn, void *user, int rank, int nranks) {
+  if (!c || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, CMX_ERR_INVALID_ARG, "bad communicator arguments");
+  int rc = cmx_comm_detach(c);
+  if (rc) return rc;
+  c->comm_fn = fn;
+  c->comm_user = user;
+  c->comm_rank = rank;
+  c->comm_size = nranks;
   return CMX_OK;
 }
 

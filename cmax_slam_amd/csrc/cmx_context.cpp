@@ -330,6 +330,9 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
   }
   stats[3] = (double)c->n_packed;
   stats[4] = (double)c->reuse_hits;
+  stats[5] = (double)c->sharded_host_syncs;
+  stats[6] = (double)c->band_misses;
+  stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
   return CMX_OK;
 }
 

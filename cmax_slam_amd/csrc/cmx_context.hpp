@@ -167,7 +167,15 @@ struct cmx_ctx {
 
   // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
   ncclComm_t comm = nullptr;
+  cmx_allreduce_fn comm_fn = nullptr;  // caller-supplied transport (cmx_comm_attach_custom) instead of RCCL
+  void *comm_user = nullptr;
   int comm_rank = 0, comm_size = 1;
+  bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
+  // row band of the sparse plane exchange (tile rows, inclusive); band_hi < band_lo: unknown -> whole plane
+  int band_lo = 0, band_hi = -1;
+  bool band_pending = false;       // the last evaluation ran the band kernel: its result waits in h_result[kBandSlot..]
+  int band_used_lo = 0, band_used_hi = -1;  // what that evaluation actually exchanged (whole plane: 0 .. tiles_y-1)
+  int64_t sharded_host_syncs = 0, band_misses = 0;
 
   // timing
   bool timing = false;
@@ -284,6 +292,7 @@ int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the f
 
 // ---- cmx_comm.cpp
 int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad);
+void comm_reset_band(cmx_ctx *c);  // a new window / packet / panorama: the next exchange covers the whole plane
 void comm_release(cmx_ctx *c);  // destroys an attached communicator (cmx_destroy)
 
 // ---- cmx_frontend.cpp / cmx_backend.cpp: the bodies behind set_packet / set_window and their *_from forms

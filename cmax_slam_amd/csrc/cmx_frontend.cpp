@@ -160,7 +160,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
-  const bool sharded = c && c->comm;
+  const bool sharded = c && c->sharded();
   if (c && c->kind == KIND_FE && omega && can_reuse(c, omega, 3, grad != nullptr)) {
     c->last_adjoint = true;  // image of this very point is resident: adjoint blur + gather only
     c->reuse_hits++;

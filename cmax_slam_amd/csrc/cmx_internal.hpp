@@ -72,6 +72,8 @@ constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nou
 constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
 constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
 constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
+constexpr int kBandSlot = 4088;      // [0] first, [1] last flagged tile row of the all-reduced occupancy map, [2] = 1 if a flagged
+                                     // row lay outside the band this evaluation exchanged (sharded large panoramas)
 constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
 
@@ -116,7 +118,7 @@ struct ImgArgs {
 };
 constexpr int kTileListMin = 2048, kTileListGrid = 1024;
 // reach: pixels of filter support beyond the tile (r for the moments pass, 2r for the adjoint pass)
-void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, hipStream_t s);
+void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, bool ordered, hipStream_t s);
 
 // fused image pass of the adjoint gradient: B = G*A (moments of B), Jt = G^T B^ in ONE kernel.
 // G^T(B - mu) = G^T B - mu*c with c = G^T 1 = cx(x)*cy(y) (1 in the interior, differs only within r of the border), and the
@@ -222,6 +224,7 @@ void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, 
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);

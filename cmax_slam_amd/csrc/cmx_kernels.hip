@@ -313,9 +313,58 @@ __global__ __launch_bounds__(1024) void tile_list_kernel(ImgArgs a, int reach, u
   for (int w = 0; w < wave; w++) off += wave_tot[w];
   if (listed) list[off + before] = entry;
 }
-void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, hipStream_t s) {
+// The same list in TILE ORDER, built by one workgroup (no atomics): the order of the list is the order in which finalize
+// sums the tiles' moment rows, so with it a result does not depend on which workgroup reserved its slots first.  Used by
+// sharded evaluations: the ranks' replicated optimiser drivers must see bit-identical numbers or they would stop taking
+// the same decisions (and issuing the same collectives); ranks share flags and history, hence this list.
+__global__ __launch_bounds__(1024) void tile_list_ordered_kernel(ImgArgs a, int reach, unsigned *list, unsigned *count, unsigned *next_count) {
+  __shared__ unsigned wave_tot[16];
+  __shared__ unsigned base_sh;
   const int ntiles = a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL(tile_list_kernel, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, a, reach, list, count, next_count);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { *next_count = 0u; base_sh = 0u; }
+  const int nx = (reach + kTileX - 1) / kTileX, ny = (reach + kTileY - 1) / kTileY;
+  __syncthreads();
+  for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+    const int t = t0 + tid;
+    bool listed = false;
+    unsigned entry = 0;
+    if (t < ntiles) {
+      const int tx = t % a.tiles_x, ty = t / a.tiles_x;
+      const bool dirty = a.zero_ptr && (!a.flags_other || a.flags_other[t] != 0);
+      bool active = false;
+      for (int dy = -ny; dy <= ny; dy++)
+        for (int dx = -nx; dx <= nx; dx++) {
+          const int x = tx + dx, y = ty + dy;
+          if (x >= 0 && y >= 0 && x < a.tiles_x && y < a.tiles_y) {
+            const int q = y * a.tiles_x + x;
+            active = active || a.flags_cur[q] != 0 || (a.igp && a.flags_igp && a.flags_igp[q] != 0);
+          }
+        }
+      if (dirty && a.flags_other) a.flags_other[t] = 0;
+      listed = active || dirty;
+      entry = (unsigned)t | (active ? 0x80000000u : 0u) | (dirty ? 0x40000000u : 0u);
+    }
+    const unsigned long long m = __ballot(listed);
+    const unsigned before = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned off = base_sh, tot = 0;
+    for (int w = 0; w < 16; w++) {
+      if (w < wave) off += wave_tot[w];
+      tot += wave_tot[w];
+    }
+    if (listed) list[off + before] = entry;
+    __syncthreads();
+    if (tid == 0) base_sh += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *count = base_sh;
+}
+void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *count, unsigned *next_count, bool ordered, hipStream_t s) {
+  const int ntiles = a.tiles_x * a.tiles_y;
+  if (ordered) hipLaunchKernelGGL(tile_list_ordered_kernel, dim3(1), dim3(1024), 0, s, a, reach, list, count, next_count);
+  else hipLaunchKernelGGL(tile_list_kernel, dim3((ntiles + 1023) / 1024), dim3(1024), 0, s, a, reach, list, count, next_count);
 }
 
 // contrast / gradient from the moments (fp64):
@@ -549,6 +598,33 @@ __device__ __forceinline__ bool tail_arrive(const TailArgs &tl, int nblocks, int
   }
   __syncthreads();
   return sm.is_last != 0;
+}
+
+// Sharded large panoramas: first and last tile row that carries a flag in the (all-reduced) occupancy map, written to
+// mapped host memory for the NEXT evaluation's exchange, and whether any flagged row lies outside the band [lo, hi] the
+// host sized THIS evaluation's exchange for (cmx_comm.cpp).  One workgroup.
+__global__ __launch_bounds__(256) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out) {
+  __shared__ int sh_lo, sh_hi;
+  if (threadIdx.x == 0) { sh_lo = tiles_y; sh_hi = -1; }
+  __syncthreads();
+  int my_lo = tiles_y, my_hi = -1;
+  const int n = tiles_x * tiles_y;
+  for (int t = threadIdx.x; t < n; t += 256)
+    if (flags[t]) {
+      const int row = t / tiles_x;
+      my_lo = min(my_lo, row);
+      my_hi = max(my_hi, row);
+    }
+  if (my_hi >= 0) { atomicMin(&sh_lo, my_lo); atomicMax(&sh_hi, my_hi); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (double)sh_lo;
+    out[1] = (double)sh_hi;
+    out[2] = (sh_hi >= 0 && (sh_lo < lo || sh_hi > hi)) ? 1.0 : 0.0;
+  }
+}
+void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(256), 0, s, flags, tiles_x, tiles_y, lo, hi, out);
 }
 
 size_t image_lds_bytes(int r) {

@@ -254,7 +254,13 @@ int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip) {
 // large panoramas: compact the tiles that need work (call once a.partials / flags / zero_ptr are final)
 int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
   if (!a.flags_cur || a.nblk <= kTileListMin) return CMX_OK;
-  if (c->deterministic) return CMX_OK;  // the list is compacted through atomics: its order, hence the order of the moment rows, varies
+  // The order of the list is the order finalize sums the tiles' moment rows in.  CMX_OPT_DETERMINISTIC: no list (which
+  // tiles are listed -- dirty ones included -- depends on the history, and so would the grouping of the sum).  Sharded
+  // evaluations: every rank must obtain bit-identical numbers or the replicated optimiser drivers stop taking the same
+  // decisions; the ranks share flags and history, so a list built in TILE ORDER by one workgroup is the same on all of
+  // them (the atomically compacted one is not).
+  if (c->deterministic) return CMX_OK;
+  const bool ordered = c->sharded();
   if ((size_t)a.nblk > c->tile_list_cap || !c->d_tile_list) {
     if (c->d_tile_list) HIP_TRY(c, hipFree(c->d_tile_list));
     if (c->d_tile_count) HIP_TRY(c, hipFree(c->d_tile_count));
@@ -267,7 +273,7 @@ int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
   }
   unsigned *cur = c->d_tile_count + c->tile_count_sel, *next = c->d_tile_count + (c->tile_count_sel ^ 1);
   c->tile_count_sel ^= 1;  // this pass counts in `cur` and zeroes `next` for the pass after it
-  launch_tile_list(a, reach, c->d_tile_list, cur, next, c->stream);
+  launch_tile_list(a, reach, c->d_tile_list, cur, next, ordered, c->stream);
   a.tile_list = c->d_tile_list;
   a.tile_count = cur;
   return CMX_OK;

@@ -80,7 +80,7 @@ class _Evaluator:
         s = np.zeros(8)
         self._ck(self._L.cmx_get_stats(self._ctx, _dp(s)))
         return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3]),
-                "reuse_hits": int(s[4])}
+                "reuse_hits": int(s[4]), "sharded_host_syncs": int(s[5]), "band_misses": int(s[6]), "band_rows": int(s[7])}
 
     def set_fast_path(self):
         """The production configuration and the library's default: adjoint gradient + LDS-privatised splat (+ image
@@ -125,6 +125,19 @@ class _Evaluator:
 
     def comm_attach(self, unique_id, rank, nranks):
         self._ck(self._L.cmx_comm_attach(self._ctx, C.c_char_p(unique_id), int(rank), int(nranks)))
+
+    def comm_attach_custom(self, fn, rank, nranks):
+        """Exchange through a caller-supplied all-reduce: fn(device_ptr, count, dtype, op, hip_stream) -> 0 on success
+        (dtype / op: _lib.DT_* / _lib.OP_*), called at the evaluator's exchange points in place of RCCL."""
+        def tramp(_user, buf, count, dt, op, stream):
+            try:
+                return int(fn(buf, count, dt, op, stream) or 0)
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._comm_cb = _lib.ALLREDUCE_FN(tramp)  # keep the trampoline alive as long as it is attached
+        self._ck(self._L.cmx_comm_attach_custom(self._ctx, C.cast(self._comm_cb, C.c_void_p), None, int(rank), int(nranks)))
 
     def comm_detach(self):
         self._ck(self._L.cmx_comm_detach(self._ctx))

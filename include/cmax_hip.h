@@ -227,15 +227,30 @@ int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
 /* Native exchange: attach an RCCL communicator to the context (one process per GPU) and every cmx_*_eval / cmx_*_solve
  * performs the all-reduces itself, in place, on the context's stream -- partial planes after the splat, and the 2P
  * partial gradient sums after the gather pass (adjoint mode).  All ranks therefore see identical contrast / gradient
- * and take identical optimiser decisions.  Back-end planes of 8 MB and more are exchanged as the band of image rows some
- * rank voted into (their tile-occupancy flags are all-reduced with max first); smaller planes travel whole.
- * Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher
- * distributes it by whatever means it has (torch.distributed broadcast in bench.py, MPI, a file).  RCCL is dlopen()ed
- * at this point only; hosts that never attach a communicator do not need it installed. */
+ * and take identical optimiser decisions.  Every rank must use the same options (cmx_set_option) and issue the same
+ * sequence of calls; which collectives an evaluation issues then depends on rank-invariant state only (plane size,
+ * options, call sequence) -- never on how many events a rank happens to hold (an empty shard takes part like any other).
+ * Back-end planes of 8 MB and more are exchanged as a band of image rows: the tile-occupancy flags are all-reduced
+ * (max), a kernel reduces them to the first / last touched tile row, and the rows exchanged are the band the PREVIOUS
+ * evaluation found (widened by two tile rows; the whole plane on a window's first evaluation) -- no host
+ * synchronisation between splat and blur.  The same kernel reports whether a touched row lay outside that band; if so
+ * (parameters jumped) the evaluation is completed by exchanging the remaining rows and finishing again.  Smaller planes
+ * travel whole.  cmx_get_stats reports host synchronisations inside sharded evaluations (0) and band misses.
+ * Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher distributes it by whatever means it has
+ * (torch.distributed broadcast in bench.py, MPI, a file).  RCCL is dlopen()ed at this point only; hosts that never
+ * attach a communicator do not need it installed. */
 #define CMX_COMM_ID_BYTES 128
 int cmx_comm_unique_id(char id[CMX_COMM_ID_BYTES]);
 int cmx_comm_attach(cmx_ctx *ctx, const char id[CMX_COMM_ID_BYTES], int rank, int nranks);
 int cmx_comm_detach(cmx_ctx *ctx);
+/* The same exchange points over a caller-supplied transport (MPI, a shared-memory ring, a test harness): `fn` must
+ * all-reduce `count` elements at `device_buf` IN PLACE across the nranks participants, ordered after the work already
+ * queued on `hip_stream` and before work queued afterwards (i.e. enqueue on that stream, or synchronise it, exchange, and
+ * return), and return 0 on success.  Ranks call it in the same order with the same count / dtype / op. */
+enum { CMX_DT_U8 = 0, CMX_DT_F32 = 1, CMX_DT_F64 = 2 };
+enum { CMX_OP_SUM = 0, CMX_OP_MAX = 1 };
+typedef int (*cmx_allreduce_fn)(void *user, void *device_buf, size_t count, int dtype, int op, void *hip_stream);
+int cmx_comm_attach_custom(cmx_ctx *ctx, cmx_allreduce_fn fn, void *user, int rank, int nranks);
 
 /* ------------------------------------------------------------------ optimiser driver (host C++) ----------
  * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors
@@ -307,7 +322,10 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * CMX_T_BATCH: the back end's per-batch pass of the gradient gather.  Every class except CMX_T_ZERO / CMX_T_COMM is timed
  * through events carried by its (main) kernel: the dispatch's own begin / end timestamps, what rocprofv3 reports. */
 /* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
- * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5..7] reserved */
+ * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
+ * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
+ * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
+ * (-1: whole plane) */
 int cmx_get_stats(cmx_ctx *ctx, double stats[8]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
