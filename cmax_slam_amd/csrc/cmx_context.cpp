@@ -62,6 +62,33 @@ int upload_gt1(cmx_ctx *c) {
     int rc = ensure(c, dst, cap, (size_t)L);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+    if (c->kind == KIND_FE && r <= kFusedMaxRadius) {
+      // banded composite operator M = G^T G of this axis: (M x)[q] = sum_i M[q][i] x[q - 2r + i], where
+      // G[p][s] = sum_j taps[r+j] [reflect101(p+j) == s] is the REFLECT_101 blur (the forward pass of the image kernels)
+      const int bw = 4 * r + 1;
+      std::vector<double> G((size_t)L * (2 * r + 1), 0.0);  // G[p][s - (p - r)] for s in [p-r, p+r]
+      auto refl = [L](int p) { if (L == 1) return 0; while (p < 0 || p >= L) p = p < 0 ? -p : 2 * (L - 1) - p; return p; };
+      for (int p = 0; p < L; p++)
+        for (int j = -r; j <= r; j++) {
+          const int s2 = refl(p + j);
+          if (s2 >= p - r && s2 <= p + r) G[(size_t)p * (2 * r + 1) + (s2 - (p - r))] += (double)c->taps[r + j];
+        }
+      std::vector<float> M((size_t)L * bw, 0.f);
+      for (int q = 0; q < L; q++)
+        for (int i = 0; i < bw; i++) {
+          const int s2 = q - 2 * r + i;
+          if (s2 < 0 || s2 >= L) continue;
+          double acc = 0;
+          for (int p = std::max(0, std::max(q, s2) - r); p <= std::min(L - 1, std::min(q, s2) + r); p++)
+            acc += G[(size_t)p * (2 * r + 1) + (q - (p - r))] * G[(size_t)p * (2 * r + 1) + (s2 - (p - r))];
+          M[(size_t)q * bw + i] = (float)acc;
+        }
+      float *&dm = axis == 0 ? c->d_Mx : c->d_My;
+      size_t &mcap = axis == 0 ? c->Mx_cap : c->My_cap;
+      rc = ensure(c, dm, mcap, M.size());
+      if (rc) return rc;
+      HIP_TRY(c, hipMemcpy(dm, M.data(), M.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   return CMX_OK;
 }
@@ -258,6 +285,8 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_itilde);
   hipFree(c->d_cx);
   hipFree(c->d_cy);
+  hipFree(c->d_Mx);
+  hipFree(c->d_My);
   hipFree(c->d_gpartials);
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
@@ -298,6 +327,9 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_TAIL_FINALIZE:
       c->tail_finalize = value != 0;
       return CMX_OK;
+    case CMX_OPT_FUSED_GATHER:
+      c->fused_gather = value != 0;
+      return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
 }
@@ -318,8 +350,9 @@ int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
   return CMX_OK;
 }
 
-int cmx_get_stats(cmx_ctx *c, double stats[8]) {
+int cmx_get_stats(cmx_ctx *c, double stats[16]) {
   if (!c || !stats) return CMX_ERR_INVALID_ARG;
+  for (int i = 0; i < 16; i++) stats[i] = 0;
   stats[0] = (double)c->rebin_count;
   stats[1] = c->last_fallback_frac;
   {  // true length of the chunk table (device-resident until the first evaluation after a binning has been collected)
@@ -333,6 +366,7 @@ int cmx_get_stats(cmx_ctx *c, double stats[8]) {
   stats[5] = (double)c->sharded_host_syncs;
   stats[6] = (double)c->band_misses;
   stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
+  stats[8] = (double)c->fused_evals;
   return CMX_OK;
 }
 

@@ -79,6 +79,14 @@ enum {
                              its last-arriving workgroup (write-through partial sums, tickets sharded by XCD, one agent-scope
                              acquire) instead of a separate one-workgroup launch behind a kernel boundary.
                              0: separate finalize launch (the round-1 flow) */
+  CMX_OPT_FUSED_GATHER = 7, /* 1 (default 0; front end, adjoint gradient, LDS-privatised splat, blur radius 2..4, no communicator,
+                             not deterministic): the gradient pass builds Jt = G^T G I on each chunk's 64x64 vote window in
+                             LDS (banded composite operator, register-blocked) and gathers from it -- the image_adjoint launch,
+                             its kernel boundary and the Jt plane disappear, the image moments come out of the same pass.
+                             Votes that left their window apply the operator directly on the vote plane; above 2 % of such
+                             votes an evaluation takes the separate-image-pass flow.  Exact, tested, and SLOWER on MI355X at
+                             BASELINE config 2 (45.9 vs 41.5 us per fdf: 651 windows of 64x64 are 8.7x the pixels of the one
+                             image pass), hence opt-in */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
                              than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
@@ -321,12 +329,12 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
 /* CMX_T_FINAL: the separate finalize launch (absent when CMX_OPT_TAIL_FINALIZE folds it into the last kernel);
  * CMX_T_BATCH: the back end's per-batch pass of the gradient gather.  Every class except CMX_T_ZERO / CMX_T_COMM is timed
  * through events carried by its (main) kernel: the dispatch's own begin / end timestamps, what rocprofv3 reports. */
-/* stats[0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
+/* stats (16 doubles): [0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane) */
-int cmx_get_stats(cmx_ctx *ctx, double stats[8]);
+ * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [9..15] reserved */
+int cmx_get_stats(cmx_ctx *ctx, double stats[16]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
 

@@ -56,8 +56,8 @@ def run(kind, events, reps, variants):
         ev.timing_enable(False)
         ks = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in tim.items() if v[1])
         kf = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in timf.items() if v[1])
-        print("%s %-18s fdf %.4f ms  f %.4f ms  c=%.9g |g|=%.6g   fdf kernels(us): %s   f kernels(us): %s"
-              % (kind, name, ms_fdf, ms_f, c, float(np.abs(g).max()), ks, kf), flush=True)
+        print("%s %-20s fdf %.4f ms  f %.4f ms  c=%.10g g=%s fused=%d  fdf kernels(us): %s   f kernels(us): %s"
+              % (kind, name, ms_fdf, ms_f, c, np.array2string(np.asarray(g)[:3], precision=8), ev.stats()["fused_evals"], ks, kf), flush=True)
     ev.close()
 
 
@@ -72,8 +72,11 @@ def main():
         elif "=" in a:
             k, v = a.split("=")
             kv[k] = int(v)
-    variants = [("tail=1", {_lib.OPT_TAIL_FINALIZE: 1}), ("tail=0", {_lib.OPT_TAIL_FINALIZE: 0}),
-                ("tail=1 again", {_lib.OPT_TAIL_FINALIZE: 1})]
+    variants = [("fused=1 tail=1", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1}),
+                ("fused=0 tail=1", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 1}),
+                ("fused=1 tail=0", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 0}),
+                ("fused=0 tail=0", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 0}),
+                ("fused=1 tail=1 again", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1})]
     for kind in kinds:
         run(kind, kv.get("events"), kv.get("reps", 300 if kind == "fe" else 100), variants)
 
