@@ -281,6 +281,7 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   c->last_P = P;
   c->accumulated = true;
   c->x_valid = true;
+  c->jt_valid = false;
   for (int k = 0; k < 3 * Kopt && k < 3 * kMaxKnots; k++) c->last_x[k] = drotv[k];
   return CMX_OK;
 }
@@ -339,6 +340,7 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   rc = be_first_iter(c);
   if (rc) return rc;
   if (grad && c->last_adjoint) rc = run_adjoint(c, P);
+  else if (!grad && speculative_jt_ok(c) && P > 0) rc = run_adjoint(c, P, /*phase=*/3);
   else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c, true);

@@ -367,6 +367,8 @@ int cmx_get_stats(cmx_ctx *c, double stats[16]) {
   stats[6] = (double)c->band_misses;
   stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
   stats[8] = (double)c->fused_evals;
+  stats[9] = (double)c->spec_images;
+  stats[10] = (double)c->spec_hits;
   return CMX_OK;
 }
 

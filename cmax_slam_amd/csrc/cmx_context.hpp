@@ -124,6 +124,9 @@ struct cmx_ctx {
   bool adj_direct = false;                   // shape of the moment partials the last adjoint image pass produced
   const unsigned *adj_tile_count = nullptr;  // (run_adjoint phase 1 -> phase 2)
   bool x_valid = false;       // plane 0 (and the pose table) hold the accumulation for last_x
+  bool jt_valid = false;      // ... and Jt + the moment rows hold the adjoint image pass of those planes (speculative, see
+                              // speculative_jt_ok); cleared by every accumulate
+  int64_t spec_images = 0, spec_hits = 0;
   int reuse_image = 1;        // df right after f at the same point reuses the image (CMX_OPT_REUSE_IMAGE)
   int64_t reuse_hits = 0;
   double last_x[3 * kMaxKnots] = {0};  // parameters of the last accumulate (the gather pass re-warps the events)
@@ -287,7 +290,8 @@ bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail);  // true: the next l
 int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip);
 int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach);
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd);
-int run_adjoint(cmx_ctx *c, int P, int phase = 0);
+int run_adjoint(cmx_ctx *c, int P, int phase = 0);  // phase 3: image pass + cost-only finalize, Jt kept
+bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
 int finish_begin(cmx_ctx *c, int kind, int want_grad);

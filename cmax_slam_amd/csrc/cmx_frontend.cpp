@@ -128,6 +128,7 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->last_P = nplanes - 1;
   c->accumulated = true;
   c->x_valid = true;
+  c->jt_valid = false;
   return CMX_OK;
 }
 
@@ -150,6 +151,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   int rc = bind_device(c);
   if (rc) return rc;
   if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
+  else if (!grad && speculative_jt_ok(c)) rc = run_adjoint(c, 3, /*phase=*/3);
   else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
   if (rc) return rc;
   rc = sync_and_collect(c, true);

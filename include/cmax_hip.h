@@ -66,7 +66,9 @@ enum {
                                  applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */
   CMX_OPT_REUSE_IMAGE = 3, /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
                              the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
-                             df at every accepted point; the reference recomputes everything, :58-70) */
+                             df at every accepted point; the reference recomputes everything, :58-70).  A cost-only
+                             evaluation then also runs the adjoint image pass (Jt) instead of the moments-only pass, so the
+                             df that follows launches its gather at once: +3..4 us per f, -12 us per df */
   CMX_OPT_DETERMINISTIC = 5, /* 1: bitwise run-to-run reproducible results (default 0).  With the LDS-privatised splat
                              (CMX_OPT_SPLAT_MODE 1, adjoint gradient or cost-only) every vote that reaches global memory
                              becomes a 64-bit integer add into a 2^-30 fixed-point plane -- integer adds commute -- and
@@ -333,7 +335,8 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [9..15] reserved */
+ * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [9] = cost-only evaluations that ran
+ * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [11..15] reserved */
 int cmx_get_stats(cmx_ctx *ctx, double stats[16]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
