@@ -233,7 +233,7 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   BeSplatArgs a = be_args(c);
   const bool lds_mode = c->splat_mode == 1 && !deriv;  // what this call would use for any number of events
   const bool use_lds = lds_mode && c->n_packed > 0;
-  if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
+  if (use_lds && (!c->bin_valid || c->last_fallback_frac > kRebinFallbackFrac)) {
     rc = do_binning(c, nullptr, &a);
     if (rc) return rc;
   }

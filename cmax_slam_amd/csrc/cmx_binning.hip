@@ -19,11 +19,25 @@
 
 namespace cmx {
 
+// Sort key = the 32x32 tile the vote lands in.  A vote that is NOT accepted under the binning parameters but lies within
+// the window margin of the accepted region is keyed by the nearest accepted cell: when the parameters move it inside (a
+// sensor-border event at omega = 0 a solve starts from; ~1 % of the events) it then finds itself in that tile's LDS
+// window.  Left in the no-window sentinel these votes took the global-atomic path from ONE or two workgroups, which made
+// them the kernel's critical path: 0.26 % of such votes cost the 1M-event splat 9.5 -> 15 us (profiles/r02_splat_drift.txt).
+__device__ __forceinline__ uint32_t tile_key(int xx, int yy, bool ok, int W, int H, int tiles_x, uint32_t sentinel) {
+  if (!ok) {
+    if (xx < 1 - kBinMargin || xx >= W - 2 + kBinMargin || yy < 1 - kBinMargin || yy >= H - 2 + kBinMargin) return sentinel;
+    xx = min(max(xx, 1), W - 3);
+    yy = min(max(yy, 1), H - 3);
+  }
+  return (uint32_t)((yy / kBinTile) * tiles_x + xx / kBinTile);
+}
+
 __global__ __launch_bounds__(256) void fe_bin_keys_kernel(FeSplatArgs a, int tiles_x, int ntiles, uint32_t *keys,
                                                           uint32_t *idx) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
     const FeWarp w = fe_warp_event<false>(a, i);
-    keys[i] = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    keys[i] = tile_key(w.xx, w.yy, w.ok, a.W, a.H, tiles_x, (uint32_t)ntiles);
     idx[i] = (uint32_t)i;
   }
 }
@@ -33,7 +47,8 @@ __global__ __launch_bounds__(256) void be_bin_keys_kernel(BeSplatArgs a, int til
     const BeWarp w = be_warp_event<0>(a, i);
     // the IL_old / IL_new split is a property of the event (its timestamp), so it can be part of the sort key:
     // every chunk then votes into ONE plane and needs one LDS window
-    keys[i] = w.ok ? (uint32_t)(2 * ((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) + (w.is_old ? 0 : 1)) : (uint32_t)(2 * ntiles);
+    const uint32_t t = tile_key(w.xx, w.yy, w.ok, a.Wp, a.Hp, tiles_x, (uint32_t)ntiles);
+    keys[i] = t == (uint32_t)ntiles ? (uint32_t)(2 * ntiles) : 2 * t + (w.is_old ? 0u : 1u);
     idx[i] = (uint32_t)i;
   }
 }
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(kBinBlock) void fe_bin_hist_kernel(FeSplatArgs a, i
   const int beg = blockIdx.x * per_block, end = min(a.n, beg + per_block);
   for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
     const FeWarp w = fe_warp_event<false>(a, i);
-    const uint32_t key = w.ok ? (uint32_t)((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) : (uint32_t)ntiles;
+    const uint32_t key = tile_key(w.xx, w.yy, w.ok, a.W, a.H, tiles_x, (uint32_t)ntiles);
     keys[i] = key;
     atomicAdd(&hist_sh[key], 1);
   }
@@ -127,8 +142,8 @@ __global__ __launch_bounds__(kBinBlock) void be_bin_hist_kernel(BeSplatArgs a, i
   const int beg = blockIdx.x * per_block, end = min(a.n, beg + per_block);
   for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
     const BeWarp w = be_warp_event<0>(a, i);
-    const uint32_t key = w.ok ? (uint32_t)(2 * ((w.yy / kBinTile) * tiles_x + w.xx / kBinTile) + (w.is_old ? 0 : 1))
-                              : (uint32_t)(2 * ntiles);
+    const uint32_t t = tile_key(w.xx, w.yy, w.ok, a.Wp, a.Hp, tiles_x, (uint32_t)ntiles);
+    const uint32_t key = t == (uint32_t)ntiles ? (uint32_t)(2 * ntiles) : 2 * t + (w.is_old ? 0u : 1u);
     keys[i] = key;
     atomicAdd(&hist_sh[key], 1);
   }
@@ -253,6 +268,7 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 // falling size classes beyond that) -- with an unsorted tail the back-end splat ran 68 us instead of 52.  Entry
 // `ntiles` is the sentinel tile of events whose vote is not accepted under the binning parameters: no LDS window.
 constexpr int kRankSortMax = 4096;
+constexpr int kSentinelChunk = 256;  // == cmx_internal.hpp's bound in do_binning (max_chunks)
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start_g, int ntiles, int planes_per_tile, int tiles_x,
                                                             int margin, int M, Chunk *chunks, int *count) {
   __shared__ int wave_tot[16];
@@ -269,6 +285,9 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
     __syncthreads();
     tile_start = ts_sh;
   }
+  // the no-window sentinel's events take the global-atomic path if they become valid: small chunks, so that this serial
+  // work is spread over many workgroups instead of forming the tail of the launch
+  auto Mof = [&](int t) { return t == ntiles ? min(M, kSentinelChunk) : M; };
   auto make_chunk = [&](int t, int beg, int end) {
     const bool sentinel = (t == ntiles);
     const int tile = t / planes_per_tile, plane = t % planes_per_tile;
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       beg = tile_start[t];
       int len = tile_start[t + 1] - beg;
       if (len < 0) len = 0;
-      nfull = len / M;
+      nfull = len / Mof(t);
     }
     int incl = nfull;
 #pragma unroll
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       if (w < wave) off += wave_tot[w];
       tot += wave_tot[w];
     }
-    for (int k = 0; k < nfull; k++) chunks[off + k] = make_chunk(t, beg + k * M, beg + (k + 1) * M);
+    for (int k = 0; k < nfull; k++) chunks[off + k] = make_chunk(t, beg + k * Mof(t), beg + (k + 1) * Mof(t));
     __syncthreads();
     if (tid == 0) base_sh += tot;
     __syncthreads();
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
     for (int t = tid; t < T; t += 1024) {
       int len = tile_start[t + 1] - tile_start[t];
       if (len < 0) len = 0;
-      const int rem = len % M;
+      const int rem = len % Mof(t);
       if (rem) key_sh[atomicAdd(&nnz_sh, 1)] = ((uint32_t)rem << 12) | (uint32_t)(4095 - t);
     }
     __syncthreads();
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       if (key == 0) continue;
       const int t = 4095 - (int)(key & 4095u);
       const int beg = tile_start[t], len = tile_start[t + 1] - beg;
-      chunks[nfull_total + p] = make_chunk(t, beg + (len / M) * M, beg + len);
+      chunks[nfull_total + p] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
       nrem++;
     }
     // block-wide sum of nrem
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
         beg = tile_start[t];
         len = tile_start[t + 1] - beg;
         if (len < 0) len = 0;
-        rem = len % M;
+        rem = len % Mof(t);
       }
       const int mine = (rem > lo && rem <= hi) ? 1 : 0;
       int incl = mine;
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
         if (w < wave) off += wave_tot[w];
         tot += wave_tot[w];
       }
-      if (mine) chunks[off] = make_chunk(t, beg + (len / M) * M, beg + len);
+      if (mine) chunks[off] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
       __syncthreads();
       if (tid == 0) base_sh += tot;
       __syncthreads();

@@ -27,7 +27,10 @@ using namespace cmx;  // internal header of one library: the parameter blocks of
 
 enum { KIND_FE = 1, KIND_BE = 2 };
 constexpr long long kMaxPixels = 1LL << 29;  // per plane (sensor or panorama): pixel loops use 32-bit ints, up to 3 planes interleaved
-constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
+constexpr long long kMaxEvents = 1LL << 30;
+// Re-sort the events by destination tile once more than this share of the votes left their LDS windows: a vote on the
+// global-atomic path costs the 1M-event splat ~3.7 us per percent (9.5 % -> 44 us instead of 9.5), a re-sort ~60 us once
+constexpr double kRebinFallbackFrac = 0.03;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
 
 struct TimedSpan { int cls; hipEvent_t a, b; };
 typedef struct ncclComm *ncclComm_t;  // as <rccl/rccl.h> declares it; only cmx_comm.cpp includes that header

@@ -102,7 +102,7 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   FeSplatArgs a = fe_args(c, omega);
   for (int k = 0; k < 3; k++) c->last_x[k] = omega[k];
   const bool use_lds = c->splat_mode == 1 && nplanes == 1 && c->n_packed > 0;
-  if (use_lds && (!c->bin_valid || c->last_fallback_frac > 0.15)) {
+  if (use_lds && (!c->bin_valid || c->last_fallback_frac > kRebinFallbackFrac)) {
     rc = do_binning(c, &a, nullptr);
     if (rc) return rc;
   }

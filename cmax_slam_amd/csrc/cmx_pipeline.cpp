@@ -91,7 +91,7 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   M = M < 1536 ? 1536 : (M > 32768 ? 32768 : M);  // floor swept on MI355X (1M events: 1536 -> 11.8 us, 2048 -> 12.9, 1024 -> 15.3)
   M = (M + 255) / 256 * 256;
   // every tile contributes floor(len/M) full chunks and at most one remainder: an upper bound known on the host
-  const int max_chunks = (n / M) + ntiles + 2;
+  const int max_chunks = (n / M) + ntiles + 2 + n / 256;  // (+ the sentinel's events in chunks of 256: bound for 'all events rejected')
   rc = ensure(c, c->d_chunks, c->chunks_cap, (size_t)max_chunks);
   if (rc) return rc;
   if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));

@@ -31,7 +31,7 @@ def run(kind, events, reps, variants):
         p = synth.config2(events or 1_000_000)
         ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
         ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
-        x0 = np.array([0.3, -0.5, 0.2])
+        x0 = np.array([0.3, -0.5, 0.2]) if not os.environ.get("AB_OMEGA_TRUE") else np.array(p.omega_true, dtype=float)
     else:
         w = synth.config3(events or 5_000_000)
         ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
@@ -39,6 +39,11 @@ def run(kind, events, reps, variants):
                       w.sample_rate, w.sigma, _lib.VARIANCE)
         x0 = np.zeros(w.P)
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+    if os.environ.get("AB_BIN_AT_ZERO"):
+        # the tile sort is taken at the first evaluation: make that AB_BIN_SCALE * x0 (default 0), then time at scale * x0
+        ev.eval(x0 * float(os.environ.get("AB_BIN_SCALE", "0")), True)
+        scale = float(os.environ["AB_BIN_AT_ZERO"])
+        x0 = x0 * scale
     for name, opts in variants:
         for k, v in opts.items():
             ev.set_option(k, v)
@@ -56,8 +61,9 @@ def run(kind, events, reps, variants):
         ev.timing_enable(False)
         ks = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in tim.items() if v[1])
         kf = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in timf.items() if v[1])
-        print("%s %-20s fdf %.4f ms  f %.4f ms  c=%.10g g=%s fused=%d  fdf kernels(us): %s   f kernels(us): %s"
-              % (kind, name, ms_fdf, ms_f, c, np.array2string(np.asarray(g)[:3], precision=8), ev.stats()["fused_evals"], ks, kf), flush=True)
+        st = ev.stats()
+        print("%s %-20s fdf %.4f ms  f %.4f ms  c=%.10g g=%s rebins=%d fallback=%.4f  fdf kernels(us): %s   f kernels(us): %s"
+              % (kind, name, ms_fdf, ms_f, c, np.array2string(np.asarray(g)[:3], precision=8), st["rebins"], st["fallback_frac"], ks, kf), flush=True)
     ev.close()
 
 
@@ -72,11 +78,11 @@ def main():
         elif "=" in a:
             k, v = a.split("=")
             kv[k] = int(v)
-    variants = [("fused=1 tail=1", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1}),
-                ("fused=0 tail=1", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 1}),
-                ("fused=1 tail=0", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 0}),
-                ("fused=0 tail=0", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 0}),
-                ("fused=1 tail=1 again", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1})]
+    variants = [("default", {})]
+    if "variants" in kv:
+        variants = [("fused=1 tail=1", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1}),
+                    ("fused=0 tail=1", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 1}),
+                    ("fused=0 tail=0", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 0})]
     for kind in kinds:
         run(kind, kv.get("events"), kv.get("reps", 300 if kind == "fe" else 100), variants)
 
