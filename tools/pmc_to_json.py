@@ -1,0 +1,43 @@
+"""profiles/pmc_traffic.json from a tools/gpu_profile.sh summary: per-launch memory-side bytes of the bench's kernels.
+
+FETCH_SIZE / WRITE_SIZE are in KiB (checked: bearing_stream_kernel writes 5M x 16 B = 80.0 MB, WRITE_SIZE = 78125.0).
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half of the bytes of a wide coalesced
+streaming read -- confirmed here on fe_splat_lds (streams 24 B/event = 24.0 MB, FETCH_SIZE = 12.2 MB) and be_gather4
+(100 MB of 16-B/lane streams, FETCH_SIZE = 53.3 MB).  `bytes` = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the kernels whose
+reads are such streams; `raw_bytes` = (FETCH_SIZE + WRITE_SIZE) * 1024 is kept beside it; kernels with mixed access widths
+(be_splat_lds: 4-byte + 16-byte lanes + divergent rotation gathers) list both and bench.py reports the corrected one.
+    python tools/pmc_to_json.py gpurun_out/prof_<tag>/summary.txt"""
+import json
+import os
+import re
+import sys
+
+NAMES = {
+    "fe_splat_lds_kernel": "frontend_fast_splat", "fe_gather_kernel": "frontend_fast_gather",
+    "image_adjoint_kernel<4, 64, 16, 1024, false>": None,  # shared by both ends in one run: split by call order is not possible
+    "be_splat_lds_kernel": "backend_fast_splat", "be_gather4_kernel": "backend_fast_gather",
+    "be_gather_batch_kernel": "backend_fast_batch", "be_pose_table_pre_kernel<4, true>": "backend_fast_pose",
+}
+
+
+def main(path):
+    vals = {}
+    for line in open(path):
+        m = re.match(r"(.{58})\s+(FETCH_SIZE|WRITE_SIZE)\s+([\d.]+)", line)
+        if not m:
+            continue
+        vals.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
+    out = {"_note": __doc__.split("\n    python")[0], "_source": os.path.basename(os.path.dirname(path)) + "/summary.txt", "kernels": {}}
+    for kname, d in vals.items():
+        for pat, key in NAMES.items():
+            if key and pat in kname and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                raw = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+                cor = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+                out["kernels"][key] = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "raw_bytes": raw, "bytes": cor}
+                out[key] = cor
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
