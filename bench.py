@@ -35,7 +35,7 @@ METRIC = "warped-events/sec/GPU (1M ev, 640x480 IWE) + CMax iters/sec"
 
 
 # ---------------------------------------------------------------------------------------------- byte models
-def byte_models(kind, order, n_events, npix, nb, P, adjoint, nnz_pixels):
+def byte_models(kind, order, n_events, npix, nb, P, adjoint, nnz_pixels, image_pixels=None):
     """Per kernel class and per launch: (algorithmic bytes, HBM-mandatory bytes).
 
     ALGORITHMIC = SURVEY.md section 8(d): per warped event 4 B coordinates + 24 B fp64 bearing + 4 px x (4 B read + 4 B
@@ -45,6 +45,7 @@ def byte_models(kind, order, n_events, npix, nb, P, adjoint, nnz_pixels):
     consumes / produces, one 4-byte write per non-zero IWE pixel for the LDS-window flush.  Vote read-modify-writes live
     in LDS and table gathers hit L2, so they are not in it.  `frac` (mandatory bytes / time / peak) can therefore never exceed 1."""
     fe = kind == "frontend"
+    ipx = npix if image_pixels is None else image_pixels  # pixels the image passes touch (back end: occupied tiles + filter reach)
     imgs = 1 if adjoint else (1 + (3 if fe else 3 * order))
     planes_in = 1 if fe else 2
     m = {}
@@ -54,12 +55,12 @@ def byte_models(kind, order, n_events, npix, nb, P, adjoint, nnz_pixels):
     #   bearing 16 B per event, the 72-byte rotation of every batch once
     if adjoint:
         m["gather"] = (n_events * (4 + 24 + 16),
-                       n_events * (24 if fe else 20) + npix * 4 + (0 if fe else nb * 72 + nb * 48))
-        m["image"] = (npix * 4 * (planes_in + 1 + planes_in), npix * 4 * (planes_in + 1 + planes_in))
+                       n_events * (24 if fe else 20) + ipx * 4 + (0 if fe else nb * 72 + nb * 48))
+        m["image"] = (npix * 4 * (planes_in + 1 + planes_in), ipx * 4 * (planes_in + 1 + planes_in))
         #   read the vote plane(s), write Jt, clear the ping-pong partner's plane(s)
     else:
-        m["image"] = (npix * 4 * 6 * (1 + P), npix * 4 * (planes_in + P))
-    m["image_f"] = (npix * 4 * 2 * planes_in, npix * 4 * 2 * planes_in)  # cost-only: read the plane(s), clear the partner
+        m["image"] = (npix * 4 * 6 * (1 + P), ipx * 4 * (planes_in + P))
+    m["image_f"] = (npix * 4 * 2 * planes_in, ipx * 4 * 2 * planes_in)  # cost-only: read the plane(s), clear the partner
     if not fe:
         m["pose"] = (nb * (8 + 72 + 152), nb * (8 + 72 + 152))
         m["batch"] = (nb * (48 + 152), nb * (48 + 152))
@@ -197,7 +198,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
 
     # ---- per-kernel roofline table
     nnz = getattr(run, "nnz_pixels", 0)
-    models = byte_models(kind, order, n_local, npix, nb, P, adjoint, nnz)
+    models = byte_models(kind, order, n_local, npix, nb, P, adjoint, nnz, getattr(run, "image_pixels", None))
     pmc = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -279,7 +280,7 @@ def frontend_workload(args, ctx, per_gpu):
     iwe = ev.computeImageOfWarpedEvents(points[-1], blur=False)
     run.nnz_pixels = int(np.count_nonzero(iwe))
     m = measure(run, points, args.steps, args.warmup, "frontend", 0, end - beg, len(p.x), p.W * p.H, 0, 3, adjoint,
-                "frontend_%s" % args.mode)
+                ("frontend_%s" % args.mode) if (world == 1 and per_gpu == 1_000_000) else "none")
     name = "BASELINE config 2: front-end fdf, %d synthetic events/GPU, 640x480 IWE, batch 100, sigma 1, variance" % per_gpu
     return ev, run, p, m, name, "%dx%d" % (p.W, p.H), points
 
@@ -330,11 +331,23 @@ def backend_workload(args, ctx, which, per_gpu, steps):
         points = [np.zeros(w.P)] + [rng.normal(0, 0.004, w.P) * s for s in (0.3, 0.6, 0.9, 1.0)]
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
     ev.accumulate(points[-1], False)
-    run.nnz_pixels = int(np.count_nonzero(ev.get_plane(_lib.PLANE_IL_OLD)) + np.count_nonzero(ev.get_plane(_lib.PLANE_IL_NEW)))
+    il_old, il_new = ev.get_plane(_lib.PLANE_IL_OLD), ev.get_plane(_lib.PLANE_IL_NEW)
+    run.nnz_pixels = int(np.count_nonzero(il_old) + np.count_nonzero(il_new))
+    # the image passes skip 64x16 tiles with nothing (votes or global map) within the filter's reach: count what is left
+    occ = (il_old != 0) | (il_new != 0)
+    if IG is not None:
+        occ |= IG != 0
+    Hp, Wp = occ.shape
+    tiles = occ[:Hp // 16 * 16, :Wp // 64 * 64].reshape(Hp // 16, 16, Wp // 64, 64).any(axis=(1, 3))
+    grown = tiles.copy()
+    for dy in (-1, 0, 1):      # reach of the 2r = 8 pixel halo: the neighbouring tiles
+        for dx in (-1, 0, 1):
+            grown |= np.roll(np.roll(tiles, dy, 0), dx, 1)
+    run.image_pixels = int(min(grown.sum() * 1024, Wp * Hp))
     n_local = len(w.x)
     nb = (n_local - 1 + w.batch - 1) // w.batch
     m = measure(run, points, steps, args.warmup, "backend", w.order, n_local, n_local * world, w.Wp * w.Hp, nb, w.P, adjoint,
-                "backend_%s" % args.mode)
+                ("backend_%s" % args.mode) if (which == "config3" and per_gpu == 5_000_000) else "none")
     desc = {"config3": "BASELINE config 3: back-end BA fdf, %d synthetic events, cubic 10-knot SO(3) spline (P=21), 1024x1024 pano",
             "config4": "BASELINE config 4: back-end BA sliding window fdf, %d synthetic events/GPU (time slab per rank), cubic 10-knot "
                        "spline (P=21), 1024x1024 pano",

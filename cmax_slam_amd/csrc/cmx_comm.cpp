@@ -81,7 +81,15 @@ static int exchange_planes(cmx_ctx *c) {
                       c->accum_count == 2 * np;
   if (!sparse) {
     int rc = comm_allreduce(c, c->d_accum, c->accum_count, CMX_DT_F32);  // sum of the ranks' partial planes
-    c->accum_flagged = false;  // the planes now hold other ranks' votes this rank's occupancy flags know nothing about
+    // the planes now hold other ranks' votes this rank's occupancy flags know nothing about: rebuild the flags from the
+    // summed planes (one small launch) so that the image passes keep skipping the empty tiles of the panorama -- without
+    // them the image pass of BASELINE config 4 (1024^2) took 26.6 us instead of 10.6
+    if (!rc && c->kind == KIND_BE && c->accum_flagged && c->d_tflags && c->accum_count == 2 * np) {
+      launch_tile_flags_pair(c->d_accum, c->d_accum + np, c->Wp, c->Hp, c->d_tflags, c->stream);
+      HIP_TRY(c, hipGetLastError());
+    } else {
+      c->accum_flagged = false;
+    }
     return rc;
   }
   const int tiles_x = (c->Wp + kTileX - 1) / kTileX, tiles_y = (c->Hp + kTileY - 1) / kTileY;

@@ -248,6 +248,7 @@ void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t
 void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s);
+void launch_tile_flags_pair(const float *a, const float *b, int W, int H, unsigned char *flags, hipStream_t s);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);

@@ -264,6 +264,25 @@ __global__ __launch_bounds__(256) void tile_flags_kernel(const float *plane, int
       flags[(y / kTileY) * tiles_x + x / kTileX] = 1;
     }
 }
+// occupancy of TWO summed planes (IL_old, IL_new after a whole-plane all-reduce): one workgroup per tile writes its flag,
+// 0 or 1 -- no memset in front, one launch
+__global__ __launch_bounds__(256) void tile_flags_pair_kernel(const float *a, const float *b, int W, int H, int tiles_x, unsigned char *flags) {
+  const int tile = blockIdx.x, x0 = (tile % tiles_x) * kTileX, y0 = (tile / tiles_x) * kTileY;
+  bool any = false;
+  for (int q = threadIdx.x; q < kTileX * kTileY; q += 256) {
+    const int x = x0 + (q % kTileX), y = y0 + (q / kTileX);
+    if (x < W && y < H) {
+      const size_t o = (size_t)y * W + x;
+      any = any || a[o] != 0.f || b[o] != 0.f;
+    }
+  }
+  const int r = __syncthreads_or(any ? 1 : 0);
+  if (threadIdx.x == 0) flags[tile] = r ? 1 : 0;
+}
+void launch_tile_flags_pair(const float *a, const float *b, int W, int H, unsigned char *flags, hipStream_t s) {
+  const int tiles_x = (W + kTileX - 1) / kTileX, tiles_y = (H + kTileY - 1) / kTileY;
+  hipLaunchKernelGGL(tile_flags_pair_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, s, a, b, W, H, tiles_x, flags);
+}
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s) {
   const int tiles_x = (W + kTileX - 1) / kTileX;
   hipLaunchKernelGGL(tile_flags_kernel, dim3(1024), dim3(256), 0, s, plane, W, H, tiles_x, flags);
