@@ -70,6 +70,9 @@ def main(n_cfg, gpu):
         v = np.array([r[k] for r in rows])
         print("  %-22s median %.2e  90%% %.2e  99%% %.2e  max %.2e  above 1e-5: %.2f%%" %
               (k, np.median(v), np.quantile(v, 0.9), np.quantile(v, 0.99), v.max(), 100 * np.mean(v > 1e-5)))
+    for sg in sorted(set(r["sigma"] for r in rows)):
+        sel = [r for r in rows if r["sigma"] == sg]
+        print("  sigma %.1f (%d evaluations): max " % (sg, len(sel)) + "  ".join("%s %.2e" % (k, max(r[k] for r in sel)) for k in keys if not k.startswith("c_")))
     key = "fast_vs_oracle" if gpu else "oracle_vs_exact"
     for r in sorted(rows, key=lambda r: -r[key])[:10]:
         print("  " + "  ".join("%s=%s" % (k, ("%.2e" % v) if isinstance(v, float) and k not in ("sigma",) else v) for k, v in r.items()))
