@@ -13,8 +13,6 @@ int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lu
   cmx_ctx *c = *out;
   c->Wp = Wp; c->Hp = Hp;
   c->imgW = Wp; c->imgH = Hp;
-  c->tail_finalize = false;  // measured on MI355X (config 3): the 42-column partial table makes the tail 1.5-2 us slower than the
-                             // separate finalize launch; the front end gains 0.6 us.  CMX_OPT_TAIL_FINALIZE overrides.
   const size_t np = (size_t)Wp * Hp;
   HIP_TRY(c, hipMalloc((void **)&c->d_IG, np * sizeof(float)));
   HIP_TRY(c, hipMalloc((void **)&c->d_IGp, np * sizeof(float)));

@@ -325,7 +325,7 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       c->ticket_wait = value != 0;
       return CMX_OK;
     case CMX_OPT_TAIL_FINALIZE:
-      c->tail_finalize = value != 0;
+      c->tail_finalize = value < 0 ? 0 : (value > 2 ? 2 : value);
       return CMX_OK;
     case CMX_OPT_FUSED_GATHER:
       c->fused_gather = value != 0;

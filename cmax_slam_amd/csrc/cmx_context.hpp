@@ -172,7 +172,7 @@ struct cmx_ctx {
   int ticket_nout = 0;                   // result words that launch writes
   bool ticket_wait = true;
   size_t result_cap = 0;
-  bool tail_finalize = true;          // CMX_OPT_TAIL_FINALIZE
+  int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
 
   // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place

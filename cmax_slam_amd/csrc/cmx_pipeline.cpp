@@ -226,6 +226,9 @@ void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
 bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail) {
   tail.counters = nullptr;
   if (!c->tail_finalize || !c->d_tail_counters || !f.direct || f.measure == 2) return false;
+  // back end, gradient evaluations: the 42-column partial table makes the tail 1.5-2 us SLOWER than the finalize launch
+  // (measured, config 3); cost-only evaluations have no table and gain like the front end.  Option value 2 forces it.
+  if (c->kind == KIND_BE && f.gP > 0 && c->tail_finalize < 2) return false;
   f.ticket = ++c->ticket_issued;
   c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
   tail.counters = c->d_tail_counters;
@@ -533,15 +536,19 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
+  if (phase == 3) {
+    f.gP = 0;
+    f.gpartials = nullptr;
+    f.gblocks = 0;
+  }
   if (!have_image) {
     Span sp(c, CMX_T_IMAGE, /*exact=*/true);
     launch_image_adjoint(ia, c->stream, sp.t0(), sp.t1());
     if (!direct) launch_reduce_partials(f, c->stream);
   }
   if (phase == 3) {  // cost-only: contrast from the moment rows; Jt and the rows stay for a gradient call at the same point
-    f.gP = 0;
-    f.gpartials = nullptr;
-    f.gblocks = 0;
+    // (its own launch: a tail finalize inside the 1024-thread image_adjoint kernel spilled the kernel's registers to scratch --
+    //  inlined, the image pass went 11 -> 20 us; out of line, solves dropped from 9.4k to 5.3k iterations/s)
     issue_finalize(c, f, false);
     HIP_TRY(c, hipGetLastError());
     c->jt_valid = true;

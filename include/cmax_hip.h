@@ -76,7 +76,8 @@ enum {
                              time order and large panoramas do not use the compacted tile list, so that every
                              floating-point sum has a fixed order.  Costs ~10-20 % per evaluation.  The reference-shaped
                              flow (derivative planes, fp32 atomics) stays order-dependent */
-  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default of a front-end context; a back-end context defaults to 0): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint
+  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default; on the back end this covers cost-only evaluations, 2 = gradient evaluations too --
+                             measured 1.5-2 us slower there, their partial table has 42 columns): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint
                              gradient: the gather pass) runs the finalize step -- contrast, gradient, result hand-off -- in
                              its last-arriving workgroup (write-through partial sums, tickets sharded by XCD, one agent-scope
                              acquire) instead of a separate one-workgroup launch behind a kernel boundary.
