@@ -82,6 +82,7 @@ class Runner:
         self.ev, self.world, self.torch, self.dist, self.device = ev, world, torch, dist, device
         self.comm_used = "none"
         self.sh = self.stream = None
+        self.ev_sharded = world > 1 or force
         if world > 1 or force:  # force: the sharded code path with a 1-rank communicator (--force-sharded, a dry run)
             self._attach(comm_mode)
 
@@ -189,6 +190,29 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
         run.step(points[i % npts], False)
     run.fence()
     elapsed_f = time.perf_counter() - t0
+    # ---- beside the headline: the same K evaluations as INDEPENDENT candidates, queued back to back with one wait per
+    # list of 16 (cmx_*_eval_many) -- what a caller with a list of trial points gets; a line search cannot use it
+    pipelined = None
+    if run.world == 1 and run.sh is None and not run.ev_sharded:
+        xs = np.vstack([points[i % npts] for i in range(16)])
+        ev.eval_many(xs, True)
+        reps = max(1, steps // 16)
+        run.fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ev.eval_many(xs, True)
+        run.fence()
+        el_m = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ev.eval_many(xs, False)
+        run.fence()
+        el_mf = time.perf_counter() - t0
+        pipelined = {"evaluations_per_call": 16, "calls": reps, "ms_per_evaluation": el_m / (16 * reps) * 1e3,
+                     "value": n_total * 16 * reps / el_m, "unit": "events/s",
+                     "cost_only_ms_per_evaluation": el_mf / (16 * reps) * 1e3,
+                     "note": "independent evaluations (cmx_*_eval_many): launch chains queued back to back, one host wait per 16; not "
+                             "the headline -- the optimiser's evaluations depend on each other"}
     if run.world > 1:
         t = run.torch.tensor([elapsed, elapsed_f], dtype=run.torch.float64, device=run.device)
         run.dist.all_reduce(t, op=run.dist.ReduceOp.MAX)
@@ -250,6 +274,8 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
         "trajectory_points": npts, "rebins": stats["rebins"], "fallback_frac_last": stats["fallback_frac"],
         "contrast": c,
     }
+    if pipelined:
+        out["pipelined"] = pipelined
     if "comm" in kernel_ms:
         n_comm = cal["comm"][1] / ncal
         out["comm"] = {"ms_per_step": kernel_ms["comm"] * n_comm, "collectives_per_step": n_comm,
@@ -489,7 +515,7 @@ def line(m, world, args, name, n_total, img, comm_used, mode_desc):
                                    "gradient sums; %s" % (world, comm_used)) if world > 1 else "single GPU"},
         "per_gpu_value": m["value"] / world,
     }
-    for k in ("cost_only", "kernel_ms", "kernels", "roofline", "whole_evaluation", "comm", "rebins", "fallback_frac_last", "contrast"):
+    for k in ("cost_only", "pipelined", "kernel_ms", "kernels", "roofline", "whole_evaluation", "comm", "rebins", "fallback_frac_last", "contrast"):
         if k in m:
             out[k] = m[k]
     return out
@@ -560,8 +586,9 @@ def main():
             ev, run, w, mb, name_b, img_b, pts_b = backend_workload(args, ctx, "config3", 5_000_000, args.steps_backend)
             be = {"config": {"workload": name_b, "events_total": len(w.x), "image": img_b, "mode": mode_desc},
                   "value": mb["value"], "unit": "events/s", "ms_per_step": mb["ms_per_step"], "steps": args.steps_backend}
-            for k in ("cost_only", "kernel_ms", "kernels", "roofline", "whole_evaluation", "rebins", "fallback_frac_last"):
-                be[k] = mb[k]
+            for k in ("cost_only", "pipelined", "kernel_ms", "kernels", "roofline", "whole_evaluation", "rebins", "fallback_frac_last"):
+                if k in mb:
+                    be[k] = mb[k]
             if args.solves > 0:
                 be["cmax"] = cmax_solves(max(1, args.solves // 2), ev, "backend", _lib)
             if not args.no_cpu_baseline:

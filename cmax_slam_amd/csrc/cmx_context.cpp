@@ -294,6 +294,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tail_counters);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
+  if (c->h_many) hipHostFree(c->h_many);
   comm_release(c);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;

@@ -172,6 +172,9 @@ struct cmx_ctx {
   int ticket_nout = 0;                   // result words that launch writes
   bool ticket_wait = true;
   size_t result_cap = 0;
+  double *h_many = nullptr, *d_many = nullptr;  // cmx_*_eval_many: one 4096-double result block per evaluation of the list
+  size_t many_cap = 0;
+  double *result_override = nullptr;            // where the next finalize writes instead of d_result (eval_many)
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
 
@@ -280,6 +283,7 @@ struct Span {
 };
 
 // ---- cmx_pipeline.cpp
+inline double *result_ptr(const cmx_ctx *c) { return c->result_override ? c->result_override : c->d_result; }
 int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast);
 int ensure_accum(cmx_ctx *c, size_t need);
 int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be);

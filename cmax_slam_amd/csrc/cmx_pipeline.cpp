@@ -346,7 +346,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
     launch_sobel_moments(sa, c->stream);
     FinalizeArgs f{};
     f.P = 0; f.nblk = a.nblk; f.measure = 2; f.npix = (double)np;
-    f.partials = c->d_partials; f.sums = c->d_sums; f.result = c->d_result;
+    f.partials = c->d_partials; f.sums = c->d_sums; f.result = result_ptr(c);
     f.direct = 1;
     f.gpartials = c->d_gpartials; f.gblocks = sa.nblk; f.gP = P;
     f.fallback = c->d_fallback;
@@ -361,7 +361,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   f.npix = (double)np;
   f.partials = c->d_partials;
   f.sums = c->d_sums;
-  f.result = c->d_result;
+  f.result = result_ptr(c);
   f.fallback = c->d_fallback;
   bool tailed = false;
   {
@@ -413,7 +413,7 @@ static int run_fused_gather(cmx_ctx *c) {
   f.P = 0;
   f.measure = c->measure;
   f.npix = (double)W * H;
-  f.result = c->d_result;
+  f.result = result_ptr(c);
   f.gpartials = c->d_gpartials;
   f.gblocks = grid;
   f.gP = 3;
@@ -506,7 +506,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   f.npix = (double)np;
   f.partials = c->d_partials;
   f.sums = c->d_sums;
-  f.result = c->d_result;
+  f.result = result_ptr(c);
   if (!have_image) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
     rc = maybe_tile_list(c, a, 2 * c->radius);
     if (rc) return rc;
@@ -742,3 +742,62 @@ int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
   return CMX_OK;
 }
 
+
+// ---- several INDEPENDENT evaluations per call (cmx_*_eval_many): the launch chains of the m evaluations are queued back
+// to back on the stream, every finalize writes to its own block of mapped host memory, and the host waits ONCE.  What a
+// sequential caller pays per evaluation on top of the kernels -- ticket -> host -> next launch, ~3 us -- disappears, and
+// the GPU never idles between evaluations.  For candidate lists (multi-start, grid initialisation, finite-difference
+// checks); a line search cannot use it (each trial point depends on the previous result).
+static int eval_many(cmx_ctx *c, int kind, int m, const double *xs, double *contrasts, double *grads) {
+  if (!c || c->kind != kind) return fail(c, CMX_ERR_STATE, "wrong context kind");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "no packet / window handed over");
+  if (m < 0 || (m > 0 && (!xs || !contrasts))) return fail(c, CMX_ERR_INVALID_ARG, "bad arguments");
+  if (c->sharded()) return fail(c, CMX_ERR_STATE, "eval_many is not available with a communicator attached");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  const int n = kind == KIND_FE ? 3 : 3 * (c->K - c->num_fixed);
+  constexpr int kBlock = 4096;  // doubles per evaluation: the layout of the one-evaluation result buffer (slots at its tail)
+  if ((size_t)m > c->many_cap) {
+    if (c->h_many) HIP_TRY(c, hipHostFree(c->h_many));
+    c->h_many = c->d_many = nullptr;
+    c->many_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_many, (size_t)m * kBlock * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_many, c->h_many, 0));
+    c->many_cap = (size_t)m;
+  }
+  const int reuse = c->reuse_image;
+  c->reuse_image = 0;  // every evaluation of the list is a full one; no speculative work for a follow-up call
+  for (int i = 0; i < m && rc == CMX_OK; i++) {
+    const double *x = xs + (size_t)i * n;
+    rc = kind == KIND_FE ? cmx_frontend_accumulate(c, x, grads != nullptr) : cmx_backend_accumulate(c, x, grads != nullptr);
+    if (rc) break;
+    if (kind == KIND_BE) {
+      rc = be_first_iter(c);
+      if (rc) break;
+    }
+    c->result_override = c->d_many + (size_t)i * kBlock;
+    if (grads && c->last_adjoint) rc = run_adjoint(c, n);
+    else rc = run_image_and_finalize(c, grads ? n : 0, nullptr, nullptr);
+    c->result_override = nullptr;
+  }
+  c->reuse_image = reuse;
+  c->x_valid = false;  // (the resident image belongs to the last point of the list: not worth tracking)
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (rc) return rc;
+  HIP_TRY(c, e);
+  for (int i = 0; i < m; i++) {
+    const double *r = c->h_many + (size_t)i * kBlock;
+    contrasts[i] = r[0];
+    if (grads) for (int k = 0; k < n; k++) grads[(size_t)i * n + k] = r[2 + k];
+  }
+  if (m > 0 && c->n_packed > 0 && c->last_used_lds)
+    c->last_fallback_frac = c->h_many[(size_t)(m - 1) * kBlock + kFallbackSlot] / (double)c->n_packed;
+  c->fallback_pending = false;
+  return CMX_OK;
+}
+int cmx_frontend_eval_many(cmx_ctx *c, int m, const double *omegas, double *contrasts, double *grads) {
+  return eval_many(c, KIND_FE, m, omegas, contrasts, grads);
+}
+int cmx_backend_eval_many(cmx_ctx *c, int m, const double *drotvs, double *contrasts, double *grads) {
+  return eval_many(c, KIND_BE, m, drotvs, contrasts, grads);
+}

@@ -161,6 +161,18 @@ class _Evaluator:
         self._ck(fn(self._ctx, C.byref(c), _dp(g) if want_grad else None))
         return c.value, (g[:n] if want_grad else None)
 
+    def eval_many(self, xs, want_grad=True):
+        """m independent evaluations in one call (cmx_*_eval_many): xs = m x n_params.  Returns (contrasts[m], grads[m, n] | None)."""
+        fe = isinstance(self, FrontendEvaluator)
+        n = 3 if fe else self.num_params
+        xs = np.ascontiguousarray(np.asarray(xs, np.float64).reshape(-1, max(n, 1)))
+        m = xs.shape[0]
+        c = np.zeros(m)
+        g = np.zeros((m, max(n, 1))) if want_grad else None
+        fn = self._L.cmx_frontend_eval_many if fe else self._L.cmx_backend_eval_many
+        self._ck(fn(self._ctx, m, _dp(xs), _dp(c), _dp(g) if want_grad else None))
+        return c, (g[:, :n] if want_grad else None)
+
     def timing_enable(self, on=True, every=1):
         """on: True = all kernel classes, False = off, or an iterable of class names (e.g. ["splat"]).
         every: sample every n-th evaluation only (the per-event kernels are timed through events attached to the

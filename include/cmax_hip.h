@@ -126,6 +126,13 @@ int cmx_frontend_set_packet(cmx_ctx *ctx, int64_t n, const uint16_t *x, const ui
  * fast path used by local_contrast_f, src/frontend/local_optim_contrast_gsl.cpp:58-63). */
 int cmx_frontend_eval(cmx_ctx *ctx, const double omega[3], double *contrast, double *grad /* [3] or NULL */);
 
+/* m INDEPENDENT evaluations in one call: omegas = m x 3, contrasts = m, grads = m x 3 or NULL (cost-only).  The m launch
+ * chains are queued back to back and the host waits once, so the per-evaluation host round trip (~3 us of ~42) and the
+ * GPU idle time behind it disappear; results are those of m cmx_frontend_eval calls.  For candidate lists (multi-start,
+ * grid initialisation, finite differences) -- the line search of local_optim_contrast_gsl.cpp cannot use it, each of its
+ * trial points depends on the previous cost.  Not available with a communicator attached. */
+int cmx_frontend_eval_many(cmx_ctx *ctx, int m, const double *omegas, double *contrasts, double *grads);
+
 /* computeImageOfWarpedEvents for display / inspection: iwe = H*W fp32 (required), deriv = H*W*3 interleaved
  * fp32 (CV_32FC3 layout) or NULL.  blur = 0 is the display overload (local_image_warped_events.cpp:41-57). */
 int cmx_frontend_get_iwe(cmx_ctx *ctx, const double omega[3], int blur, float *iwe, float *deriv);
@@ -154,6 +161,9 @@ int cmx_backend_set_window(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uin
 /* global_contrast_fdf body: drotv = 3*(K-num_fixed) incremental rotation vectors applied by LEFT
  * multiplication to the non-fixed knots (trajectory.cpp:236 / :497); grad has the same length or is NULL. */
 int cmx_backend_eval(cmx_ctx *ctx, const double *drotv, double *contrast, double *grad);
+
+/* m independent evaluations in one call (see cmx_frontend_eval_many): drotvs = m x 3(K-num_fixed), grads likewise or NULL */
+int cmx_backend_eval_many(cmx_ctx *ctx, int m, const double *drotvs, double *contrasts, double *grads);
 
 enum { CMX_PLANE_IL_OLD = 0, CMX_PLANE_IL_NEW = 1, CMX_PLANE_IWE = 2, CMX_PLANE_DERIV0 = 16 };
 /* planes of the LAST evaluation (what updateIG / publishEventImage read, event_pano_warper.cpp:109-126):

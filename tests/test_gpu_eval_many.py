@@ -1,0 +1,57 @@
+"""-m gpu: cmx_*_eval_many -- m independent evaluations queued back to back, one wait -- returns what m single evaluations
+return (and what the oracle returns), for both ends, with and without gradients, and leaves the context usable."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import _lib, synth
+from util import RTOL, rel_scalar, rel_vec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_frontend_eval_many(hip, oracle, fast):
+    p = synth.frontend_packet(50_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=81)
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    if fast:
+        fe.set_fast_path()
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    rng = np.random.default_rng(5)
+    xs = np.vstack([np.zeros(3), p.omega_true] + [p.omega_true * rng.uniform(0, 1.3) + rng.normal(0, 0.2, 3) for _ in range(7)])
+    c, g = fe.eval_many(xs, True)
+    c0, _ = fe.eval_many(xs, False)
+    for i, x in enumerate(xs):
+        c_ref, g_ref = ref.eval(x)
+        assert rel_scalar(c[i], c_ref) < RTOL and rel_scalar(c0[i], c_ref) < RTOL, i
+        assert rel_vec(g[i], g_ref) < RTOL, i
+        cs, gs = fe.eval(x)          # the context keeps working, and agrees with its own single evaluations
+        assert rel_scalar(c[i], cs) < 1e-6 and rel_vec(g[i], gs) < RTOL   # (fp32 atomics: two runs of the reference-shaped path differ by ~4e-6 at the optimum)
+    assert fe.eval_many(np.zeros((0, 3)), True)[0].size == 0
+    x, rep = fe.setupProblemAndOptimize(np.zeros(3))
+    assert rep["final_cost"] < rep["initial_cost"]
+
+
+def test_backend_eval_many(hip, oracle):
+    w = synth.backend_window(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 10, 3, 0.35, seed=82)
+    IG = np.zeros((w.Hp, w.Wp), np.float32)
+    IG[100:140, 200:300] = 1.1
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be.set_fast_path()
+    be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE, IG)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, IG)
+    rng = np.random.default_rng(6)
+    xs = np.vstack([np.zeros(w.P)] + [rng.normal(0, 0.01, w.P) for _ in range(5)])   # first point = 0: alpha is fixed there
+    c, g = be.eval_many(xs, True)
+    c0, _ = be.eval_many(xs, False)
+    for i, x in enumerate(xs):
+        c_ref, g_ref = ref.eval(x)
+        assert rel_scalar(c[i], c_ref) < RTOL and rel_scalar(c0[i], c_ref) < RTOL, i
+        assert rel_vec(g[i], g_ref) < RTOL, i
+    assert rel_scalar(be.alpha, ref.alpha) < RTOL and ref.alpha > 0
+    with pytest.raises(hip.CmaxHipError):
+        be.comm_attach(be.comm_unique_id(), 0, 1)
+        be.eval_many(xs, True)       # not with a communicator attached
