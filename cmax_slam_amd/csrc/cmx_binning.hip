@@ -480,6 +480,7 @@ void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, h
   hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fixed, planes, n);
 }
 
+static_assert(kBinWindow * kBinWindow % 256 == 0, "window cells per thread");
 constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -> 12.6 us, 1 -> 13.3, 4 -> 14.1, 8 -> 15.2 per 1M events)
 
 template <bool FIXED, bool STREAM>
@@ -540,10 +541,20 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   if (nfall) atomicAdd(b.fallback, nfall);
   if (has_win) {
     __syncthreads();
-    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
-      const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
-      const fix_t v = win[ly * kBinStride + lx];
+    // all of a thread's window cells are read before the first is flushed: one LDS round trip instead of sixteen
+    // (the rolled loop waited for every read in turn: ~0.9 of the kernel's ~9 us, profiles/r02_splat_timeline.txt)
+    constexpr int kCells = kBinWindow * kBinWindow / 256;
+    fix_t cell[kCells];
+#pragma unroll
+    for (int k = 0; k < kCells; k++) {
+      const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
+      cell[k] = win[ly * kBinStride + lx];
+    }
+#pragma unroll
+    for (int k = 0; k < kCells; k++) {
+      const fix_t v = cell[k];
       if (v != 0ull) {
+        const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
         const size_t at = (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx);
         if (FIXED) atomicAdd(b.fixed + at, v);
         else atomic_add_f32(a.planes + at, (float)((double)v * kFixInv));
@@ -631,10 +642,18 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
   if (has_win) {
     __syncthreads();
     const size_t plane_off = c.plane ? np : 0;
-    for (int p = tid; p < kBinWindow * kBinWindow; p += 256) {
-      const int ly = p / kBinWindow, lx = p - ly * kBinWindow;
-      const fix_t v = win[ly * kBinStride + lx];
+    constexpr int kCells = kBinWindow * kBinWindow / 256;  // (see fe_splat_lds_kernel: reads first, then the flush)
+    fix_t cell[kCells];
+#pragma unroll
+    for (int k = 0; k < kCells; k++) {
+      const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
+      cell[k] = win[ly * kBinStride + lx];
+    }
+#pragma unroll
+    for (int k = 0; k < kCells; k++) {
+      const fix_t v = cell[k];
       if (v != 0ull) {
+        const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
         const size_t at = plane_off + (size_t)(c.wy0 + ly) * a.Wp + (c.wx0 + lx);
         if (FIXED) atomicAdd(b.fixed + at, v);
         else atomic_add_f32(a.planes + at, (float)((double)v * kFixInv));
