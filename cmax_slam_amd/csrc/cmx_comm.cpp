@@ -60,7 +60,7 @@ int comm_allreduce(cmx_ctx *c, void *buf, size_t count, int dt /* CMX_DT_* */, i
 // row and writes that to mapped host memory; the planes are then summed over the band of rows the PREVIOUS evaluation
 // found, widened by kBandMargin tile rows (the whole plane while no band is known) -- 64 MB per evaluation become ~16 MB
 // at 4096x2048 (BASELINE config 5) with no host synchronisation between splat and blur.  band_kernel also reports whether
-// a touched row lay outside the band that was exchanged; settle_band() then completes the evaluation (rare: the
+// a touched row lay outside the band that was exchanged; finish_sharded() then completes the evaluation with a whole-plane exchange (rare: the
 // parameters moved the votes by more than two tile rows between two evaluations).
 constexpr size_t kSparseExchangeMinPlaneBytes = (size_t)8 << 20;
 constexpr int kBandMargin = 2;
