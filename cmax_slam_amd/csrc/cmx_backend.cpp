@@ -25,6 +25,8 @@ int cmx_backend_create(cmx_ctx **out, int device, int W, int H, const double *lu
   HIP_TRY(c, hipMalloc((void **)&c->d_alpha, sizeof(double)));
   HIP_TRY(c, hipMemset(c->d_alpha, 0, sizeof(double)));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_spline, sizeof(SplineArgs), hipHostMallocDefault));
+  // the clears above ran on the null stream and the context's stream is non-blocking: complete them before anything is queued
+  HIP_TRY(c, hipDeviceSynchronize());
   return CMX_OK;
 }
 

@@ -490,10 +490,13 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   const Chunk c = b.chunks[blockIdx.x];
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
-  if (has_win) {
+  // votes on the global path are counted per workgroup (LDS) and reported with ONE device atomic: a counter every thread
+  // adds to is a single memory-side address -- ~1.3 ns per add, 13 us per percent of a million events' votes
+  __shared__ unsigned sfall;
+  if (tid == 0) sfall = 0;
+  if (has_win)
     for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
-    __syncthreads();
-  }
+  __syncthreads();
   unsigned nfall = 0;
   for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * kUnroll) {
     bool act[kUnroll];
@@ -538,9 +541,10 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
       }
     }
   }
-  if (nfall) atomicAdd(b.fallback, nfall);
+  if (nfall) atomicAdd(&sfall, nfall);
+  __syncthreads();
+  if (tid == 0 && sfall) atomicAdd(b.fallback, sfall);
   if (has_win) {
-    __syncthreads();
     // all of a thread's window cells are read before the first is flushed: one LDS round trip instead of sixteen
     // (the rolled loop waited for every read in turn: ~0.9 of the kernel's ~9 us, profiles/r02_splat_timeline.txt)
     constexpr int kCells = kBinWindow * kBinWindow / 256;
@@ -587,10 +591,13 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
   const size_t np = (size_t)a.Wp * a.Hp;
-  if (has_win) {
+  // votes on the global path are counted per workgroup (LDS) and reported with ONE device atomic: a counter every thread
+  // adds to is a single memory-side address -- ~1.3 ns per add, 13 us per percent of a million events' votes
+  __shared__ unsigned sfall;
+  if (tid == 0) sfall = 0;
+  if (has_win)
     for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
-    __syncthreads();
-  }
+  __syncthreads();
   unsigned nfall = 0;
   constexpr int U = 2;
   for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * U) {
@@ -638,9 +645,10 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
       }
     }
   }
-  if (nfall) atomicAdd(b.fallback, nfall);
+  if (nfall) atomicAdd(&sfall, nfall);
+  __syncthreads();
+  if (tid == 0 && sfall) atomicAdd(b.fallback, sfall);
   if (has_win) {
-    __syncthreads();
     const size_t plane_off = c.plane ? np : 0;
     constexpr int kCells = kBinWindow * kBinWindow / 256;  // (see fe_splat_lds_kernel: reads first, then the flush)
     fix_t cell[kCells];

@@ -178,6 +178,7 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   memset(c->h_result, 0, c->result_cap * sizeof(double));
   HIP_TRY(c, hipMalloc((void **)&c->d_tail_counters, kTailCounterWords * sizeof(unsigned)));
   HIP_TRY(c, hipMemset(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned)));
+  HIP_TRY(c, hipDeviceSynchronize());  // null-stream clears / copies above vs the context's non-blocking stream
   return CMX_OK;
 }
 
