@@ -39,6 +39,7 @@ double time_to_sec(long long t_ns) {  // ros::Time::toSec
 // (see adjoint_kernel / image_adjoint_kernel).  1 in the interior; only the outer r pixels differ.
 int upload_gt1(cmx_ctx *c) {
   const int r = c->radius;
+  c->Mx_radius = -1;
   for (int axis = 0; axis < 2; axis++) {
     const int L = axis == 0 ? c->imgW : c->imgH;
     if (L <= 0) continue;
@@ -62,7 +63,7 @@ int upload_gt1(cmx_ctx *c) {
     int rc = ensure(c, dst, cap, (size_t)L);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
-    if (c->kind == KIND_FE && r <= kFusedMaxRadius) {
+    if (r >= 1 && r <= kFusedMaxRadius && L > 4 * r) {  // (front end: fused gather r = 2..4; both ends: image_adjoint2, r = 4)
       // banded composite operator M = G^T G of this axis: (M x)[q] = sum_i M[q][i] x[q - 2r + i], where
       // G[p][s] = sum_j taps[r+j] [reflect101(p+j) == s] is the REFLECT_101 blur (the forward pass of the image kernels)
       const int bw = 4 * r + 1;
@@ -88,6 +89,7 @@ int upload_gt1(cmx_ctx *c) {
       rc = ensure(c, dm, mcap, M.size());
       if (rc) return rc;
       HIP_TRY(c, hipMemcpy(dm, M.data(), M.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (axis == 1) c->Mx_radius = r;  // both axes built
     }
   }
   return CMX_OK;
@@ -331,6 +333,10 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_FUSED_GATHER:
       c->fused_gather = value != 0;
+      return CMX_OK;
+    case CMX_OPT_COMPOSITE_IMAGE:
+      c->composite_image = value != 0;
+      c->x_valid = false;  // a resident Jt of the other form is not reused
       return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }

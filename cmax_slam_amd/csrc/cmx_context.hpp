@@ -103,6 +103,8 @@ struct cmx_ctx {
   size_t cx_cap = 0, cy_cap = 0;
   float *d_Mx = nullptr, *d_My = nullptr;  // banded G^T G per axis, [L][4r+1] (fused front-end gather: out-of-window votes)
   size_t Mx_cap = 0, My_cap = 0;
+  int Mx_radius = -1;                      // blur radius the tables were built for (-1: none)
+  bool composite_image = true;             // CMX_OPT_COMPOSITE_IMAGE
   bool fused_gather = false;               // CMX_OPT_FUSED_GATHER (opt-in: measured slower on MI355X)
   int64_t fused_evals = 0;                 // gradient evaluations that took the fused pass
   double *d_gpartials = nullptr;

@@ -128,6 +128,7 @@ void launch_tile_list(const ImgArgs &a, int reach, unsigned *list, unsigned *cou
 struct ImgAdjArgs {
   ImgArgs img;      // composition + taps + partials (rows 0,1) ; P / dplanes / out_blurd unused
   float *jt;        // out: G^T B^  (W*H)
+  const float *Mx, *My;  // optional: banded G^T G per axis, [L][4r+1]: the three-phase form of the pass (r == 4)
 };
 size_t image_adjoint_lds_bytes(int r);
 int image_adjoint_tiles_x(int W);

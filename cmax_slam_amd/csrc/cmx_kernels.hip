@@ -1008,7 +1008,145 @@ __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   }  // work loop
 }
 
+// The same pass with G^T G applied as ONE banded operator per axis (Mx, My: rows of M = G^T G with the reflections and the
+// restriction to the image folded in, cmx_context.cpp upload_gt1): Jt = My (Mx I) needs no B on a halo, so the tile goes
+//   raw (tile + 2r) -> [row pass: G_x raw on tile rows +-r, M_x raw on tile rows +-2r] -> [column pass: B and Jt on the tile]
+// -- three barrier-separated phases instead of five.  B (and with it the moments) is computed in the operation order of
+// image_moments_kernel; Jt differs from the four-pass form by fp32 rounding only (~1e-7 relative).
+size_t image_adjoint2_lds_bytes(int r) {
+  const size_t aw = kAdjTX + 4 * r, ah = kAdjTY + 4 * r;
+  return sizeof(double) * 32 + sizeof(float) * (aw * ah + (size_t)kAdjTX * (kAdjTY + 2 * r) + (size_t)kAdjTX * ah);
+}
+
+template <int R, bool LIST>
+__global__ __launch_bounds__(kAdjThreads) void image_adjoint2_kernel(ImgAdjArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads, NTAP = 4 * R + 1;
+  constexpr int AW = TX + 4 * R, AH = TY + 4 * R, GH = TY + 2 * R;
+  static_assert(NT == TX * TY, "one thread per tile pixel in the column pass");
+  static_assert(AH <= 2 * TY, "two row-pass rows per thread");
+  const ImgArgs &a = g.img;
+  const int W = a.W, H = a.H;
+  float taps[2 * R + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * R + 1; j++) taps[j] = a.taps[j];
+  double *red = reinterpret_cast<double *>(smem_raw);
+  float *bufA = reinterpret_cast<float *>(smem_raw + 32 * sizeof(double));  // raw, AW x AH
+  float *bufG = bufA + AW * AH;                                             // G_x raw, TX x GH (tile rows -r .. TY+r)
+  float *bufM = bufG + TX * GH;                                             // M_x raw, TX x AH (tile rows -2r .. TY+2r)
+  const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
+  const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
+  const int n_work = LIST ? (int)(*a.tile_count) : 0;
+  for (int wi = blockIdx.x, once = 1; LIST ? (wi < n_work) : (once != 0); wi += gridDim.x, once = 0) {
+  const unsigned entry = LIST ? a.tile_list[wi] : (unsigned)wi;
+  const int tile = (int)(entry & 0x3fffffffu);
+  const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
+  if (LIST) __syncthreads();  // LDS of the previous tile is free
+  if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
+    const bool dirty = LIST ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
+    if (dirty) {
+      for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
+        const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
+        const int gx = x0 + (q % TX), gy = y0 + (q / TX);
+        if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
+      }
+    }
+    if (!LIST) {  // (the list pre-pass has already un-flagged it)
+      __syncthreads();   // every thread has read the flag
+      if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+    }
+  }
+  const int slot = LIST ? wi : tile;  // row position of this tile's partial moments
+  if (LIST ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * R, TX, TY)) {
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + slot] = 0.0;
+      a.partials[(size_t)1 * a.nblk + slot] = 0.0;
+    }
+    continue;
+  }
+  // coefficient rows: every row of M at least 2r away from the border is the same 4r+1-tap kernel (wave-uniform loads);
+  // tiles that touch the left / right border fetch the row of their own column, top / bottom the row of the wave's line
+  float mx[NTAP];
+  {
+    const bool interior = x0 >= 2 * R && x0 + TX - 1 <= W - 1 - 2 * R;
+    const float *row = g.Mx + (size_t)(interior ? 2 * R : min(x0 + tx, W - 1)) * NTAP;
+#pragma unroll
+    for (int i = 0; i < NTAP; i++) mx[i] = row[i];
+  }
+  for (int idx = tid; idx < AW * AH; idx += NT) {
+    const int ly = idx / AW, lx = idx - ly * AW;
+    const int gx = reflect101(x0 + lx - 2 * R, W), gy = reflect101(y0 + ly - 2 * R, H);
+    const size_t off = (size_t)gy * W + gx;
+    float v = a.src_a[off];
+    if (a.src_b) v = v + a.src_b[off];
+    if (a.igp) v = a.igp[off] * alpha + v;
+    bufA[idx] = v;  // (beyond the image: the reflected value for G_x; M's rows carry zeros there)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; h++) {  // row pass: raw rows ty and ty + TY, output column tx
+    const int ly = ty + h * TY;
+    if (ly < AH) {
+      const float *S = bufA + ly * AW + tx;
+      float in[NTAP];
+#pragma unroll
+      for (int i = 0; i < NTAP; i++) in[i] = S[i];
+      float m = mx[0] * in[0];
+#pragma unroll
+      for (int i = 1; i < NTAP; i++) m += mx[i] * in[i];
+      bufM[ly * TX + tx] = m;
+      if (ly >= R && ly < R + GH) {  // forward row pass, same op order as image_moments
+        float s = taps[0] * in[R];
+#pragma unroll
+        for (int j = 1; j <= 2 * R; j++) s += taps[j] * in[R + j];
+        bufG[(ly - R) * TX + tx] = s;
+      }
+    }
+  }
+  float my[NTAP];
+  {
+    const bool interior = y0 >= 2 * R && y0 + TY - 1 <= H - 1 - 2 * R;
+    const float *row = g.My + (size_t)(interior ? 2 * R : min(y0 + ty, H - 1)) * NTAP;  // wave-uniform (a wave is one tile row)
+#pragma unroll
+    for (int i = 0; i < NTAP; i++) my[i] = row[i];
+  }
+  __syncthreads();
+  double sI = 0, sII = 0;
+  {
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx < W && gy < H) {
+      const float *T = bufG + (ty + R) * TX + tx;
+      float s = taps[R] * T[0];
+#pragma unroll
+      for (int t = 1; t <= R; t++) s += taps[R + t] * (T[t * TX] + T[-t * TX]);
+      sI = (double)s;
+      sII = (double)s * (double)s;
+      if (a.out_blur0) a.out_blur0[(size_t)gy * W + gx] = s;
+      const float *Q = bufM + ty * TX + tx;
+      float j = my[0] * Q[0];
+#pragma unroll
+      for (int i = 1; i < NTAP; i++) j += my[i] * Q[i * TX];
+      g.jt[(size_t)gy * W + gx] = j;
+    }
+  }
+  {
+    double t0, t1;
+    block_sum2(sI, sII, red, NT / 64, t0, t1);
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + slot] = t0;
+      a.partials[(size_t)1 * a.nblk + slot] = t1;
+    }
+  }
+  }  // work loop
+}
+
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+  if (a.Mx && a.My && a.img.r == 4) {  // composite operator available (built with the blur for r == 4)
+    const size_t lds2 = image_adjoint2_lds_bytes(4);
+    if (a.img.tile_list) CMX_LAUNCH((image_adjoint2_kernel<4, true>), dim3(min(a.img.nblk, kTileListGrid)), dim3(kAdjThreads), lds2, s, t0, t1, a);
+    else CMX_LAUNCH((image_adjoint2_kernel<4, false>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+    return;
+  }
   const size_t lds = image_adjoint_lds_bytes(a.img.r);
   if (a.img.tile_list) {
     const dim3 g(min(a.img.nblk, kTileListGrid));

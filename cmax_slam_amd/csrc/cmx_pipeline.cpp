@@ -387,7 +387,7 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
 // Only while the tile sort still fits the parameters: votes that left their window cost ~300 loads each there.
 static bool use_fused_gather(const cmx_ctx *c, int phase) {
   return c->kind == KIND_FE && phase == 0 && c->fused_gather && c->splat_mode == 1 && c->bin_valid && c->streams_valid &&
-         c->last_used_lds && !c->deterministic && !c->sharded() && !c->accum_external && fe_fused_radius_ok(c->radius) && c->d_Mx &&
+         c->last_used_lds && !c->deterministic && !c->sharded() && !c->accum_external && fe_fused_radius_ok(c->radius) && c->Mx_radius == c->radius && c->d_Mx &&
          c->d_My && c->n_packed > 0 && c->nchunks > 0 && c->last_fallback_frac <= 0.02 && c->measure != CMX_GRADIENT_MAGNITUDE;
 }
 
@@ -454,6 +454,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
   ImgAdjArgs ia{};
   ImgArgs &a = ia.img;
+  if (c->composite_image && c->radius == 4 && c->d_Mx && c->d_My && c->Mx_radius == 4) { ia.Mx = c->d_Mx; ia.My = c->d_My; }
   a.W = W; a.H = H; a.r = c->radius;
   memcpy(a.taps, c->taps, sizeof(a.taps));
   a.src_a = c->d_accum;
