@@ -668,7 +668,7 @@ size_t image_lds_bytes(int r) {
 // the loop below runs exactly once (kept as a loop so that both forms share one body; a runtime trip count costs the
 // one-tile form its register allocation -- the taps spill -- hence the compile-time switch)
 template <int R, bool LIST>  // R >= 0: compile-time radius (loops unroll, taps live in registers, index maths is constant); -1: a.r
-__global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
+__device__ __forceinline__ void image_moments_body(const ImgArgs &a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ FinSmem fin_sm;  // tail finalize scratch (sizeof % 16 == 0: the dynamic region stays aligned)
   const bool tail = a.tail.counters != nullptr;  // P == 0 by construction (host side)
@@ -801,6 +801,10 @@ __global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) {
   }  // work loop
   if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<kImgThreads>(a.tail.fin, fin_sm);
 }
+template <int R, bool LIST>
+__global__ __launch_bounds__(kImgThreads) void image_moments_kernel(ImgArgs a) { image_moments_body<R, LIST>(a); }
+// (an occupancy bound of 8 waves per SIMD -- 54 instead of 82 VGPRs, two workgroups per CU -- made this kernel SLOWER:
+// 9.7 -> 10.5 us with the tail finalize at 640x480; image_adjoint2_kernel is the opposite case)
 
 void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int groups = a.P > 0 ? (a.P + kPlaneGroup - 1) / kPlaneGroup : 1;
@@ -1018,9 +1022,15 @@ size_t image_adjoint2_lds_bytes(int r) {
   return sizeof(double) * 32 + sizeof(float) * (aw * ah + (size_t)kAdjTX * (kAdjTY + 2 * r) + (size_t)kAdjTX * ah);
 }
 
-template <int R, bool LIST>
-__global__ __launch_bounds__(kAdjThreads) void image_adjoint2_kernel(ImgAdjArgs g) {
+// TAIL: finalize in the last-arriving workgroup (cost-only evaluations that keep Jt for the df that follows).  Two 1024-thread
+// workgroups fit a CU only at <= 64 VGPRs (8 waves per SIMD), and 300 tiles on 256 CUs need the second one: at 76 VGPRs the
+// pass took 11 us instead of 8.2 -- hence the occupancy bound (the finalize body, run by one workgroup, may spill; the
+// image phases do not) and the compile-time switch.
+template <int R, bool LIST, bool TAIL>
+__global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void image_adjoint2_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ FinSmem fin_sm;
+  constexpr bool tail = TAIL;
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads, NTAP = 4 * R + 1;
   constexpr int AW = TX + 4 * R, AH = TY + 4 * R, GH = TY + 2 * R;
   static_assert(NT == TX * TY, "one thread per tile pixel in the column pass");
@@ -1059,8 +1069,13 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint2_kernel(ImgAdjArgs 
   const int slot = LIST ? wi : tile;  // row position of this tile's partial moments
   if (LIST ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * R, TX, TY)) {
     if (tid == 0) {
-      a.partials[(size_t)0 * a.nblk + slot] = 0.0;
-      a.partials[(size_t)1 * a.nblk + slot] = 0.0;
+      if (tail) {
+        st_sc1(a.partials + (size_t)0 * a.nblk + slot, 0.0);
+        st_sc1(a.partials + (size_t)1 * a.nblk + slot, 0.0);
+      } else {
+        a.partials[(size_t)0 * a.nblk + slot] = 0.0;
+        a.partials[(size_t)1 * a.nblk + slot] = 0.0;
+      }
     }
     continue;
   }
@@ -1133,18 +1148,31 @@ __global__ __launch_bounds__(kAdjThreads) void image_adjoint2_kernel(ImgAdjArgs 
     double t0, t1;
     block_sum2(sI, sII, red, NT / 64, t0, t1);
     if (tid == 0) {
-      a.partials[(size_t)0 * a.nblk + slot] = t0;
-      a.partials[(size_t)1 * a.nblk + slot] = t1;
+      if (tail) {  // write-through: the last-arriving workgroup of this launch reads them
+        st_sc1(a.partials + (size_t)0 * a.nblk + slot, t0);
+        st_sc1(a.partials + (size_t)1 * a.nblk + slot, t1);
+      } else {
+        a.partials[(size_t)0 * a.nblk + slot] = t0;
+        a.partials[(size_t)1 * a.nblk + slot] = t1;
+      }
     }
   }
   }  // work loop
+  if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<NT>(a.tail.fin, fin_sm);
 }
 
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (a.Mx && a.My && a.img.r == 4) {  // composite operator available (built with the blur for r == 4)
     const size_t lds2 = image_adjoint2_lds_bytes(4);
-    if (a.img.tile_list) CMX_LAUNCH((image_adjoint2_kernel<4, true>), dim3(min(a.img.nblk, kTileListGrid)), dim3(kAdjThreads), lds2, s, t0, t1, a);
-    else CMX_LAUNCH((image_adjoint2_kernel<4, false>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+    const bool tail = a.img.tail.counters != nullptr;
+    if (a.img.tile_list) {
+      const dim3 gl(min(a.img.nblk, kTileListGrid));
+      if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, true, true>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else CMX_LAUNCH((image_adjoint2_kernel<4, true, false>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
+    } else {
+      if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, false, true>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else CMX_LAUNCH((image_adjoint2_kernel<4, false, false>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+    }
     return;
   }
   const size_t lds = image_adjoint_lds_bytes(a.img.r);

@@ -542,15 +542,17 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     f.gpartials = nullptr;
     f.gblocks = 0;
   }
+  bool image_tailed = false;
   if (!have_image) {
     Span sp(c, CMX_T_IMAGE, /*exact=*/true);
+    // cost-only with Jt kept (phase 3): the three-phase image pass has the registers to carry the finalize as its tail
+    // (the five-phase kernel did not: inlined, its taps spilled and the pass went 11 -> 20 us)
+    if (phase == 3 && ia.Mx) image_tailed = arm_tail(c, f, a.tail);
     launch_image_adjoint(ia, c->stream, sp.t0(), sp.t1());
     if (!direct) launch_reduce_partials(f, c->stream);
   }
   if (phase == 3) {  // cost-only: contrast from the moment rows; Jt and the rows stay for a gradient call at the same point
-    // (its own launch: a tail finalize inside the 1024-thread image_adjoint kernel spilled the kernel's registers to scratch --
-    //  inlined, the image pass went 11 -> 20 us; out of line, solves dropped from 9.4k to 5.3k iterations/s)
-    issue_finalize(c, f, false);
+    if (!image_tailed) issue_finalize(c, f, false);
     HIP_TRY(c, hipGetLastError());
     c->jt_valid = true;
     c->spec_images++;
