@@ -35,8 +35,6 @@ def main():
         ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
         pts = bench.record_trajectory(ev, np.zeros(3), "frontend", solver.FRONTEND)
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
-    if os.environ.get("TP_SHIFT"):
-        ev.set_option(_lib.OPT_WINDOW_SHIFT, int(os.environ["TP_SHIFT"]))
     print("rebins after the recorded solve:", ev.stats()["rebins"])
     for i, x in enumerate(pts):
         for _ in range(5):
