@@ -93,14 +93,30 @@ __global__ __launch_bounds__(64) void be_pose_table_kernel(const SplineArgs sp, 
 }
 
 // the same table from a spline whose per-pair constants the host has already evaluated (K <= kMaxKnotsPre)
+// A thread's work hangs on three dependent memory round trips of ~1.2 us each -- kernel arguments, batch_t[b], then the
+// constants of the segment batch_t[b] falls into (PMC: 61 % of the wave cycles are waits, profiles/r02_pose_kernarg.txt).
+// The constants do not depend on b: the workgroup copies all of them to LDS while batch_t[b] is in flight.
+constexpr int kPoseThreads = 256;
 template <int N, bool WANT_J>
-__global__ __launch_bounds__(64) void be_pose_table_pre_kernel(const SplineArgsPre sp, const long long *batch_t, int nb,
-                                                               PoseR *outR, PoseEntry *out) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= nb) return;
+__global__ __launch_bounds__(kPoseThreads) void be_pose_table_pre_kernel(const SplineArgsPre sp, const long long *batch_t, int nb,
+                                                                         PoseR *outR, PoseEntry *out) {
+  __shared__ Quat sh_knots[kMaxKnotsPre];
+  __shared__ PairConsts sh_pair[kMaxKnotsPre - 1];
+  const int b = blockIdx.x * kPoseThreads + threadIdx.x;
+  const bool live = b < nb;
+  const long long t_ns = batch_t[live ? b : nb - 1];
+  {
+    const double *gk = reinterpret_cast<const double *>(sp.knots), *gp = reinterpret_cast<const double *>(sp.pair);
+    double *lk = reinterpret_cast<double *>(sh_knots), *lp = reinterpret_cast<double *>(sh_pair);
+    const int nk = sp.K * 4, npd = (sp.K - 1) * (int)(sizeof(PairConsts) / sizeof(double));
+    for (int i = threadIdx.x; i < nk; i += kPoseThreads) lk[i] = gk[i];
+    for (int i = threadIdx.x; i < npd; i += kPoseThreads) lp[i] = gp[i];
+  }
+  __syncthreads();
+  if (!live) return;
   Mat3 R, J[N];
   int idx;
-  spline_eval_pre<N, WANT_J>(sp, batch_t[b], R, J, idx);
+  spline_eval_pre<N, WANT_J>(sp, sh_knots, sh_pair, t_ns, R, J, idx);
   PoseEntry &o = out[b];
 #pragma unroll
   for (int i = 0; i < 9; i++) outR[b].R[i] = R.m[i];
@@ -122,12 +138,13 @@ void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, 
   if (spline.K <= kMaxKnotsPre) {
     SplineArgsPre pre;
     spline_precompute(spline, pre);
+    const dim3 gp((nb + kPoseThreads - 1) / kPoseThreads), bp(kPoseThreads);
     if (order == 2) {
-      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<2, true>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
-      else CMX_LAUNCH((be_pose_table_pre_kernel<2, false>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<2, true>), gp, bp, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      else CMX_LAUNCH((be_pose_table_pre_kernel<2, false>), gp, bp, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
     } else {
-      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<4, true>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
-      else CMX_LAUNCH((be_pose_table_pre_kernel<4, false>), g, b, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      if (want_j) CMX_LAUNCH((be_pose_table_pre_kernel<4, true>), gp, bp, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
+      else CMX_LAUNCH((be_pose_table_pre_kernel<4, false>), gp, bp, 0, s, t0, t1, pre, d_batch_t, nb, outR, out);
     }
     return;
   }

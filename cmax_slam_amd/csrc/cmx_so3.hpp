@@ -242,8 +242,11 @@ inline void spline_precompute(const SplineArgs &sp, SplineArgsPre &o) {  // host
   }
 }
 
+// knots / pair: where the knot and pair constants are read from -- sp's own arrays, or a copy (the device kernel stages
+// them in LDS: indexed per lane in the kernel-argument segment they cost a dependent, uncached round trip)
 template <int N, bool WANT_J>
-CMX_HD void spline_eval_pre(const SplineArgsPre &sp, long long t_ns, Mat3 &R, Mat3 *Jblocks, int &start_idx) {
+CMX_HD void spline_eval_pre(const SplineArgsPre &sp, const Quat *knots, const PairConsts *pair, long long t_ns, Mat3 &R,
+                            Mat3 *Jblocks, int &start_idx) {
   const long long st = t_ns - sp.start_ns;
   const long long s = st / sp.dt_ns;
   const double u = (double)(st % sp.dt_ns) / (double)sp.dt_ns;
@@ -260,13 +263,13 @@ CMX_HD void spline_eval_pre(const SplineArgsPre &sp, long long t_ns, Mat3 &R, Ma
     coeff[i] = a;
   }
   start_idx = (int)s;
-  Quat res = sp.knots[s];
+  Quat res = knots[s];
   Mat3 Jh;
 #pragma unroll
   for (int i = 0; i < 9; i++) Jh.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < N - 1; i++) {
-    const PairConsts &pc = sp.pair[s + i];
+    const PairConsts &pc = pair[s + i];
     const double k = coeff[i + 1];
     const double kd[3] = {pc.delta[0] * k, pc.delta[1] * k, pc.delta[2] * k};
     // exp(k delta): the operations of so3_exp, with sin / cos of the half angle kept for the Jacobian below
