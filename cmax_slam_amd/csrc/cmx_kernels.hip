@@ -1123,10 +1123,12 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
       float in[NTAP];
 #pragma unroll
       for (int i = 0; i < NTAP; i++) in[i] = S[i];
-      float m = mx[0] * in[0];
+      // 17-term sums of the composite operator in fp64, rounded once: the four-pass form rounds after every 9-term pass,
+      // and near a stationary point the gradient is a small difference of these (exact-arithmetic sweep)
+      double m = (double)mx[0] * (double)in[0];
 #pragma unroll
-      for (int i = 1; i < NTAP; i++) m += mx[i] * in[i];
-      bufM[ly * TX + tx] = m;
+      for (int i = 1; i < NTAP; i++) m = __builtin_fma((double)mx[i], (double)in[i], m);  // (not an oracle-ordered sum: fused)
+      bufM[ly * TX + tx] = (float)m;
       if (ly >= R && ly < R + GH) {  // forward row pass, same op order as image_moments
         float s = taps[0] * in[R];
 #pragma unroll
@@ -1155,10 +1157,10 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
       sII = (double)s * (double)s;
       if (a.out_blur0) a.out_blur0[(size_t)gy * W + gx] = s;
       const float *Q = bufM + ty * TX + tx;
-      float j = my[0] * Q[0];
+      double j = (double)my[0] * (double)Q[0];
 #pragma unroll
-      for (int i = 1; i < NTAP; i++) j += my[i] * Q[i * TX];
-      g.jt[(size_t)gy * W + gx] = j;
+      for (int i = 1; i < NTAP; i++) j = __builtin_fma((double)my[i], (double)Q[i * TX], j);
+      g.jt[(size_t)gy * W + gx] = (float)j;
     }
   }
   {
