@@ -43,6 +43,8 @@ SYMBOLS = {
     "cmx_frontend_eval": (C.c_int, [ctx_p, c_dp, c_dp, c_dp]),
     "cmx_frontend_eval_many": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
     "cmx_backend_eval_many": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
+    "cmx_frontend_eval_each": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
+    "cmx_backend_eval_each": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
     "cmx_frontend_get_iwe": (C.c_int, [ctx_p, c_dp, C.c_int, c_fp, c_fp]),
     "cmx_backend_create": (C.c_int, [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_int]),
     "cmx_backend_set_window": (C.c_int, [ctx_p, C.c_int64, c_u16p, c_u16p, c_i64p, C.c_int, C.c_int, c_dp, C.c_int64,

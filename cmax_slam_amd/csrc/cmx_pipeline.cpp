@@ -804,3 +804,25 @@ int cmx_frontend_eval_many(cmx_ctx *c, int m, const double *omegas, double *cont
 int cmx_backend_eval_many(cmx_ctx *c, int m, const double *drotvs, double *contrasts, double *grads) {
   return eval_many(c, KIND_BE, m, drotvs, contrasts, grads);
 }
+
+// ---- m DEPENDENT-style evaluations per call (cmx_*_eval_each): exactly m calls of cmx_*_eval, each waited for before the
+// next is issued, without returning to the caller in between -- what an optimiser loop written in C/C++ does.  For hosts
+// whose own loop is expensive per call (an interpreter): the evaluation sequence of a line search cannot be known in
+// advance, but replaying a recorded one, or timing the evaluator without the caller's overhead, can use it.
+int cmx_frontend_eval_each(cmx_ctx *c, int m, const double *omegas, double *contrasts, double *grads) {
+  if (!c || m < 0 || (m > 0 && (!omegas || !contrasts))) return c ? fail(c, CMX_ERR_INVALID_ARG, "bad arguments") : CMX_ERR_INVALID_ARG;
+  for (int i = 0; i < m; i++) {
+    const int rc = cmx_frontend_eval(c, omegas + 3 * (size_t)i, contrasts + i, grads ? grads + 3 * (size_t)i : nullptr);
+    if (rc) return rc;
+  }
+  return CMX_OK;
+}
+int cmx_backend_eval_each(cmx_ctx *c, int m, const double *drotvs, double *contrasts, double *grads) {
+  if (!c || m < 0 || (m > 0 && (!drotvs || !contrasts))) return c ? fail(c, CMX_ERR_INVALID_ARG, "bad arguments") : CMX_ERR_INVALID_ARG;
+  const size_t P = (size_t)(c->order > 0 ? 3 * (c->K - c->num_fixed) : 0);
+  for (int i = 0; i < m; i++) {
+    const int rc = cmx_backend_eval(c, drotvs + P * i, contrasts + i, grads ? grads + P * i : nullptr);
+    if (rc) return rc;
+  }
+  return CMX_OK;
+}

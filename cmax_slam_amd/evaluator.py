@@ -173,6 +173,19 @@ class _Evaluator:
         self._ck(fn(self._ctx, m, _dp(xs), _dp(c), _dp(g) if want_grad else None))
         return c, (g[:, :n] if want_grad else None)
 
+    def eval_each(self, xs, want_grad=True):
+        """m evaluations one after the other inside ONE native call (cmx_*_eval_each): the same as [self.eval(x) for x in xs]
+        without the interpreter between them.  Returns (contrasts[m], grads[m, n] | None)."""
+        fe = isinstance(self, FrontendEvaluator)
+        n = 3 if fe else self.num_params
+        xs = np.ascontiguousarray(np.asarray(xs, np.float64).reshape(-1, max(n, 1)))
+        m = xs.shape[0]
+        c = np.zeros(m)
+        g = np.zeros((m, max(n, 1))) if want_grad else None
+        fn = self._L.cmx_frontend_eval_each if fe else self._L.cmx_backend_eval_each
+        self._ck(fn(self._ctx, m, _dp(xs), _dp(c), _dp(g) if want_grad else None))
+        return c, (g[:, :n] if want_grad else None)
+
     def timing_enable(self, on=True, every=1):
         """on: True = all kernel classes, False = off, or an iterable of class names (e.g. ["splat"]).
         every: sample every n-th evaluation only (the per-event kernels are timed through events attached to the

@@ -137,6 +137,11 @@ int cmx_frontend_eval(cmx_ctx *ctx, const double omega[3], double *contrast, dou
  * trial points depends on the previous cost.  Not available with a communicator attached. */
 int cmx_frontend_eval_many(cmx_ctx *ctx, int m, const double *omegas, double *contrasts, double *grads);
 
+/* exactly m calls of cmx_frontend_eval, one after the other (each waited for before the next is issued), without returning
+ * to the caller in between: the evaluation pattern of the optimiser loop (local_optim_contrast_gsl.cpp:125-176) for hosts
+ * whose own per-call overhead is large (an interpreter) -- replaying a recorded sequence, timing the evaluator itself. */
+int cmx_frontend_eval_each(cmx_ctx *ctx, int m, const double *omegas, double *contrasts, double *grads);
+
 /* computeImageOfWarpedEvents for display / inspection: iwe = H*W fp32 (required), deriv = H*W*3 interleaved
  * fp32 (CV_32FC3 layout) or NULL.  blur = 0 is the display overload (local_image_warped_events.cpp:41-57). */
 int cmx_frontend_get_iwe(cmx_ctx *ctx, const double omega[3], int blur, float *iwe, float *deriv);
@@ -168,6 +173,8 @@ int cmx_backend_eval(cmx_ctx *ctx, const double *drotv, double *contrast, double
 
 /* m independent evaluations in one call (see cmx_frontend_eval_many): drotvs = m x 3(K-num_fixed), grads likewise or NULL */
 int cmx_backend_eval_many(cmx_ctx *ctx, int m, const double *drotvs, double *contrasts, double *grads);
+/* m calls of cmx_backend_eval, one after the other (see cmx_frontend_eval_each) */
+int cmx_backend_eval_each(cmx_ctx *ctx, int m, const double *drotvs, double *contrasts, double *grads);
 
 enum { CMX_PLANE_IL_OLD = 0, CMX_PLANE_IL_NEW = 1, CMX_PLANE_IWE = 2, CMX_PLANE_DERIV0 = 16 };
 /* planes of the LAST evaluation (what updateIG / publishEventImage read, event_pano_warper.cpp:109-126):

@@ -55,3 +55,31 @@ def test_backend_eval_many(hip, oracle):
     with pytest.raises(hip.CmaxHipError):
         be.comm_attach(be.comm_unique_id(), 0, 1)
         be.eval_many(xs, True)       # not with a communicator attached
+
+
+def test_eval_each_is_a_sequence_of_single_evaluations(hip):
+    """cmx_*_eval_each = m calls of cmx_*_eval inside one native call: same bits in deterministic mode, same reuse rules."""
+    p = synth.config1()
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe.set_fast_path()
+    fe.set_option(_lib.OPT_DETERMINISTIC, 1)
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    xs = np.array([[0.0, 0.0, 0.0], [0.1, -0.2, 0.05], [0.1, -0.2, 0.05], [0.6, -0.9, 0.4]])
+    single = [fe.eval(x) for x in xs]
+    c, g = fe.eval_each(xs, True)
+    c0, g0 = fe.eval_each(xs, False)
+    for i, (cs, gs) in enumerate(single):
+        assert c[i] == cs and np.array_equal(g[i], gs) and c0[i] == cs, i
+    assert g0 is None and fe.eval_each(np.zeros((0, 3)))[0].size == 0
+    w = synth.backend_window(20_000, 120, 90, 130.0, 130.0, 59.5, 44.5, 512, 256, 4, 8, 2, 0.2, seed=9)
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be.set_fast_path()
+    be.set_option(_lib.OPT_DETERMINISTIC, 1)
+    be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE)
+    rng = np.random.default_rng(3)
+    xb = np.vstack([np.zeros(w.P)] + [rng.normal(0, 0.01, w.P) for _ in range(3)])
+    single = [be.eval(x) for x in xb]
+    c, g = be.eval_each(xb, True)
+    for i, (cs, gs) in enumerate(single):
+        assert c[i] == cs and np.array_equal(g[i], gs), i

@@ -50,6 +50,9 @@ def run(kind, events, reps, variants):
         c, g = ev.eval(x0, True)
         ms_fdf = timed(lambda: ev.eval(x0, True), reps)
         ms_f = timed(lambda: ev.eval(x0, False), reps)
+        xs = np.tile(np.asarray(x0, float), (50, 1))
+        ms_fdf_c = timed(lambda: ev.eval_each(xs, True), max(reps // 50, 2)) / 50
+        ms_f_c = timed(lambda: ev.eval_each(xs, False), max(reps // 50, 2)) / 50
         ev.timing_enable(True)
         ev.timing_get()
         for _ in range(50):
@@ -62,6 +65,7 @@ def run(kind, events, reps, variants):
         ks = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in tim.items() if v[1])
         kf = " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in timf.items() if v[1])
         st = ev.stats()
+        print("%s %-20s native loop: fdf %.4f ms  f %.4f ms" % (kind, name, ms_fdf_c, ms_f_c))
         print("%s %-20s fdf %.4f ms  f %.4f ms  c=%.10g g=%s rebins=%d fallback=%.4f  fdf kernels(us): %s   f kernels(us): %s"
               % (kind, name, ms_fdf, ms_f, c, np.array2string(np.asarray(g)[:3], precision=8), st["rebins"], st["fallback_frac"], ks, kf), flush=True)
     ev.close()
