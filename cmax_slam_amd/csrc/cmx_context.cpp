@@ -63,7 +63,7 @@ int upload_gt1(cmx_ctx *c) {
     int rc = ensure(c, dst, cap, (size_t)L);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
-    if (r >= 1 && r <= kFusedMaxRadius && L > 4 * r) {  // (front end: fused gather r = 2..4; both ends: image_adjoint2, r = 4)
+    if (r >= 1 && r <= kMaxRadius && L > 4 * r) {  // (front end: fused gather r = 2..4; both ends: image_adjoint2 / 2g)
       // banded composite operator M = G^T G of this axis: (M x)[q] = sum_i M[q][i] x[q - 2r + i], where
       // G[p][s] = sum_j taps[r+j] [reflect101(p+j) == s] is the REFLECT_101 blur (the forward pass of the image kernels)
       const int bw = 4 * r + 1;

@@ -1180,8 +1180,115 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
   if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<NT>(a.tail.fin, fin_sm);
 }
 
+// The same three phases for any blur radius (1 <= r <= kMaxRadius; sigma = 2, 3 -> r = 8, 12): loops over the taps at run
+// time, coefficient rows read through the caches instead of living in registers.  Written for accuracy, not speed: with
+// 17- and 25-tap kernels the four-pass form rounds four long fp32 sums per pixel, and near a stationary point the gradient is a
+// small difference of them -- here Jt is two fp64-accumulated sums (the production path stays within
+// 1e-5 of the exact-arithmetic value where the fp32 reference arithmetic itself does not).
+template <bool LIST>
+__global__ __launch_bounds__(kAdjThreads) void image_adjoint2g_kernel(ImgAdjArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads;
+  const ImgArgs &a = g.img;
+  const int W = a.W, H = a.H, r = a.r, ntap = 4 * r + 1;
+  const int AW = TX + 4 * r, AH = TY + 4 * r, GH = TY + 2 * r;
+  double *red = reinterpret_cast<double *>(smem_raw);
+  float *bufA = reinterpret_cast<float *>(smem_raw + 32 * sizeof(double));  // raw, AW x AH
+  float *bufG = bufA + AW * AH;                                             // G_x raw, TX x GH
+  float *bufM = bufG + TX * GH;                                             // M_x raw, TX x AH
+  const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
+  const float alpha = a.alpha ? (float)(*a.alpha) : 0.f;
+  const int n_work = LIST ? (int)(*a.tile_count) : 0;
+  for (int wi = blockIdx.x, once = 1; LIST ? (wi < n_work) : (once != 0); wi += gridDim.x, once = 0) {
+  const unsigned entry = LIST ? a.tile_list[wi] : (unsigned)wi;
+  const int tile = (int)(entry & 0x3fffffffu);
+  const int x0 = (tile % a.tiles_x) * TX, y0 = (tile / a.tiles_x) * TY;
+  if (LIST) __syncthreads();  // LDS of the previous tile is free
+  if (a.zero_ptr) {  // clear this tile of the other accumulation buffer (ping-pong: no memset launch next time)
+    const bool dirty = LIST ? (entry & 0x40000000u) != 0 : (!a.flags_other || a.flags_other[tile] != 0);
+    if (dirty) {
+      for (int idx = tid; idx < TX * TY * a.zero_planes; idx += NT) {
+        const int pl = idx / (TX * TY), q = idx - pl * (TX * TY);
+        const int gx = x0 + (q % TX), gy = y0 + (q / TX);
+        if (gx < W && gy < H) a.zero_ptr[(size_t)pl * W * H + (size_t)gy * W + gx] = 0.f;
+      }
+    }
+    if (!LIST) {
+      __syncthreads();
+      if (tid == 0 && a.flags_other && dirty) a.flags_other[tile] = 0;
+    }
+  }
+  const int slot = LIST ? wi : tile;
+  if (LIST ? !(entry & 0x80000000u) : !tile_active(a, tile % a.tiles_x, tile / a.tiles_x, 2 * r, TX, TY)) {
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + slot] = 0.0;
+      a.partials[(size_t)1 * a.nblk + slot] = 0.0;
+    }
+    continue;
+  }
+  for (int idx = tid; idx < AW * AH; idx += NT) {
+    const int ly = idx / AW, lx = idx - ly * AW;
+    const int gx = reflect101(x0 + lx - 2 * r, W), gy = reflect101(y0 + ly - 2 * r, H);
+    const size_t off = (size_t)gy * W + gx;
+    float v = a.src_a[off];
+    if (a.src_b) v = v + a.src_b[off];
+    if (a.igp) v = a.igp[off] * alpha + v;
+    bufA[idx] = v;
+  }
+  __syncthreads();
+  {
+    const bool interior = x0 >= 2 * r && x0 + TX - 1 <= W - 1 - 2 * r;
+    const float *mrow = g.Mx + (size_t)(interior ? 2 * r : min(x0 + tx, W - 1)) * ntap;
+    for (int ly = ty; ly < AH; ly += TY) {  // row pass, output column tx
+      const float *S = bufA + ly * AW + tx;
+      double m = 0.0;
+      for (int i = 0; i < ntap; i++) m = __builtin_fma((double)mrow[i], (double)S[i], m);
+      bufM[ly * TX + tx] = (float)m;
+      if (ly >= r && ly < r + GH) {  // forward row pass, same op order as image_moments
+        float sacc = a.taps[0] * S[r];
+        for (int j = 1; j <= 2 * r; j++) sacc += a.taps[j] * S[r + j];
+        bufG[(ly - r) * TX + tx] = sacc;
+      }
+    }
+  }
+  __syncthreads();
+  double sI = 0, sII = 0;
+  {
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx < W && gy < H) {
+      const float *T = bufG + (ty + r) * TX + tx;
+      float sacc = a.taps[r] * T[0];
+      for (int t = 1; t <= r; t++) sacc += a.taps[r + t] * (T[t * TX] + T[-t * TX]);
+      sI = (double)sacc;
+      sII = (double)sacc * (double)sacc;
+      if (a.out_blur0) a.out_blur0[(size_t)gy * W + gx] = sacc;
+      const bool interior = y0 >= 2 * r && y0 + TY - 1 <= H - 1 - 2 * r;
+      const float *mrow = g.My + (size_t)(interior ? 2 * r : min(y0 + ty, H - 1)) * ntap;
+      const float *Q = bufM + ty * TX + tx;
+      double j = 0.0;
+      for (int i = 0; i < ntap; i++) j = __builtin_fma((double)mrow[i], (double)Q[i * TX], j);
+      g.jt[(size_t)gy * W + gx] = (float)j;
+    }
+  }
+  {
+    double t0, t1;
+    block_sum2(sI, sII, red, NT / 64, t0, t1);
+    if (tid == 0) {
+      a.partials[(size_t)0 * a.nblk + slot] = t0;
+      a.partials[(size_t)1 * a.nblk + slot] = t1;
+    }
+  }
+  }  // work loop
+}
+
 void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  if (a.Mx && a.My && a.img.r == 4) {  // composite operator available (built with the blur for r == 4)
+  if (a.Mx && a.My && a.img.r != 4 && a.img.r >= 1) {  // composite operator, any radius (tail finalize: r == 4 only)
+    const size_t ldsg = image_adjoint2_lds_bytes(a.img.r);
+    if (a.img.tile_list) CMX_LAUNCH((image_adjoint2g_kernel<true>), dim3(min(a.img.nblk, kTileListGrid)), dim3(kAdjThreads), ldsg, s, t0, t1, a);
+    else CMX_LAUNCH((image_adjoint2g_kernel<false>), dim3(a.img.nblk), dim3(kAdjThreads), ldsg, s, t0, t1, a);
+    return;
+  }
+  if (a.Mx && a.My && a.img.r == 4) {  // composite operator, radius 4: taps and coefficient rows in registers
     const size_t lds2 = image_adjoint2_lds_bytes(4);
     const bool tail = a.img.tail.counters != nullptr;
     if (a.img.tile_list) {

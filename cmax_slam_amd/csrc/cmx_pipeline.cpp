@@ -454,7 +454,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
   ImgAdjArgs ia{};
   ImgArgs &a = ia.img;
-  if (c->composite_image && c->radius == 4 && c->d_Mx && c->d_My && c->Mx_radius == 4) { ia.Mx = c->d_Mx; ia.My = c->d_My; }
+  if (c->composite_image && c->radius >= 1 && c->d_Mx && c->d_My && c->Mx_radius == c->radius) { ia.Mx = c->d_Mx; ia.My = c->d_My; }
   a.W = W; a.H = H; a.r = c->radius;
   memcpy(a.taps, c->taps, sizeof(a.taps));
   a.src_a = c->d_accum;
@@ -547,7 +547,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     Span sp(c, CMX_T_IMAGE, /*exact=*/true);
     // cost-only with Jt kept (phase 3): the three-phase image pass has the registers to carry the finalize as its tail
     // (the five-phase kernel did not: inlined, its taps spilled and the pass went 11 -> 20 us)
-    if (phase == 3 && ia.Mx) image_tailed = arm_tail(c, f, a.tail);
+    if (phase == 3 && ia.Mx && c->radius == 4) image_tailed = arm_tail(c, f, a.tail);
     launch_image_adjoint(ia, c->stream, sp.t0(), sp.t1());
     if (!direct) launch_reduce_partials(f, c->stream);
   }

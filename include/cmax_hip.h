@@ -91,9 +91,11 @@ enum {
                              BASELINE config 2 (45.9 vs 41.5 us per fdf: 651 windows of 64x64 are 8.7x the pixels of the one
                              image pass), hence opt-in */
   CMX_OPT_COMPOSITE_IMAGE = 8, /* 1 (default): the image pass of the adjoint gradient applies G^T G as one banded operator per
-                             axis (blur radius 4, i.e. sigma in [0.94, 1.06]: the reference's blur_sigma = 1): three
-                             barrier-separated phases per tile instead of five.  B and the contrast are unchanged to the
-                             bit; Jt differs from the four-pass form by fp32 rounding (~1e-7 relative).  0: four passes */
+                             axis, its 4r+1-term sums accumulated in fp64: three barrier-separated phases per tile instead
+                             of five (radius 4 = the reference's blur_sigma 1 has a register-resident form), and a gradient
+                             that stays within 1e-5 of the exact-arithmetic value of the reference's formula where long fp32
+                             sums do not.  B and the contrast are unchanged to the bit.
+                             0: the four-pass fp32 form */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
                              than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
