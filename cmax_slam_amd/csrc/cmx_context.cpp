@@ -180,6 +180,8 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   memset(c->h_result, 0, c->result_cap * sizeof(double));
   HIP_TRY(c, hipMalloc((void **)&c->d_tail_counters, kTailCounterWords * sizeof(unsigned)));
   HIP_TRY(c, hipMemset(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_gacc, (size_t)kTailShards * kGaccStride * sizeof(double)));
+  HIP_TRY(c, hipMemset(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double)));
   HIP_TRY(c, hipDeviceSynchronize());  // null-stream clears / copies above vs the context's non-blocking stream
   return CMX_OK;
 }
@@ -295,6 +297,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
   hipFree(c->d_tail_counters);
+  hipFree(c->d_gacc);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->h_many) hipHostFree(c->h_many);

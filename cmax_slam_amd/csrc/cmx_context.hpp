@@ -179,6 +179,7 @@ struct cmx_ctx {
   double *result_override = nullptr;            // where the next finalize writes instead of d_result (eval_many)
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
+  double *d_gacc = nullptr;             // kTailShards x kGaccStride gradient accumulators of the tail finalize, all-zero between launches
 
   // native RCCL exchange (cmx_comm_attach): every evaluation all-reduces its partial planes / gradient sums in place
   ncclComm_t comm = nullptr;

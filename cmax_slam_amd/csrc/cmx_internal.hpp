@@ -67,6 +67,11 @@ struct FinalizeArgs {
   int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
   int moment_cols;         // 1: two more columns follow -- sum B^2, sum B -- and the image moments are taken from them
   unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
+  // tail finalize of the back-end gradient: instead of a [column][workgroup] table the per-batch pass adds its column sums to
+  // kTailShards rows of accumulators (device-scope fp64 atomics, row = workgroup % kTailShards); the finalize sums the rows
+  // and stores zeros back, so that the buffer is all-zero between launches.  Null = the table (gpartials / gblocks)
+  double *gacc;
+  int gacc_stride;            // doubles per shard row (>= number of columns)
 };
 // tail of the mapped result buffer (doubles / u64 bit patterns)
 constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nout) and result[kFallbackSlot], ^ ticket*kTicketMix
@@ -84,6 +89,7 @@ constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
 constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kTailCounterWords = (kTailShards + 1) * kTailStride;
+constexpr int kGaccStride = 2 * 3 * kMaxKnots + 2;  // doubles per accumulator row: S1 | S2 columns (+ spare), see FinalizeArgs::gacc
 struct TailArgs {
   unsigned *counters;  // all-zero between launches (the last arrivers reset what they completed); null = no tail finalize
   FinalizeArgs fin;

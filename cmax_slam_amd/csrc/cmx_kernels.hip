@@ -448,7 +448,19 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     // with one accumulator per column -- every thread's loads go out in one round.  Few rows, many columns (back end:
     // ~200 x 42): each wave takes whole columns, four at a time.
     const int ncol = (a.mu_free ? 2 * a.gP : a.gP) + (a.moment_cols ? 2 : 0);
-    if (a.gP > 0 && ncol <= 8) {
+    if (a.gacc) {  // kTailShards accumulator rows: one round of loads, then the zeros the next launch expects
+      if (t < ncol) {
+        double v[kTailShards];
+#pragma unroll
+        for (int q = 0; q < kTailShards; q++) v[q] = ld_sc1(a.gacc + (size_t)q * a.gacc_stride + t);
+        double w = 0;
+#pragma unroll
+        for (int q = 0; q < kTailShards; q++) w += v[q];
+        sm.cols[t] = w;
+#pragma unroll
+        for (int q = 0; q < kTailShards; q++) st_sc1(a.gacc + (size_t)q * a.gacc_stride + t, 0.0);
+      }
+    } else if (a.gP > 0 && ncol <= 8) {
       double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int b0 = 0; b0 < a.gblocks; b0 += 2 * NT) {
         // branch-free: every load of the round is issued before the first use (a predicated load inside the accumulation
@@ -1443,7 +1455,11 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   if (threadIdx.x < (g.cx ? 6 : 3)) {
     const int k = threadIdx.x;
     const double v = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
-    if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
+    if (tail && g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc)
+      if (v != 0.0)
+        __hip_atomic_fetch_add(g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride + k, v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
     else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
   if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
@@ -1898,6 +1914,14 @@ __global__ __launch_bounds__(256) void be_gather_batch_kernel(BeGatherArgs g, in
   }
   __syncthreads();
   const bool tail = g.tail.counters != nullptr;
+  if (tail && g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc)
+    double *row = g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride;
+    for (int j = tid; j < g.P; j += 256) {
+      const double v1 = shG[j], v2 = shG2[j];
+      if (v1 != 0.0) __hip_atomic_fetch_add(row + j, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v2 != 0.0) __hip_atomic_fetch_add(row + g.P + j, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else
   for (int j = tid; j < g.P; j += 256) {  // [column][block]
     if (tail) {  // write-through: read by the last-arriving workgroup of this launch
       st_sc1(g.gpartials + (size_t)j * gridDim.x + blockIdx.x, shG[j]);

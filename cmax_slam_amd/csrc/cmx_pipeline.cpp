@@ -226,9 +226,20 @@ void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
 bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail) {
   tail.counters = nullptr;
   if (!c->tail_finalize || !c->d_tail_counters || !f.direct || f.measure == 2) return false;
-  // back end, gradient evaluations: the 42-column partial table makes the tail 1.5-2 us SLOWER than the finalize launch
-  // (measured, config 3); cost-only evaluations have no table and gain like the front end.  Option value 2 forces it.
-  if (c->kind == KIND_BE && f.gP > 0 && c->tail_finalize < 2) return false;
+  // back end, gradient evaluations: read as a 42-column x 196-row table by one 256-thread workgroup the tail is 1.5-2 us
+  // SLOWER than the finalize launch (measured, config 3).  Outside CMX_OPT_DETERMINISTIC the per-batch pass therefore adds
+  // its column sums to kTailShards rows of accumulators with device-scope fp64 atomics (the order of the adds varies run
+  // to run -- so does the vote image in that mode) and the tail reads 8 x 42 values.  Option value 2 forces the table form.
+  if (c->kind == KIND_BE && f.gP > 0 && c->tail_finalize < 2) {
+    if (c->deterministic || !c->d_gacc || 2 * f.gP > kGaccStride) return false;
+    f.gacc = c->d_gacc;
+    f.gacc_stride = kGaccStride;
+  }
+  // front end: the same accumulators instead of the ~1000 x 6 table (gather + tail 14.9 -> 13.2 us); value 2 keeps the table
+  if (c->kind == KIND_FE && f.gP > 0 && !f.moment_cols && c->tail_finalize < 2 && !c->deterministic && c->d_gacc) {
+    f.gacc = c->d_gacc;
+    f.gacc_stride = kGaccStride;
+  }
   f.ticket = ++c->ticket_issued;
   c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
   tail.counters = c->d_tail_counters;
@@ -659,6 +670,7 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
       if (w[kTicketSlot] != c->ticket_issued) {
         const unsigned long long got = w[kTicketSlot];
         if (c->d_tail_counters) (void)hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream);
+        if (c->d_gacc) (void)hipMemsetAsync(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double), c->stream);
         return fail(c, CMX_ERR_HIP, "evaluation ended without its finalize step (ticket %llu, expected %llu)", got,
                     (unsigned long long)c->ticket_issued);
       }

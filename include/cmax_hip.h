@@ -76,11 +76,15 @@ enum {
                              time order and large panoramas do not use the compacted tile list, so that every
                              floating-point sum has a fixed order.  Costs ~10-20 % per evaluation.  The reference-shaped
                              flow (derivative planes, fp32 atomics) stays order-dependent */
-  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default; on the back end this covers cost-only evaluations, 2 = gradient evaluations too --
-                             measured 1.5-2 us slower there, their partial table has 42 columns): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint
-                             gradient: the gather pass) runs the finalize step -- contrast, gradient, result hand-off -- in
-                             its last-arriving workgroup (write-through partial sums, tickets sharded by XCD, one agent-scope
-                             acquire) instead of a separate one-workgroup launch behind a kernel boundary.
+  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint gradient:
+                             the gather pass / the back end's per-batch pass) runs the finalize step -- contrast, gradient,
+                             result hand-off -- in its last-arriving workgroup (write-through partial sums, tickets sharded
+                             by XCD, sc1 loads) instead of a separate one-workgroup launch behind a kernel boundary.  The
+                             gradient sums of the workgroups reach it through 8 rows of accumulators (device-scope fp64
+                             atomic adds; their order varies run to run, like the vote image's in this mode); with
+                             CMX_OPT_DETERMINISTIC the front end uses a [column][workgroup] table instead and back-end
+                             gradient evaluations keep the separate launch (the 42-column table made the tail slower).
+                             2: tail with the table form everywhere (back-end gradient included).
                              0: separate finalize launch (the round-1 flow) */
   CMX_OPT_FUSED_GATHER = 7, /* 1 (default 0; front end, adjoint gradient, LDS-privatised splat, blur radius 2..4, no communicator,
                              not deterministic): the gradient pass builds Jt = G^T G I on each chunk's 64x64 vote window in
