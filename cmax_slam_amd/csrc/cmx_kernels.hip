@@ -441,26 +441,24 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   if (t == 0) sm.shchk = 0ull;
   const double N = a.npix;
-  if (a.measure != 2 && a.gP > 0) {
+  // Everything this workgroup reads was written by other CUs: each dependent round of loads is a ~1.2 us trip to memory.
+  // The reads that do not depend on one another -- fallback counter, accumulator rows, moment rows -- are issued together.
+  unsigned fb_count = 0u;
+  if (t == 0 && a.fallback) fb_count = *a.fallback;
+  const int ncol_acc = (a.gacc && a.measure != 2 && a.gP > 0) ? (a.mu_free ? 2 * a.gP : a.gP) : 0;
+  double gv[kTailShards];
+  if (t < ncol_acc) {
+#pragma unroll
+    for (int q = 0; q < kTailShards; q++) gv[q] = ld_sc1(a.gacc + (size_t)q * a.gacc_stride + t);
+  }
+  if (a.measure != 2 && a.gP > 0 && !a.gacc) {
     // adjoint mode: grad_k = (2/N) (S1_k - mu*S2_k);  gpartials is [column][gblocks], columns = S1 (gP) then S2 (gP).
     // ONE workgroup reads tables other CUs wrote: every load is a ~1-2 us round trip to memory / a remote L2, so what
     // matters is how many are in flight.  Many rows, few columns (front end: ~1000 x 6): all threads stride over the rows
     // with one accumulator per column -- every thread's loads go out in one round.  Few rows, many columns (back end:
     // ~200 x 42): each wave takes whole columns, four at a time.
     const int ncol = (a.mu_free ? 2 * a.gP : a.gP) + (a.moment_cols ? 2 : 0);
-    if (a.gacc) {  // kTailShards accumulator rows: one round of loads, then the zeros the next launch expects
-      if (t < ncol) {
-        double v[kTailShards];
-#pragma unroll
-        for (int q = 0; q < kTailShards; q++) v[q] = ld_sc1(a.gacc + (size_t)q * a.gacc_stride + t);
-        double w = 0;
-#pragma unroll
-        for (int q = 0; q < kTailShards; q++) w += v[q];
-        sm.cols[t] = w;
-#pragma unroll
-        for (int q = 0; q < kTailShards; q++) st_sc1(a.gacc + (size_t)q * a.gacc_stride + t, 0.0);
-      }
-    } else if (a.gP > 0 && ncol <= 8) {
+    if (a.gP > 0 && ncol <= 8) {
       double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int b0 = 0; b0 < a.gblocks; b0 += 2 * NT) {
         // branch-free: every load of the round is issued before the first use (a predicated load inside the accumulation
@@ -548,6 +546,14 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   } else if (t < 2) {
     sm.sh[t] = a.sums[t];
   }
+  if (t < ncol_acc) {  // accumulator rows (loaded above): their sum, then the zeros the next launch expects
+    double w = 0;
+#pragma unroll
+    for (int q = 0; q < kTailShards; q++) w += gv[q];
+    sm.cols[t] = w;
+#pragma unroll
+    for (int q = 0; q < kTailShards; q++) st_sc1(a.gacc + (size_t)q * a.gacc_stride + t, 0.0);
+  }
   __syncthreads();
   const double s0 = sm.sh[0], s1 = sm.sh[1];
   const double mu = s0 / N;
@@ -564,7 +570,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     sm.outv[0] = c;
     sm.outv[1] = mu;
     if (a.fallback) {
-      sm.shfall = (double)(*a.fallback);
+      sm.shfall = (double)fb_count;
       *a.fallback = 0u;
     } else {
       sm.shfall = 0.0;
