@@ -171,7 +171,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     for i in range(warmup):
         run.step(points[i % npts], True)
     # ---- calibration (untimed): every kernel class, fdf then cost-only
-    ncal = max(2 * npts, 8)
+    ncal = max(8 * npts, 64)  # (16 evaluations gave per-kernel means that moved by 10 % from run to run)
     ev.timing_enable(True)
     ev.timing_get()
     for i in range(ncal):
@@ -540,7 +540,7 @@ def line(m, world, args, name, n_total, img, comm_used, mode_desc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--steps-backend", type=int, default=None, help="timed steps of the nested back-end leg at N=1 (default: --steps)")
     ap.add_argument("--workload", default="auto", choices=["auto", "frontend", "backend"],
