@@ -337,6 +337,9 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_FUSED_GATHER:
       c->fused_gather = value != 0;
       return CMX_OK;
+    case CMX_OPT_FOLD_BATCH:
+      c->fold_batch = value != 0;
+      return CMX_OK;
     case CMX_OPT_COMPOSITE_IMAGE:
       c->composite_image = value != 0;
       c->x_valid = false;  // a resident Jt of the other form is not reused

@@ -168,7 +168,9 @@ struct BeGatherArgs {
   const double *tb;        // optional: bearing (x, y) of every event in TIME order (16 B, z == 1): coalesced stream for the
                            // four-events-per-lane pass instead of four divergent bearing-table gathers per lane
   TailArgs tail;           // be_gather_batch: finalize in the last-arriving workgroup (counters == null: separate launch)
+  int fold;                // 1: fold the per-batch pass into be_gather4 when the launcher's conditions hold (be_gather_folds)
 };
+bool be_gather_folds(const BeGatherArgs &a);
 
 struct AlphaArgs {
   const float *igp, *il_old, *il_new;

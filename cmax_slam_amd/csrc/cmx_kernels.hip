@@ -1781,7 +1781,19 @@ __global__ __launch_bounds__(256) void be_gather_kernel(BeGatherArgs g) {
 // The same pass with FOUR consecutive events per lane (per_batch % 4 == 0, so a lane's events share one batch): one
 // 16-byte event load and one rotation-table read per lane, the four warps are independent instruction streams, and
 // the segmented wave reduction -- a third of the one-event form's instructions -- is paid once per 256 events.
+// NF = 0: per-batch partial sums go to vparts and be_gather_batch_kernel finishes them.  NF = 2 / 4 (spline order): the
+// per-batch pass is FOLDED in -- the head lane of every batch run applies the batch's 3 x 3NF Jacobian to its partial V
+// (J is linear: partial sums may be multiplied one by one) and adds the columns to workgroup accumulators in LDS; the
+// workgroup's sums go to the accumulator rows of the tail finalize (FinalizeArgs::gacc) and the last-arriving workgroup
+// finalizes.  No vparts round trip, no per-batch launch.  Not in CMX_OPT_DETERMINISTIC (order of the fp64 atomics).
+template <int NF>
 __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
+  __shared__ double shG[NF ? kMaxGradLDS : 1], shG2[NF ? kMaxGradLDS : 1];
+  __shared__ FinSmem fin_sm;
+  if (NF) {
+    for (int j = threadIdx.x; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
+    __syncthreads();
+  }
   const BeSplatArgs &a = g.ev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
@@ -1847,13 +1859,49 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
         if (same) { U0 += u0; U1 += u1; U2 += u2; }
       }
     }
-    const int bprev = __shfl_up(batch, 1, 64);
-    if (batch >= 0 && (lane == 0 || bprev != batch)) {
-      const int part = (base >> 8) - ((batch * a.per_batch) >> 8);
-      double *dst = g.vparts + ((size_t)batch * g.parts_per_batch + part) * 6;
-      dst[0] = V0; dst[1] = V1; dst[2] = V2;
-      dst[3] = U0; dst[4] = U1; dst[5] = U2;
+    if (NF) {
+      // lane = (run r of this wave pass, column c of the run's batch Jacobian): a wave pass of 256 events meets at most
+      // 256 / per_batch + 2 <= 64 / (3 NF) batch runs (the launcher's condition).  The first lane of a run holds the run's
+      // sums: every (run, column) lane fetches them and adds its column.  (Fetching the Jacobian entries a pass ahead
+      // kept six more registers alive across the warp: 172 VGPRs, two waves per SIMD instead of three, 60 -> 78 us.)
+      const int fr = lane / (3 * NF), fc = lane - fr * (3 * NF);
+      const int fb = base / a.per_batch + fr;
+      const int first_ev = max(base, fb * a.per_batch);
+      const bool f_ok = first_ev < min(a.n, base + 256);
+      const int fhead = (first_ev - base) >> 2;
+      float fj0 = 0.f, fj1 = 0.f, fj2 = 0.f;
+      int fj = -1;
+      if (f_ok) {
+        const PoseEntry &pe = a.poses[fb];
+        fj0 = pe.Jcp[fc]; fj1 = pe.Jcp[3 * NF + fc]; fj2 = pe.Jcp[6 * NF + fc];
+        fj = 3 * (pe.idx_cp_beg - a.num_fixed) + fc;
+      }
+      const double v0 = __shfl(V0, fhead, 64), v1 = __shfl(V1, fhead, 64), v2 = __shfl(V2, fhead, 64);
+      if (f_ok && fj >= 0) atomicAdd(&shG[fj], v0 * (double)fj0 + v1 * (double)fj1 + v2 * (double)fj2);
+      if (any_u) {  // wave-uniform
+        const double u0 = __shfl(U0, fhead, 64), u1 = __shfl(U1, fhead, 64), u2 = __shfl(U2, fhead, 64);
+        if (f_ok && fj >= 0 && (u0 != 0.0 || u1 != 0.0 || u2 != 0.0))
+          atomicAdd(&shG2[fj], u0 * (double)fj0 + u1 * (double)fj1 + u2 * (double)fj2);
+      }
+    } else {
+      const int bprev = __shfl_up(batch, 1, 64);
+      if (batch >= 0 && (lane == 0 || bprev != batch)) {
+        const int part = (base >> 8) - ((batch * a.per_batch) >> 8);
+        double *dst = g.vparts + ((size_t)batch * g.parts_per_batch + part) * 6;
+        dst[0] = V0; dst[1] = V1; dst[2] = V2;
+        dst[3] = U0; dst[4] = U1; dst[5] = U2;
+      }
     }
+  }
+  if (NF) {
+    __syncthreads();
+    double *row = g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride;
+    for (int j = threadIdx.x; j < g.P; j += 256) {
+      const double v1 = shG[j], v2 = shG2[j];
+      if (v1 != 0.0) __hip_atomic_fetch_add(row + j, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v2 != 0.0) __hip_atomic_fetch_add(row + g.P + j, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
   }
 }
 
@@ -1959,9 +2007,20 @@ int be_batch_blocks(int nb) {
   return blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
 }
 
+bool be_gather_folds(const BeGatherArgs &a) {
+  // (256 / per_batch + 2) runs x 3 NF columns must fit the 64 lanes of a wave
+  return a.fold && a.slice_shift == 8 && !a.deterministic && a.tail.counters && a.tail.fin.gacc && a.P > 0 && a.P <= kMaxGradLDS &&
+         (a.ev.order == 2 || a.ev.order == 4) && (256 / a.ev.per_batch + 2) * 3 * a.ev.order <= 64;
+}
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1, hipEvent_t b0, hipEvent_t b1) {
   // (t0, t1) bracket the per-event kernel, (b0, b1) the per-batch pass that follows
-  if (a.slice_shift == 8) CMX_LAUNCH(be_gather4_kernel, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, t0, t1, a);
+  if (be_gather_folds(a)) {  // per-batch pass and finalize inside the four-events-per-lane kernel (see be_gather4_kernel)
+    const dim3 g4(gather_blocks((a.ev.n + 3) / 4));
+    if (a.ev.order == 2) CMX_LAUNCH(be_gather4_kernel<2>, g4, dim3(256), 0, s, t0, t1, a);
+    else CMX_LAUNCH(be_gather4_kernel<4>, g4, dim3(256), 0, s, t0, t1, a);
+    return 0;
+  }
+  if (a.slice_shift == 8) CMX_LAUNCH(be_gather4_kernel<0>, dim3(gather_blocks((a.ev.n + 3) / 4)), dim3(256), 0, s, t0, t1, a);
   else CMX_LAUNCH(be_gather_kernel, dim3(gather_blocks(a.ev.n)), dim3(256), 0, s, t0, t1, a);
   const int blocks = be_batch_blocks(nb);
   if (a.deterministic) {

@@ -622,8 +622,13 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       }
       if (c->n_packed > 0 && P > 0) {
         if (phase == 0) tailed = arm_tail(c, f, g.tail);
-        Span sb(c, CMX_T_BATCH, /*exact=*/true);
-        launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), sb.t0(), sb.t1());
+        g.fold = c->fold_batch ? 1 : 0;
+        if (be_gather_folds(g)) {  // one kernel: gather, per-batch pass and finalize
+          launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), nullptr, nullptr);
+        } else {
+          Span sb(c, CMX_T_BATCH, /*exact=*/true);
+          launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), sb.t0(), sb.t1());
+        }
       } else {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
       }

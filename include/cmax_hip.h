@@ -100,6 +100,10 @@ enum {
                              that stays within 1e-5 of the exact-arithmetic value of the reference's formula where long fp32
                              sums do not.  B and the contrast are unchanged to the bit.
                              0: the four-pass fp32 form */
+  CMX_OPT_FOLD_BATCH = 9, /* 1 (default; back end, adjoint gradient, batches of a multiple of four events, tail finalize on, not
+                             deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
+                             inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
+                             0: separate per-batch kernel */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
                              than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
