@@ -239,6 +239,11 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     # ---- per-kernel roofline table
     nnz = getattr(run, "nnz_pixels", 0)
     models = byte_models(kind, order, n_local, npix, nb, P, adjoint, nnz, getattr(run, "image_pixels", None))
+    if kind == "backend" and adjoint and "batch" not in kernel_ms and "gather" in models:
+        # the per-batch pass ran inside the gather kernel (CMX_OPT_FOLD_BATCH): it reads the 152-byte Jacobian record of every
+        # batch there and the 48-byte per-batch partial sums never exist
+        a_g, m_g = models["gather"]
+        models["gather"] = (a_g + nb * 152, m_g - nb * 48 + nb * 152)
     pmc = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
