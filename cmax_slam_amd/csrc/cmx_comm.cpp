@@ -121,13 +121,18 @@ void comm_reset_band(cmx_ctx *c) {
 }
 
 static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad) {
+  // the gradient sums travel as the accumulator rows the kernels add to (kTailShards x kGaccStride doubles, 25 KB: the
+  // collective is latency-bound either way) whenever run_adjoint can use them; otherwise as the 2P-double buffer
+  c->shard_acc = true;
   int rc = finish_begin(c, kind, grad != nullptr);
-  if (rc) return rc;
-  if (c->pending_P > 0) {
-    rc = comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, CMX_DT_F64);  // adjoint mode: S1,S2 partial sums
-    if (rc) return rc;
+  if (!rc && c->pending_P > 0) {
+    const bool rows = !c->deterministic && c->d_gacc && 2 * c->pending_P <= kGaccStride;  // (run_adjoint's condition: rank-invariant)
+    rc = rows ? comm_allreduce(c, c->d_gacc, (size_t)kTailShards * kGaccStride, CMX_DT_F64)
+              : comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, CMX_DT_F64);  // adjoint mode: S1,S2 partial sums
   }
-  return finish_end(c, kind, contrast, grad);
+  if (!rc) rc = finish_end(c, kind, contrast, grad);
+  c->shard_acc = false;
+  return rc;
 }
 
 // evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream

@@ -106,6 +106,7 @@ struct cmx_ctx {
   int Mx_radius = -1;                      // blur radius the tables were built for (-1: none)
   bool composite_image = true;             // CMX_OPT_COMPOSITE_IMAGE
   bool fold_batch = true;                  // CMX_OPT_FOLD_BATCH
+  bool shard_acc = false;                  // set by cmx_comm.cpp around a split evaluation it all-reduces itself (see run_adjoint)
   bool fused_gather = false;               // CMX_OPT_FUSED_GATHER (opt-in: measured slower on MI355X)
   int64_t fused_evals = 0;                 // gradient evaluations that took the fused pass
   double *d_gpartials = nullptr;

@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   if (threadIdx.x < (g.cx ? 6 : 3)) {
     const int k = threadIdx.x;
     const double v = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
-    if (tail && g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc)
+    if (g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc); with or without the tail
       if (v != 0.0)
         __hip_atomic_fetch_add(g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride + k, v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1901,7 +1901,7 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
       if (v1 != 0.0) __hip_atomic_fetch_add(row + j, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v2 != 0.0) __hip_atomic_fetch_add(row + g.P + j, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
+    if (g.tail.counters && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
   }
 }
 
@@ -1968,7 +1968,7 @@ __global__ __launch_bounds__(256) void be_gather_batch_kernel(BeGatherArgs g, in
   }
   __syncthreads();
   const bool tail = g.tail.counters != nullptr;
-  if (tail && g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc)
+  if (g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc); with or without the tail
     double *row = g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride;
     for (int j = tid; j < g.P; j += 256) {
       const double v1 = shG[j], v2 = shG2[j];
@@ -2009,7 +2009,7 @@ int be_batch_blocks(int nb) {
 
 bool be_gather_folds(const BeGatherArgs &a) {
   // (256 / per_batch + 2) runs x 3 NF columns must fit the 64 lanes of a wave
-  return a.fold && a.slice_shift == 8 && !a.deterministic && a.tail.counters && a.tail.fin.gacc && a.P > 0 && a.P <= kMaxGradLDS &&
+  return a.fold && a.slice_shift == 8 && !a.deterministic && a.tail.fin.gacc && a.P > 0 && a.P <= kMaxGradLDS &&
          (a.ev.order == 2 || a.ev.order == 4) && (256 / a.ev.per_batch + 2) * 3 * a.ev.order <= 64;
 }
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1, hipEvent_t b0, hipEvent_t b1) {

@@ -534,9 +534,17 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   f.direct = direct ? 1 : 0;
   f.nvalid = a.tile_count;
   f.mu_free = 1;
+  // split call with the evaluator's own communicator: the workgroups' sums go to the accumulator rows (FinalizeArgs::gacc),
+  // the rows are all-reduced as they are (cmx_comm.cpp) and the finalize sums them -- no per-batch kernel, no
+  // reduce_gpartials launch.  Callers that all-reduce cmx_grad_ptr() themselves keep the 2P-double buffer.
+  // (rank-invariant condition: every rank must issue the same collective, also one whose shard is empty)
+  const bool acc_split = phase != 0 && c->shard_acc && !c->deterministic && c->d_gacc && 2 * P <= kGaccStride && P > 0;
   if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
     f.gpartials = c->d_gpartials;
     f.gblocks = gb;
+  } else if (acc_split) {
+    f.gacc = c->d_gacc;
+    f.gacc_stride = kGaccStride;
   } else {           // split call: finalize reads the (all-reduced) per-parameter sums
     f.gpartials = c->d_gsum;
     f.gblocks = 1;
@@ -596,6 +604,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       }
       if (c->n_packed > 0) {
         if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        else if (acc_split) g.tail.fin = f;  // (no counters: accumulators without the tail)
         launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       } else {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
@@ -622,6 +631,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       }
       if (c->n_packed > 0 && P > 0) {
         if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        else if (acc_split) g.tail.fin = f;  // (no counters: accumulators without the tail)
         g.fold = c->fold_batch ? 1 : 0;
         if (be_gather_folds(g)) {  // one kernel: gather, per-batch pass and finalize
           launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), nullptr, nullptr);
@@ -633,7 +643,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
       }
     }
-    if (phase == 1) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
+    if (phase == 1 && !acc_split) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
   }
   if (phase == 1) {
     HIP_TRY(c, hipGetLastError());
