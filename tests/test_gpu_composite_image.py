@@ -82,3 +82,44 @@ def test_backend_composite_image_pass(hip, oracle, Wp, Hp):
         assert rel_scalar(ca, c_ref) < RTOL and rel_vec(ga, g_ref) < RTOL, (Wp, Hp, ca, c_ref)
         assert rel_scalar(ca, cb) < 1e-6 and rel_vec(ga, gb) < 5e-6
     assert evs[0].alpha != 0.0
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.7, 2.0, 3.0])       # radius 2, 7, 8, 12: the run-time-radius form of the composite pass
+@pytest.mark.parametrize("Wp,Hp", [(600, 300), (4096, 2048)])  # one workgroup per tile / tile-list walk
+def test_backend_composite_image_pass_other_radii(hip, oracle, Wp, Hp, sigma):
+    W, H = 120, 90
+    f = 1.1 * W
+    w = synth.backend_window(25_000, W, H, f, f, (W - 1) / 2, (H - 1) / 2, Wp, Hp, 4, 7, 2, 0.2, seed=334)
+    rng = np.random.default_rng(6)
+    IG = np.zeros((Hp, Wp), np.float32)
+    IG[Hp // 2 - 20:Hp // 2 + 20, Wp // 2 - 40:Wp // 2 + 40] = rng.uniform(0.5, 3.0, (40, 80)).astype(np.float32)
+    evs = []
+    for composite in (1, 0):
+        be = hip.BackendEvaluator(W, H, w.lut, Wp, Hp)
+        be.set_fast_path()
+        be.set_option(_lib.OPT_COMPOSITE_IMAGE, composite)
+        be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                      w.sample_rate, sigma, _lib.VARIANCE, IG)
+        evs.append(be)
+    ref = oracle.Backend(W, H, w.lut, Wp, Hp, w.order, w.batch, w.sample_rate, sigma, _lib.VARIANCE)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, IG)
+    for x in (np.zeros(w.P), rng.normal(0, 0.02, w.P)):
+        c_ref, g_ref = ref.eval(x)
+        ca, ga = evs[0].eval(x)
+        cb, gb = evs[1].eval(x)
+        assert rel_scalar(ca, c_ref) < RTOL and rel_vec(ga, g_ref) < RTOL, (Wp, Hp, sigma)
+        assert rel_scalar(ca, cb) < 1e-6 and rel_vec(ga, gb) < RTOL
+
+
+@pytest.mark.parametrize("W,H,sigma", [(60, 50, 3.0), (49, 53, 3.0), (48, 60, 3.0), (100, 35, 2.0), (33, 33, 2.0)])
+def test_frontend_composite_small_images_large_radius(hip, oracle, W, H, sigma):
+    """image barely larger (or not larger) than the operator's 4r+1 band: tables built iff both sides exceed 4r"""
+    f = 0.9 * max(W, H)
+    p = synth.frontend_packet(8_000, W, H, f, f, (W - 1) / 2, (H - 1) / 2, seed=72)
+    fe = _fe(hip, p, sigma, _lib.VARIANCE, True)
+    ref = oracle.Frontend(W, H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, sigma, _lib.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in ([0.3, -0.5, 0.2], p.omega_true):
+        c_ref, g_ref = ref.eval(om)
+        c, g = fe.eval(om)
+        assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL, (W, H, sigma, g, g_ref)
