@@ -83,9 +83,9 @@ constexpr int kBandSlot = 4088;      // [0] first, [1] last flagged tile row of 
 constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
 
-// Tail finalize (cmx_kernels.hip, tail_arrive): the LAST kernel of an evaluation -- image_moments (cost-only),
-// fe_gather / be_gather_batch (adjoint gradient) -- runs the finalize step in its last-arriving workgroup, so an
-// evaluation ends without the one-workgroup finalize launch and the kernel boundary in front of it.
+// Tail finalize (cmx_kernels.hip, tail_arrive): the LAST kernel of an evaluation -- image_moments / image_adjoint2 (cost-only),
+// fe_gather / be_gather4 with the per-batch pass folded in / be_gather_batch (adjoint gradient) -- runs the finalize step in
+// its last-arriving workgroup, so an evaluation ends without the one-workgroup finalize launch and the boundary in front of it.
 constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
 constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kTailCounterWords = (kTailShards + 1) * kTailStride;
@@ -167,7 +167,8 @@ struct BeGatherArgs {
   int deterministic;       // per-parameter block sums in a fixed order instead of LDS fp64 atomics
   const double *tb;        // optional: bearing (x, y) of every event in TIME order (16 B, z == 1): coalesced stream for the
                            // four-events-per-lane pass instead of four divergent bearing-table gathers per lane
-  TailArgs tail;           // be_gather_batch: finalize in the last-arriving workgroup (counters == null: separate launch)
+  TailArgs tail;           // be_gather_batch / folded be_gather4: finalize in the last-arriving workgroup (counters == null: separate
+                           // launch); tail.fin.gacc set without counters: accumulator rows only (sharded split evaluation)
   int fold;                // 1: fold the per-batch pass into be_gather4 when the launcher's conditions hold (be_gather_folds)
 };
 bool be_gather_folds(const BeGatherArgs &a);
