@@ -1516,7 +1516,7 @@ __device__ __forceinline__ float jt_direct(const FeFusedArgs &g, int x, int y) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void fe_fused_gather_kernel(FeFusedArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void fe_fused_gather_kernel(FeFusedArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NT = 256, TW = 64, AW = TW + 4 * R, NTAP = 4 * R + 1, NIN = 4 + 4 * R;
   static_assert(AW % 4 == 0, "16-byte LDS rows");
