@@ -1,0 +1,70 @@
+"""CPU: oracle/frontend.c + oracle/backend.c (the C restatement every GPU parity test is measured against) versus
+oracle/iwe_numpy.py, a second restatement of the same reference lines written independently in numpy -- the per-event
+stage of both IWE builders: batch times in ros::Time arithmetic, warp, projection, Jacobian chains, bilinear votes and
+signed-weight derivative votes, IL_old / IL_new split, fixed-knot column rule, sampling stride, the back end's
+one-trailing-event quirk.  Both accumulate in the reference's order, so the float images must agree BIT FOR BIT.
+The batch poses come from the reference's own Basalt spline compiled from /root/reference (oracle/_ref) when that library
+is present, else from oracle/so3_spline.c (pinned against it by tests/test_oracle_golden.py).
+Neither side is the reference (OpenCV / ROS absent): two agreeing restatements, parity still unpinned."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import synth
+from oracle import iwe_numpy as iw
+
+
+@pytest.mark.parametrize("N,W,H,batch", [(5000, 120, 90, 100), (4901, 97, 61, 100), (257, 64, 48, 1), (1000, 240, 180, 7),
+                                         (3001, 80, 60, 1000), (1, 50, 40, 100)])
+def test_frontend_vote_stage_bit_for_bit(oracle, N, W, H, batch):
+    f = 0.9 * max(W, H)
+    p = synth.frontend_packet(N, W, H, f, f, (W - 1) / 2, (H - 1) / 2, seed=N)
+    ref = oracle.Frontend(W, H, p.lut, p.fx, p.fy, p.cx, p.cy, batch, 1.0, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in ([0.0, 0.0, 0.0], [0.3, -0.5, 0.2], p.omega_true, [-3.0, 2.0, 4.0]):
+        i0, d0 = ref.iwe(om, deriv=True, blur=False)
+        i1, d1 = iw.frontend_iwe(p.x, p.y, p.t_ns, p.t_ref_ns, p.lut, W, H, p.fx, p.fy, p.cx, p.cy, om, batch, True)
+        assert np.array_equal(i0, i1), (N, batch, om, np.abs(i0 - i1).max())
+        assert np.array_equal(d0, d1), (N, batch, om, np.abs(d0 - d1).max())
+        assert np.array_equal(ref.iwe(om, deriv=False, blur=False), i1)     # the display overload
+
+
+def test_ros_time_batch_midpoint(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        t0 = int(rng.integers(0, 2**40))
+        t1 = t0 + int(rng.integers(0, 3_000_000_000))
+        assert iw.batch_time_ns(t0, t1) == oracle.time_batch_ns(t0, t1), (t0, t1)
+    for t0, t1 in ((0, 1), (5, 5), (1_000_000_000 - 1, 1_000_000_000 + 2), (123456789012345, 123456789012346)):
+        assert iw.batch_time_ns(t0, t1) == oracle.time_batch_ns(t0, t1)
+
+
+@pytest.mark.parametrize("order,K,nf,batch,rate,N", [(4, 8, 2, 100, 1, 6000), (2, 5, 1, 64, 3, 6000), (4, 7, 0, 128, 2, 6017),
+                                                     (4, 6, 5, 100, 1, 3001), (2, 4, 0, 50, 5, 2501), (4, 9, 3, 100, 1, 4000)])
+def test_backend_vote_stage_bit_for_bit(oracle, order, K, nf, batch, rate, N):
+    T = 0.05 * (K - order + 1)
+    w = synth.backend_window(N, 120, 90, 130.0, 130.0, 59.5, 44.5, 256, 128, order, K, nf, T, seed=11 + K + N)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, order, batch, rate, 0.0, 0)       # sigma = 0: no blur
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, nf, w.t_next_win_beg_ns, None)
+    P = 3 * (K - nf)
+    try:
+        oracle.ref_lib()
+        use_ref = True
+    except Exception:
+        use_ref = False
+    rng = np.random.default_rng(N)
+    for x in (np.zeros(P), rng.normal(0, 0.02, P)):
+        iwe0, pl0 = ref.iwe(x, planes=True)
+        knots = oracle.left_update(w.knots_init, x, nf)
+
+        def pose_of(t):
+            _, R, J, idx = oracle.spline_eval(order, knots, w.start_ns, w.dt_ns, t, jac=True, use_ref=use_ref)
+            return R, J, idx
+        a, b, pl1 = iw.backend_iwe(w.x, w.y, w.t_ns, w.lut, w.W, w.Wp, w.Hp, order, nf, w.t_next_win_beg_ns, batch, rate, pose_of, P)
+        assert np.array_equal(ref.IL_old, a) and np.array_equal(ref.IL_new, b), (order, K, nf, N)
+        assert np.array_equal(iwe0, a + b)                                              # cv::add, alpha = 0
+        assert np.array_equal(pl0, pl1), (order, K, nf, N, np.abs(pl0 - pl1).max())
+        assert a.sum() + b.sum() > 0.5 * (N // rate)                                     # (the events do land on the map)
+    if N % batch == 1:  # the trailing batch of one event is skipped by the reference's cursor: same images without it
+        a2, b2, _ = iw.backend_iwe(w.x[:-1], w.y[:-1], w.t_ns[:-1], w.lut, w.W, w.Wp, w.Hp, order, nf, w.t_next_win_beg_ns, batch,
+                                   rate, pose_of, P)
+        assert np.array_equal(a, a2) and np.array_equal(b, b2)
