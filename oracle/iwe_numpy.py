@@ -216,3 +216,55 @@ def _gemm_f32(A, B):
     for k in range(3):
         out = out + a[:, :, k:k + 1] * b[None, k:k + 1, :]
     return out.astype(F32)
+
+
+# ---- global-map upkeep and alpha (event_pano_warper.cpp:81-165) ----------------------------------------------------
+def q_to_R(q_xyzw):
+    """Eigen::Quaterniond::toRotationMatrix() (Sophus::SO3d::matrix()), same operation order."""
+    x, y, z, w = (float(v) for v in q_xyzw)
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1.0 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1.0 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1.0 - (txx + tyy)]])
+
+
+def mark_visited(update_times, q_xyzw, lut, W, H, Wp, Hp, radius):
+    """setUpdateTimesIG (:81-107): every sensor pixel warped by the pose marks a (2 radius + 1)^2 neighbourhood of a mask --
+    with the reference's row test `0 <= y_mask + j` --, then cv::add(times, mask, times) on CV_8U (saturating)."""
+    R = q_to_R(q_xyzw)
+    lut = np.asarray(lut, np.float64).reshape(-1, 3)
+    ray = (R[None, :, 0] * lut[:, 0:1] + R[None, :, 1] * lut[:, 1:2]) + R[None, :, 2] * lut[:, 2:3]
+    fx = (Wp / 360.0) * 180.0 / math.pi
+    fy = (Hp / 180.0) * 180.0 / math.pi
+    pxm = Wp / 2.0 + np.arctan2(ray[:, 0], ray[:, 2]) * fx
+    pym = Hp / 2.0 + np.arcsin(ray[:, 1] / np.sqrt(ray[:, 0] * ray[:, 0] + ray[:, 1] * ray[:, 1] + ray[:, 2] * ray[:, 2])) * fy
+    ic = np.trunc(pxm).astype(np.int64)
+    ir = np.trunc(pym).astype(np.int64)
+    mask = np.zeros((Hp, Wp), np.uint8)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            xm, ym = ic + i, ir + j
+            ok = (0 <= ym + j) & (ym < Hp) & (0 <= xm) & (xm < Wp) & (ym >= 0)   # (ym >= 0: .at() with a negative row is UB in
+            mask[ym[ok], xm[ok]] = 1                                             #  the reference; no pixel goes there in-bounds)
+    update_times[:] = np.minimum(update_times.astype(np.int32) + mask, 255).astype(np.uint8)
+
+
+def update_ig(IG, IL_old, update_times, max_update_times):
+    """updateIG (:109-126)"""
+    m = update_times <= max_update_times
+    IG[m] = (IG[m] + IL_old[m]).astype(F32)
+
+
+def alpha(IGp, IL):
+    """updateAlpha (:134-165): ratio of the event densities num / area with area = sum(1 - exp(-I)) (float images, double sums)."""
+    if np.count_nonzero(IGp) < 1:
+        return 0.0
+
+    def density(I):
+        e = np.exp((F32(-1.0) * I).astype(F32)).astype(F32)     # cv::exp on CV_32F of the float MatExpr -(1/lambda0) * I
+        area = float(np.sum((F32(1) - e).astype(F32), dtype=np.float64))
+        return float(np.sum(I, dtype=np.float64)) / area
+    return density(IL) / density(IGp)

@@ -68,3 +68,34 @@ def test_backend_vote_stage_bit_for_bit(oracle, order, K, nf, batch, rate, N):
         a2, b2, _ = iw.backend_iwe(w.x[:-1], w.y[:-1], w.t_ns[:-1], w.lut, w.W, w.Wp, w.Hp, order, nf, w.t_next_win_beg_ns, batch,
                                    rate, pose_of, P)
         assert np.array_equal(a, a2) and np.array_equal(b, b2)
+
+
+def test_map_upkeep_and_alpha(oracle):
+    """setUpdateTimesIG / updateIG / updateAlpha: C restatement vs numpy restatement (exact where the arithmetic is integer or a
+    float add; alpha to the accuracy of two float exp implementations)."""
+    W, H, Wp, Hp = 64, 48, 256, 128
+    w = synth.backend_window(4000, W, H, 70.0, 70.0, 31.5, 23.5, Wp, Hp, 4, 7, 2, 0.2, seed=91)
+    be = oracle.Backend(W, H, w.lut, Wp, Hp, 4, 100, 1, 1.0, 0)
+    be.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, 2, w.t_next_win_beg_ns, None)
+    be.iwe(np.zeros(w.P))                       # fills IL_old / IL_new
+    rng = np.random.default_rng(4)
+    times = np.zeros((Hp, Wp), np.uint8)
+    IG = np.zeros((Hp, Wp), np.float32)
+    for step in range(6):
+        q = rng.normal(0, 1, 4)
+        q[3] += 3.0
+        q /= np.linalg.norm(q)
+        be.mark_visited(q, radius=3)
+        iw.mark_visited(times, q, w.lut, W, H, Wp, Hp, 3)
+        assert np.array_equal(be.update_times, times), step
+        be.update_ig(2)
+        iw.update_ig(IG, be.IL_old, times, 2)
+        assert np.array_equal(be.IG, IG), step
+    assert times.max() >= 3 and IG.max() > 0     # some pixels stopped being updated, some were
+    # alpha on a window with a prior map
+    be2 = oracle.Backend(W, H, w.lut, Wp, Hp, 4, 100, 1, 1.0, 0)
+    be2.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, 2, w.t_next_win_beg_ns, IG)
+    be2.iwe(np.zeros(w.P))
+    a_np = iw.alpha(IG, (be2.IL_old + be2.IL_new).astype(np.float32))
+    assert a_np > 0 and abs(be2.alpha - a_np) < 2e-6 * a_np, (be2.alpha, a_np)
+    assert iw.alpha(np.zeros_like(IG), be2.IL_old) == 0.0
