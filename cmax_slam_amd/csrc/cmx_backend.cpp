@@ -282,6 +282,7 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   c->accumulated = true;
   c->x_valid = true;
   c->jt_valid = false;
+  c->gated_pending = false;  // (a gated gradient pass still in flight belongs to the previous point: nobody will ask for it)
   for (int k = 0; k < 3 * Kopt && k < 3 * kMaxKnots; k++) c->last_x[k] = drotv[k];
   return CMX_OK;
 }
@@ -339,9 +340,21 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (rc) return rc;
   rc = be_first_iter(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, P);
-  else if (!grad && speculative_jt_ok(c) && P > 0) rc = run_adjoint(c, P, /*phase=*/3);
-  else rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) {
+    bool served = false;
+    rc = collect_gated(c, P, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
+    if (rc || served) return rc;
+    rc = run_adjoint(c, P);
+  } else if (!grad && speculative_jt_ok(c) && P > 0) {
+    rc = finish_cost_only_speculative(c, P);
+    if (rc) return rc;
+    *contrast = c->h_result[0];
+    return CMX_OK;
+  } else {
+    c->gated_pending = false;
+    c->gate_mode = 0;
+    rc = run_image_and_finalize(c, grad ? P : 0, nullptr, nullptr);
+  }
   if (rc) return rc;
   rc = sync_and_collect(c, true);
   if (rc) return rc;

@@ -178,6 +178,11 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
   HIP_TRY(c, hipHostMalloc((void **)&c->h_result, c->result_cap * sizeof(double), hipHostMallocMapped));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result, c->h_result, 0));
   memset(c->h_result, 0, c->result_cap * sizeof(double));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_result2, c->result_cap * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_result2, c->h_result2, 0));
+  memset(c->h_result2, 0, c->result_cap * sizeof(double));
+  HIP_TRY(c, hipMalloc((void **)&c->d_gate, sizeof(int)));
+  HIP_TRY(c, hipMemset(c->d_gate, 0, sizeof(int)));
   HIP_TRY(c, hipMalloc((void **)&c->d_tail_counters, kTailCounterWords * sizeof(unsigned)));
   HIP_TRY(c, hipMemset(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned)));
   HIP_TRY(c, hipMalloc((void **)&c->d_gacc, (size_t)kTailShards * kGaccStride * sizeof(double)));
@@ -300,6 +305,8 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_gacc);
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
+  if (c->h_result2) hipHostFree(c->h_result2);
+  hipFree(c->d_gate);
   if (c->h_many) hipHostFree(c->h_many);
   comm_release(c);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -337,6 +344,10 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_FUSED_GATHER:
       c->fused_gather = value != 0;
       return CMX_OK;
+    case CMX_OPT_GATED_DF:
+      c->gated_df = value != 0;
+      c->gated_pending = false;
+      return CMX_OK;
     case CMX_OPT_FOLD_BATCH:
       c->fold_batch = value != 0;
       return CMX_OK;
@@ -346,6 +357,13 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     default: return fail(c, CMX_ERR_INVALID_ARG, "unknown option %d", key);
   }
+}
+
+int cmx_hint_next_df(cmx_ctx *c, double threshold, int mode) {
+  if (!c || mode < 0 || mode > 4) return CMX_ERR_INVALID_ARG;
+  c->gate_thr = threshold;
+  c->gate_mode = mode;
+  return CMX_OK;
 }
 
 int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
@@ -383,6 +401,8 @@ int cmx_get_stats(cmx_ctx *c, double stats[16]) {
   stats[8] = (double)c->fused_evals;
   stats[9] = (double)c->spec_images;
   stats[10] = (double)c->spec_hits;
+  stats[11] = (double)c->gated_launches;
+  stats[12] = (double)c->gated_hits;
   return CMX_OK;
 }
 

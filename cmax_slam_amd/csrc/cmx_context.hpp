@@ -179,6 +179,17 @@ struct cmx_ctx {
   double *h_many = nullptr, *d_many = nullptr;  // cmx_*_eval_many: one 4096-double result block per evaluation of the list
   size_t many_cap = 0;
   double *result_override = nullptr;            // where the next finalize writes instead of d_result (eval_many)
+  // gated gradient pass behind a cost-only evaluation (cmx_hint_next_df; cmx_pipeline.cpp run_adjoint / finish_cost_only)
+  double *h_result2 = nullptr, *d_result2 = nullptr;  // second mapped result block: the gated pass reports here
+  int *d_gate = nullptr;                        // written by the cost-only evaluation's finalize, read by the gated launch
+  int gate_mode = 0;                            // hint for the NEXT cost-only evaluation (consumed by it): 0 none, 1..4 see gate_condition
+  double gate_thr = 0;
+  bool gated_df = true;                         // CMX_OPT_GATED_DF
+  bool gate_arm = false;                        // set around run_adjoint(phase 3) when a gated pass will be queued behind it
+  bool gated_pending = false, gated_fired = false;  // a gated pass is queued behind the last evaluation / its gate opened
+  unsigned long long ticket2_issued = 0;
+  int ticket2_nout = 0;
+  unsigned long long gated_launches = 0, gated_hits = 0;
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
   double *d_gacc = nullptr;             // kTailShards x kGaccStride gradient accumulators of the tail finalize, all-zero between launches
@@ -298,11 +309,13 @@ FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]);
 BeSplatArgs be_args(const cmx_ctx *c);
 bool adjoint_ok(const cmx_ctx *c);
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce);
-bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail);  // true: the next launch carries the finalize (no separate launch)
+bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail, bool gated = false);  // true: the next launch carries the finalize (no separate launch)
 int attach_tiles(cmx_ctx *c, ImgArgs &a, bool may_skip);
 int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach);
 int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd);
-int run_adjoint(cmx_ctx *c, int P, int phase = 0);  // phase 3: image pass + cost-only finalize, Jt kept
+int run_adjoint(cmx_ctx *c, int P, int phase = 0);  // phase 3: image pass + cost-only finalize, Jt kept; 4: gated gradient pass
+int finish_cost_only_speculative(cmx_ctx *c, int P);  // phase 3 (+ the gated pass when a hint is set), then the wait
+int collect_gated(cmx_ctx *c, int P, double *contrast, double *grad, bool *served);  // a df served by the pass already queued
 bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);

@@ -23,6 +23,11 @@ struct FunctionFdf {
   void (*fdf)(const double *x, void *params, double *f, double *g);
   size_t n;
   void *params;
+  // optional (not in GSL): called right before a cost-only evaluation with the test on its value f that decides whether the
+  // gradient at the same point is requested next -- mode 1: f < thr, 2: f <= thr, 3: !(f >= thr), 4: always.  An evaluator
+  // that can act on it (cmx_hint_next_df) queues the gradient pass behind the cost evaluation; the sequence of f / df
+  // calls is unchanged.
+  void (*hint)(double thr, int mode, void *params) = nullptr;
 };
 
 enum { FRCG_SUCCESS = 0, FRCG_CONTINUE = -2, FRCG_ENOPROG = 27 };  // GSL_SUCCESS / GSL_CONTINUE / GSL_ENOPROG
@@ -66,6 +71,7 @@ class FrcgMinimizer {
     dir = (pg >= 0.0) ? +1.0 : -1.0;
     // trial point x_c = x - step * p
     take_step(x, p, stepc, dir / pnorm_, x1, dx);
+    if (fn_.hint) fn_.hint(fa, 1, fn_.params);  // df(x1) follows iff fc < fa
     fc = fn_.f(x1.data(), fn_.params);
     if (fc < fa) {
       // success: reduced the function value
@@ -151,6 +157,7 @@ class FrcgMinimizer {
         fn_.df(x1.data(), fn_.params, gradient.data());
         return;
       }
+      if (fn_.hint) fn_.hint(fa, stepb > 0.0 ? 3 : 4, fn_.params);  // df(x1) follows unless (fb >= fa && stepb > 0)
       fb = fn_.f(x1.data(), fn_.params);
       if (fb >= fa && stepb > 0.0) {
         // downhill step failed: reduce the step and try again
@@ -194,6 +201,7 @@ class FrcgMinimizer {
         else stepm = stepb - 0.38 * (stepb - stepa);
       }
       take_step(x, p, stepm, lambda, x1, dx1);
+      if (fn_.hint) fn_.hint(fb, 2, fn_.params);  // df(x1) follows iff fm <= fb
       fm = fn_.f(x1.data(), fn_.params);
       if (fm > fb) {
         if (fm < fv) { w = v; v = stepm; fw = fv; fv = fm; }

@@ -129,6 +129,7 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->accumulated = true;
   c->x_valid = true;
   c->jt_valid = false;
+  c->gated_pending = false;  // (a gated gradient pass still in flight belongs to the previous point: nobody will ask for it)
   return CMX_OK;
 }
 
@@ -150,9 +151,21 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
     return fail(c, CMX_ERR_STATE, "gradient requested but accumulate ran without it");
   int rc = bind_device(c);
   if (rc) return rc;
-  if (grad && c->last_adjoint) rc = run_adjoint(c, 3);
-  else if (!grad && speculative_jt_ok(c)) rc = run_adjoint(c, 3, /*phase=*/3);
-  else rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  if (grad && c->last_adjoint) {
+    bool served = false;
+    rc = collect_gated(c, 3, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
+    if (rc || served) return rc;
+    rc = run_adjoint(c, 3);
+  } else if (!grad && speculative_jt_ok(c)) {
+    rc = finish_cost_only_speculative(c, 3);
+    if (rc) return rc;
+    *contrast = c->h_result[0];
+    return CMX_OK;
+  } else {
+    c->gated_pending = false;
+    c->gate_mode = 0;
+    rc = run_image_and_finalize(c, grad ? 3 : 0, nullptr, nullptr);
+  }
   if (rc) return rc;
   rc = sync_and_collect(c, true);
   if (rc) return rc;

@@ -72,7 +72,17 @@ struct FinalizeArgs {
   // and stores zeros back, so that the buffer is all-zero between launches.  Null = the table (gpartials / gblocks)
   double *gacc;
   int gacc_stride;            // doubles per shard row (>= number of columns)
+  // gated gradient pass (cmx_hint_next_df): the finalize of a cost-only evaluation decides from its own cost f = -contrast
+  // whether the gradient pass queued behind it runs: *gate_out = (f < thr | f <= thr | !(f >= thr) | 1) for mode 1..4
+  int *gate_out;
+  double gate_thr;
+  int gate_mode;
 };
+// the condition of the gate, the same expression on the device (finalize) and on the host (which result to expect)
+static inline __host__ __device__ int gate_condition(double contrast, double thr, int mode) {
+  const double f = -contrast;
+  return mode == 1 ? (f < thr) : mode == 2 ? (f <= thr) : mode == 3 ? !(f >= thr) : 1;
+}
 // tail of the mapped result buffer (doubles / u64 bit patterns)
 constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nout) and result[kFallbackSlot], ^ ticket*kTicketMix
 constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
@@ -151,6 +161,7 @@ struct FeGatherArgs {
   const double *tb;        // optional, time order (sxy == null): per-event bearing (x, y) stream
   const float *cx, *cy;    // G^T 1 factors (W and H floats) when itilde holds G^T B (mu-free form); null: itilde = G^T(B-mu)
   int r;                   // blur radius (defines the border band where cx, cy differ from 1)
+  const int *gate;         // optional: the launch does nothing when *gate == 0 (gated gradient pass, FinalizeArgs::gate_out)
   TailArgs tail;           // finalize in the last-arriving workgroup (counters == null: separate finalize launch)
 };
 
@@ -167,6 +178,7 @@ struct BeGatherArgs {
   int deterministic;       // per-parameter block sums in a fixed order instead of LDS fp64 atomics
   const double *tb;        // optional: bearing (x, y) of every event in TIME order (16 B, z == 1): coalesced stream for the
                            // four-events-per-lane pass instead of four divergent bearing-table gathers per lane
+  const int *gate;         // optional: the launch does nothing when *gate == 0 (gated gradient pass, FinalizeArgs::gate_out)
   TailArgs tail;           // be_gather_batch / folded be_gather4: finalize in the last-arriving workgroup (counters == null: separate
                            // launch); tail.fin.gacc set without counters: accumulator rows only (sharded split evaluation)
   int fold;                // 1: fold the per-batch pass into be_gather4 when the launcher's conditions hold (be_gather_folds)

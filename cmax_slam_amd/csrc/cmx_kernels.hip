@@ -569,6 +569,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     }
     sm.outv[0] = c;
     sm.outv[1] = mu;
+    if (a.gate_out) *a.gate_out = gate_condition(c, a.gate_thr, a.gate_mode);  // read by the NEXT launch (kernel boundary)
     if (a.fallback) {
       sm.shfall = (double)fb_count;
       *a.fallback = 0u;
@@ -1370,6 +1371,7 @@ int fe_gather_blocks(int n) {
 }
 
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
+  if (g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
   __shared__ double red[4 * 6];
   __shared__ FinSmem fin_sm;
   const FeSplatArgs &a = g.ev;
@@ -1790,6 +1792,7 @@ template <int NF>
 __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
   __shared__ double shG[NF ? kMaxGradLDS : 1], shG2[NF ? kMaxGradLDS : 1];
   __shared__ FinSmem fin_sm;
+  if (g.gate && *g.gate == 0) return;  // gated gradient pass (see fe_gather_kernel)
   if (NF) {
     for (int j = threadIdx.x; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
     __syncthreads();

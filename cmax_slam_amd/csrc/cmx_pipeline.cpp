@@ -223,7 +223,7 @@ void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
 // Tail finalize (CMX_OPT_TAIL_FINALIZE): hand the finalize to the launch that is about to be issued.  Only the forms whose
 // inputs are per-workgroup partial tables of that very launch or results of earlier launches qualify (f.direct, no
 // reduce_partials pass in between).
-bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail) {
+bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail, bool gated) {
   tail.counters = nullptr;
   if (!c->tail_finalize || !c->d_tail_counters || !f.direct || f.measure == 2) return false;
   // back end, gradient evaluations: read as a 42-column x 196-row table by one 256-thread workgroup the tail is 1.5-2 us
@@ -240,8 +240,13 @@ bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail) {
     f.gacc = c->d_gacc;
     f.gacc_stride = kGaccStride;
   }
-  f.ticket = ++c->ticket_issued;
-  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  if (gated) {  // the gated pass reports to the second result block with its own ticket sequence
+    f.ticket = ++c->ticket2_issued;
+    c->ticket2_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  } else {
+    f.ticket = ++c->ticket_issued;
+    c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  }
   tail.counters = c->d_tail_counters;
   tail.fin = f;
   return true;
@@ -457,7 +462,10 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   const size_t np = (size_t)W * H;
   if (phase != 3 && use_fused_gather(c, phase)) return run_fused_gather(c);
   // image pass already done for these very planes (phase 2: by finish_begin; phase 0 after a speculative cost-only pass)
-  const bool have_image = phase == 2 || (phase == 0 && c->jt_valid);
+  // phase 4: the gated gradient pass queued behind a cost-only evaluation (phase 3) of the same point -- gather + tail finalize
+  // into the second result block, running only if that evaluation's finalize opens the gate (cmx_hint_next_df)
+  const bool have_image = phase == 2 || ((phase == 0 || phase == 4) && c->jt_valid);
+  if (phase == 4 && !have_image) return CMX_OK;
   float *jt_before = c->d_itilde;
   int rc = ensure(c, c->d_itilde, c->itilde_cap, np);
   if (rc) return rc;
@@ -518,7 +526,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   f.npix = (double)np;
   f.partials = c->d_partials;
   f.sums = c->d_sums;
-  f.result = result_ptr(c);
+  f.result = phase == 4 ? c->d_result2 : result_ptr(c);
   if (!have_image) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
     rc = maybe_tile_list(c, a, 2 * c->radius);
     if (rc) return rc;
@@ -539,7 +547,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   // reduce_gpartials launch.  Callers that all-reduce cmx_grad_ptr() themselves keep the 2P-double buffer.
   // (rank-invariant condition: every rank must issue the same collective, also one whose shard is empty)
   const bool acc_split = phase != 0 && c->shard_acc && !c->deterministic && c->d_gacc && 2 * P <= kGaccStride && P > 0;
-  if (phase == 0) {  // single call: finalize sums the gather kernel's block partials itself
+  if (phase == 0 || phase == 4) {  // single call: finalize sums the gather kernel's block partials itself
     f.gpartials = c->d_gpartials;
     f.gblocks = gb;
   } else if (acc_split) {
@@ -560,6 +568,11 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     f.gP = 0;
     f.gpartials = nullptr;
     f.gblocks = 0;
+    if (c->gate_arm) {  // this finalize decides whether the pass queued behind it runs
+      f.gate_out = c->d_gate;
+      f.gate_thr = c->gate_thr;
+      f.gate_mode = c->gate_mode;
+    }
   }
   bool image_tailed = false;
   if (!have_image) {
@@ -578,6 +591,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     return CMX_OK;
   }
   if (have_image && phase == 0) c->spec_hits++;
+  const bool gated = phase == 4;
   bool tailed = false;  // the gather launch carries the finalize
   {
     Span sp(c, CMX_T_GATHER, /*exact=*/true);
@@ -603,8 +617,14 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         g.tb = c->d_tb;
       }
       if (c->n_packed > 0) {
-        if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        if (phase == 0 || gated) tailed = arm_tail(c, f, g.tail, gated);
         else if (acc_split) g.tail.fin = f;  // (no counters: accumulators without the tail)
+        if (gated) {
+          if (!tailed) return CMX_OK;  // no tail available in this configuration: no gated pass (the df will run as usual)
+          g.gate = c->d_gate;
+          c->gated_pending = true;
+          c->gated_launches++;
+        }
         launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       } else {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
@@ -630,9 +650,15 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
         g.tb = c->d_tb;
       }
       if (c->n_packed > 0 && P > 0) {
-        if (phase == 0) tailed = arm_tail(c, f, g.tail);
+        if (phase == 0 || gated) tailed = arm_tail(c, f, g.tail, gated);
         else if (acc_split) g.tail.fin = f;  // (no counters: accumulators without the tail)
         g.fold = c->fold_batch ? 1 : 0;
+        if (gated) {  // only the one-kernel form can be gated
+          if (!tailed || !be_gather_folds(g)) return CMX_OK;
+          g.gate = c->d_gate;
+          c->gated_pending = true;
+          c->gated_launches++;
+        }
         if (be_gather_folds(g)) {  // one kernel: gather, per-batch pass and finalize
           launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), nullptr, nullptr);
         } else {
@@ -645,7 +671,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     }
     if (phase == 1 && !acc_split) launch_reduce_gpartials(c->d_gpartials, gb, 2 * P, c->d_gsum, c->stream);
   }
-  if (phase == 1) {
+  if (phase == 1 || gated) {
     HIP_TRY(c, hipGetLastError());
     return CMX_OK;
   }
@@ -654,29 +680,33 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   return CMX_OK;
 }
 
+// spin on a completion ticket in a mapped result block; true once a consistent snapshot carrying `want` has been read
+static bool spin_for_ticket(const double *h_block, unsigned long long want, int nout) {
+  const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(h_block);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool done = false;
+  for (unsigned spins = 0;; spins++) {
+    if (w[kTicketSlot] == want) {  // ticket seen: accept only a consistent snapshot of the results
+      unsigned long long x = w[kFallbackSlot];
+      for (int k = 0; k < nout; k++) x ^= w[k];
+      if ((x ^ (want * kTicketMix)) == w[kChecksumSlot]) { done = true; break; }
+    }
+    __builtin_ia32_pause();
+    if ((spins & 1023u) == 1023u &&
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+      break;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return done;
+}
+
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
   // ends_in_finalize: the last thing queued on the stream is an evaluation's finalize kernel.  Wait for it through
   // its completion ticket in mapped host memory (a few microseconds earlier than the runtime reports the stream idle);
   // anything slower than the spin budget, and every caller that queued copies or other kernels after the finalize,
   // takes the ordinary stream synchronisation.
   bool done = false;
-  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) {
-    const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result);
-    const unsigned long long want = c->ticket_issued;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; spins++) {
-      if (w[kTicketSlot] == want) {  // ticket seen: accept only a consistent snapshot of the results
-        unsigned long long x = w[kFallbackSlot];
-        for (int k = 0; k < c->ticket_nout; k++) x ^= w[k];
-        if ((x ^ (want * kTicketMix)) == w[kChecksumSlot]) { done = true; break; }
-      }
-      __builtin_ia32_pause();
-      if ((spins & 1023u) == 1023u &&
-          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
-        break;
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) done = spin_for_ticket(c->h_result, c->ticket_issued, c->ticket_nout);
   if (!done) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (ends_in_finalize && c->ticket_issued) {
@@ -710,6 +740,52 @@ bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad) {
   if (!want_grad || !c->reuse_image || !c->have_data || !c->accumulated || !c->x_valid) return false;
   if (!adjoint_ok(c) || c->accum_external) return false;
   return memcmp(x, c->last_x, sizeof(double) * (size_t)n) == 0;
+}
+
+// ---- gated gradient pass (cmx_hint_next_df).  The FR-CG line search asks for the gradient at the point of a cost-only
+// evaluation exactly when that evaluation's cost passes a test it knows beforehand (f < fa on the trial step, !(f >= fa)
+// in the bracketing loop, f <= fb in Brent's loop).  With the test handed over in front of the cost-only evaluation, its
+// finalize writes the outcome to d_gate and the gradient pass -- queued behind it right away, reporting to the second result
+// block -- runs or returns at once.  The df call that follows finds its result in flight instead of starting a launch:
+// one host-to-GPU turnaround (~6 us) less per accepted point.
+int finish_cost_only_speculative(cmx_ctx *c, int P) {
+  const bool want_gate = c->gated_df && c->gate_mode != 0 && !c->sharded() && !c->accum_external && c->ticket_wait;
+  c->gated_pending = false;
+  c->gate_arm = want_gate;
+  int rc = run_adjoint(c, P, /*phase=*/3);
+  c->gate_arm = false;
+  const int mode = c->gate_mode;
+  const double thr = c->gate_thr;
+  c->gate_mode = 0;  // the hint is for ONE evaluation
+  if (rc) return rc;
+  if (want_gate) {
+    rc = run_adjoint(c, P, /*phase=*/4);  // sets gated_pending when the pass could be queued
+    if (rc) return rc;
+  }
+  rc = sync_and_collect(c, true);  // waits for the cost-only finalize's ticket, not for the pass queued behind it
+  if (rc) { c->gated_pending = false; return rc; }
+  if (c->gated_pending) c->gated_fired = gate_condition(c->h_result[0], thr, mode) != 0;  // the device evaluated the same expression
+  return CMX_OK;
+}
+
+// gradient evaluation at the point of the last cost-only evaluation: served by the gated pass if one is in flight
+int collect_gated(cmx_ctx *c, int P, double *contrast, double *grad, bool *served) {
+  *served = false;
+  if (!c->gated_pending) return CMX_OK;
+  c->gated_pending = false;
+  if (!c->gated_fired) return CMX_OK;  // the gate stayed shut (the caller asks anyway): ordinary gradient pass
+  bool done = spin_for_ticket(c->h_result2, c->ticket2_issued, c->ticket2_nout);
+  if (!done) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (reinterpret_cast<const unsigned long long *>(c->h_result2)[kTicketSlot] != c->ticket2_issued)
+      return fail(c, CMX_ERR_HIP, "gated gradient pass ended without its finalize step");
+  }
+  *contrast = c->h_result2[0];
+  for (int k = 0; k < P; k++) grad[k] = c->h_result2[2 + k];
+  c->gated_hits++;
+  c->spec_hits++;
+  *served = true;
+  return CMX_OK;
 }
 
 // ---- three-phase finish for sharded adjoint evaluations: begin (image, adjoint blur, gather -> partial gradient

@@ -48,6 +48,10 @@ void contrast_df(const double *x, void *p, double *df) {
   double cost;
   contrast_fdf(x, p, &cost, df);
 }
+void contrast_hint(double thr, int mode, void *p) {  // the line search's acceptance test, handed to the evaluator
+  SolveState *s = static_cast<SolveState *>(p);
+  (void)cmx_hint_next_df(s->ctx, thr, mode);
+}
 
 // the driver loop shared by both ends (and by cmx_frcg_minimize for arbitrary functors)
 struct Counted {
@@ -69,12 +73,17 @@ void counted_fdf(const double *x, void *p, double *f, double *g) {
   c->n_df++;
   c->inner.fdf(x, c->inner.params, f, g);
 }
+void counted_hint(double thr, int mode, void *p) {
+  Counted *c = static_cast<Counted *>(p);
+  if (c->inner.hint) c->inner.hint(thr, mode, c->inner.params);
+}
 
 void drive(const cmx::FunctionFdf &user, double *x_inout, double initial_step_size, double tol, double epsabs_grad,
            double tolfun, int num_max_line_searches, bool extra_iterate, const int *err, cmx_solve_report *rep) {
   Counted cnt;
   cnt.inner = user;
   cmx::FunctionFdf fn{counted_f, counted_df, counted_fdf, user.n, &cnt};
+  fn.hint = counted_hint;
   const int n = (int)user.n;
   cmx::FrcgMinimizer solver;
   solver.set(fn, x_inout, initial_step_size, tol);  // "This call already evaluates the function"
@@ -121,6 +130,7 @@ int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double
   st.n = n;
   st.g.assign((size_t)(n > 0 ? n : 1), 0.0);
   cmx::FunctionFdf fn{contrast_f, contrast_df, contrast_fdf, (size_t)n, &st};
+  fn.hint = contrast_hint;
   drive(fn, x_inout, 0.1, tol, epsabs_grad, 1e-4, 50, extra_iterate, &st.err, rep);
   return st.err;
 }

@@ -80,7 +80,13 @@ class _Evaluator:
         s = np.zeros(16)
         self._ck(self._L.cmx_get_stats(self._ctx, _dp(s)))
         return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3]),
-                "reuse_hits": int(s[4]), "sharded_host_syncs": int(s[5]), "band_misses": int(s[6]), "band_rows": int(s[7]), "fused_evals": int(s[8]), "spec_images": int(s[9]), "spec_hits": int(s[10])}
+                "reuse_hits": int(s[4]), "sharded_host_syncs": int(s[5]), "band_misses": int(s[6]), "band_rows": int(s[7]), "fused_evals": int(s[8]), "spec_images": int(s[9]), "spec_hits": int(s[10]),
+                "gated_launches": int(s[11]), "gated_hits": int(s[12])}
+
+    def hint_next_df(self, threshold, mode):
+        """cmx_hint_next_df: the next cost-only evaluation's value f = -contrast decides (mode 1: f < threshold, 2: f <= threshold,
+        3: not f >= threshold, 4: always) whether the gradient pass is queued behind it."""
+        self._ck(self._L.cmx_hint_next_df(self._ctx, float(threshold), int(mode)))
 
     def set_fast_path(self):
         """The production configuration and the library's default: adjoint gradient + LDS-privatised splat (+ image

@@ -104,6 +104,7 @@ enum {
                              deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
                              inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
                              0: separate per-batch kernel */
+  CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
                              than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
@@ -139,6 +140,16 @@ int cmx_frontend_set_packet(cmx_ctx *ctx, int64_t n, const uint16_t *x, const ui
 /* local_contrast_fdf body: contrast (and d contrast / d omega if grad != NULL; grad == NULL is the cost-only
  * fast path used by local_contrast_f, src/frontend/local_optim_contrast_gsl.cpp:58-63). */
 int cmx_frontend_eval(cmx_ctx *ctx, const double omega[3], double *contrast, double *grad /* [3] or NULL */);
+
+/* Line-search hint (used by cmx_frontend_solve / cmx_backend_solve; available to any host whose line search knows its
+ * acceptance test in advance).  Call right before a COST-ONLY evaluation: `mode` says under which condition on that
+ * evaluation's value f = -contrast the gradient at the same point will be requested next -- 1: f < threshold (GSL
+ * conjugate_fr's trial step: fc < fa), 2: f <= threshold (Brent loop: fm <= fb), 3: !(f >= threshold) (bracketing loop),
+ * 4: always, 0: withdraw the hint.  The evaluator then queues the gradient pass behind the cost evaluation, gated on the
+ * device by the cost it has just computed; a following cmx_*_eval(same parameters, grad != NULL) finds its result in flight
+ * and saves one host-to-GPU turnaround (~6 us).  The hint holds for one evaluation; results never depend on it.
+ * Adjoint gradient with CMX_OPT_REUSE_IMAGE and CMX_OPT_TAIL_FINALIZE on, no communicator; ignored otherwise. */
+int cmx_hint_next_df(cmx_ctx *ctx, double threshold, int mode);
 
 /* m INDEPENDENT evaluations in one call: omegas = m x 3, contrasts = m, grads = m x 3 or NULL (cost-only).  The m launch
  * chains are queued back to back and the host waits once, so the per-evaluation host round trip (~3 us of ~42) and the
@@ -367,7 +378,7 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [9] = cost-only evaluations that ran
+ * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [11..15] reserved */
 int cmx_get_stats(cmx_ctx *ctx, double stats[16]);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
