@@ -93,6 +93,8 @@ SYMBOLS = {
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "cmx_frcg_minimize_hinted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "cmx_integrate_ang_vel": (C.c_int, [C.c_int, c_i64p, c_dp, C.c_int64, c_dp, c_i64p, c_dp, C.c_int, c_i64p, c_dp,
                                         C.POINTER(C.c_int)]),
     "cmx_num_ctrl_poses": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_double]),

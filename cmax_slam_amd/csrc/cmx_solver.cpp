@@ -160,4 +160,14 @@ int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, in
   return CMX_OK;
 }
 
+int cmx_frcg_minimize_hinted(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, cmx_hint_fn hint, void *params, int n, double *x,
+                             double step_size, double tol, double epsabs_grad, double tolfun, int max_iterations,
+                             cmx_solve_report *report) {
+  if (!f || !df || !fdf || n <= 0 || !x) return CMX_ERR_INVALID_ARG;
+  cmx::FunctionFdf fn{f, df, fdf, (size_t)n, params};
+  fn.hint = hint;
+  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, false, nullptr, report);
+  return CMX_OK;
+}
+
 }  // extern "C"

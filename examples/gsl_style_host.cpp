@@ -46,6 +46,11 @@ void local_contrast_df(const double *v, void *p, double *df) {
   double cost;
   local_contrast_fdf(v, p, &cost, df);
 }
+// not in GSL's gsl_multimin_function_fdf: the line search's acceptance test, forwarded to the evaluator so that the gradient
+// pass is queued (gated on the device) behind the cost evaluation it will follow ("Line-search hint")
+void local_contrast_hint(double threshold, int mode, void *p) {
+  cmx_hint_next_df(static_cast<Estimator *>(p)->cmx, threshold, mode);
+}
 
 template <typename T>
 bool read_vec(FILE *fp, std::vector<T> &v, size_t n) {
@@ -93,7 +98,8 @@ int main(int argc, char **argv) {
   local_contrast_fdf(w0, &est, &f0, g0);
   double w[3] = {0, 0, 0};  // ang_vel_ starts at 0 (ang_vel_estimator.cpp:26)
   cmx_solve_report rep;
-  rc = cmx_frcg_minimize(local_contrast_f, local_contrast_df, local_contrast_fdf, &est, 3, w, 0.1, 0.05, 1e-3, 1e-4, 50, &rep);
+  rc = cmx_frcg_minimize_hinted(local_contrast_f, local_contrast_df, local_contrast_fdf, local_contrast_hint, &est, 3, w, 0.1, 0.05,
+                                1e-3, 1e-4, 50, &rep);
   if (rc != CMX_OK || est.status != CMX_OK) {
     fprintf(stderr, "solve failed\n");
     return 1;

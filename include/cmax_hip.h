@@ -328,6 +328,13 @@ typedef void (*cmx_df_fn)(const double *x, void *params, double *g);
 typedef void (*cmx_fdf_fn)(const double *x, void *params, double *f, double *g);
 int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, int n, double *x, double step_size,
                       double tol, double epsabs_grad, double tolfun, int max_iterations, cmx_solve_report *report);
+/* the same with a fourth callback that receives, in front of every cost-only evaluation, the line search's acceptance test
+ * (threshold, mode: see cmx_hint_next_df) -- a host that keeps its own f / df / fdf bodies forwards it to cmx_hint_next_df
+ * and gets the gated gradient pass; hint == NULL is cmx_frcg_minimize */
+typedef void (*cmx_hint_fn)(double threshold, int mode, void *params);
+int cmx_frcg_minimize_hinted(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, cmx_hint_fn hint, void *params, int n, double *x,
+                             double step_size, double tol, double epsabs_grad, double tolfun, int max_iterations,
+                             cmx_solve_report *report);
 
 /* ------------------------------------------------------------------ control-pose initialisation (host C++) ---
  * what the back-end thread does between two window solves to turn the front end's
