@@ -284,7 +284,7 @@ int maybe_tile_list(cmx_ctx *c, ImgArgs &a, int reach) {
     if (c->d_tile_list) HIP_TRY(c, hipFree(c->d_tile_list));
     if (c->d_tile_count) HIP_TRY(c, hipFree(c->d_tile_count));
     c->d_tile_list = c->d_tile_count = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&c->d_tile_list, (size_t)a.nblk * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tile_list, (2 * (size_t)a.nblk + 8) * sizeof(unsigned)));  // list + dense scratch of the ordered form
     HIP_TRY(c, hipMalloc((void **)&c->d_tile_count, 2 * sizeof(unsigned)));
     HIP_TRY(c, hipMemsetAsync(c->d_tile_count, 0, 2 * sizeof(unsigned), c->stream));
     c->tile_list_cap = (size_t)a.nblk;
