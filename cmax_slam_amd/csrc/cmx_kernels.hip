@@ -697,18 +697,36 @@ __device__ __forceinline__ bool tail_arrive(const TailArgs &tl, int nblocks, int
 // Sharded large panoramas: first and last tile row that carries a flag in the (all-reduced) occupancy map, written to
 // mapped host memory for the NEXT evaluation's exchange, and whether any flagged row lies outside the band [lo, hi] the
 // host sized THIS evaluation's exchange for (cmx_comm.cpp).  One workgroup.
-__global__ __launch_bounds__(256) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out) {
+__global__ __launch_bounds__(1024) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out) {
   __shared__ int sh_lo, sh_hi;
   if (threadIdx.x == 0) { sh_lo = tiles_y; sh_hi = -1; }
   __syncthreads();
   int my_lo = tiles_y, my_hi = -1;
   const int n = tiles_x * tiles_y;
-  for (int t = threadIdx.x; t < n; t += 256)
-    if (flags[t]) {
-      const int row = t / tiles_x;
-      my_lo = min(my_lo, row);
-      my_hi = max(my_hi, row);
+  if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(flags) & 15) == 0) {  // 16 flags per load, every load of a thread in one round
+    for (int t = 16 * (int)threadIdx.x; t < n; t += 16 * 1024) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(flags + t);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (w[q]) {
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if ((w[q] >> (8 * b)) & 0xffu) {
+              const int row = (t + 4 * q + b) / tiles_x;
+              my_lo = min(my_lo, row);
+              my_hi = max(my_hi, row);
+            }
+        }
     }
+  } else {
+    for (int t = threadIdx.x; t < n; t += 1024)
+      if (flags[t]) {
+        const int row = t / tiles_x;
+        my_lo = min(my_lo, row);
+        my_hi = max(my_hi, row);
+      }
+  }
   if (my_hi >= 0) { atomicMin(&sh_lo, my_lo); atomicMax(&sh_hi, my_hi); }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -718,7 +736,7 @@ __global__ __launch_bounds__(256) void band_kernel(const unsigned char *flags, i
   }
 }
 void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s) {
-  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(256), 0, s, flags, tiles_x, tiles_y, lo, hi, out);
+  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(1024), 0, s, flags, tiles_x, tiles_y, lo, hi, out);
 }
 
 size_t image_lds_bytes(int r) {
