@@ -434,15 +434,22 @@ def cmax_solves(n_solves, ev, kind, _lib):
     start (front end: omega = 0; back end: zero increments on the perturbed knots), image reuse on as in production."""
     ev.set_option(_lib.OPT_REUSE_IMAGE, 1)
     iters = evals = 0
+    s0 = ev.stats()
     t0 = time.perf_counter()
     for _ in range(n_solves):
         x, rep = ev.setupProblemAndOptimize(np.zeros(3)) if kind == "frontend" else ev.setupProblemAndOptimize()
         iters += rep["iterations"]
         evals += rep["n_f"] + rep["n_df"]
     el = time.perf_counter() - t0
+    s1 = ev.stats()
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
     return {"iters_per_s": iters / el, "evals_per_s": evals / el, "solves": n_solves, "iters_per_solve": iters / n_solves,
-            "ms_per_solve": el / n_solves * 1e3, "final_cost": rep["final_cost"], "solution": [float(v) for v in x[:6]]}
+            "ms_per_solve": el / n_solves * 1e3, "final_cost": rep["final_cost"], "solution": [float(v) for v in x[:6]],
+            "evals_per_solve": evals / n_solves,
+            # gradient evaluations that found the resident image (df after f) / that found their result already in flight
+            # (the gradient pass gated on the device behind the cost-only evaluation, cmx_hint_next_df), per solve
+            "df_on_resident_image_per_solve": (s1["spec_hits"] - s0["spec_hits"]) / n_solves,
+            "df_served_in_flight_per_solve": (s1["gated_hits"] - s0["gated_hits"]) / n_solves}
 
 
 def host_cpu():
