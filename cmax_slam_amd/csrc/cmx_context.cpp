@@ -97,11 +97,17 @@ int upload_gt1(cmx_ctx *c) {
 
 // cv::GaussianBlur(Size(0,0), sigma) on CV_32F: ksize = cvRound(sigma*8+1)|1; fp64 kernel normalised, cast to fp32
 int setup_blur(cmx_ctx *c, double sigma) {
+  // same sigma as last time (the image size of a context never changes): taps, G^T 1 factors and operator tables are on the
+  // device already -- a packet / window no longer pays four to six synchronous table uploads
+  if (c->blur_sigma_built == sigma && sigma >= 0) return CMX_OK;
+  c->blur_sigma_built = -1.0;
   c->sigma = sigma;
   if (!(sigma > 0)) {
     c->radius = 0;
     c->taps[0] = 1.f;
-    return upload_gt1(c);
+    const int rc0 = upload_gt1(c);
+    if (!rc0) c->blur_sigma_built = sigma;
+    return rc0;
   }
   const int n = ((int)lrint(sigma * 4 * 2 + 1)) | 1;
   const int r = n / 2;
@@ -116,7 +122,9 @@ int setup_blur(cmx_ctx *c, double sigma) {
   sum = 1. / sum;
   for (int i = 0; i < n; i++) c->taps[i] = (float)(t[i] * sum);
   c->radius = r;
-  return upload_gt1(c);
+  const int rc1 = upload_gt1(c);
+  if (!rc1) c->blur_sigma_built = sigma;
+  return rc1;
 }
 
 // ---- timing helpers
@@ -231,6 +239,17 @@ int ensure_pinned_xy(cmx_ctx *c, size_t n) {
   return CMX_OK;
 }
 
+int ensure_pinned_dts(cmx_ctx *c, size_t n) {
+  if (n <= c->h_dts_cap && c->h_dts) return CMX_OK;
+  if (c->h_dts) HIP_TRY(c, hipHostFree(c->h_dts));
+  c->h_dts = nullptr;
+  c->h_dts_cap = 0;
+  const size_t cap = n + n / 4 + 256;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_dts, cap * sizeof(double), hipHostMallocDefault));
+  c->h_dts_cap = cap;
+  return CMX_OK;
+}
+
 // =============================================================================================== generic
 const char *cmx_version(void) { return "cmax-hip 0.1 (gfx950)"; }
 
@@ -306,6 +325,7 @@ void cmx_destroy(cmx_ctx *c) {
   if (!c->gsum_external) hipFree(c->d_gsum);
   if (c->h_result) hipHostFree(c->h_result);
   if (c->h_result2) hipHostFree(c->h_result2);
+  if (c->h_dts) hipHostFree(c->h_dts);
   hipFree(c->d_gate);
   if (c->h_many) hipHostFree(c->h_many);
   comm_release(c);

@@ -52,6 +52,9 @@ struct cmx_ctx {
   size_t xy_cap = 0;
   uint32_t *h_xy = nullptr;  // pinned staging for the packed events (host packing runs on several threads)
   size_t h_xy_cap = 0;
+  double *h_dts = nullptr;   // pinned staging for the per-batch dt table (uploaded asynchronously with the events)
+  size_t h_dts_cap = 0;
+  double blur_sigma_built = -1.0;  // sigma the blur taps / G^T 1 factors / operator tables on the device were built for (-1: none)
   int n_packed = 0, per_batch = 1, nb = 0;
   bool have_data = false;
 
@@ -266,6 +269,7 @@ int create_common(cmx_ctx **out, int kind, int device, int W, int H, const doubl
 int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
 int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
 int ensure_pinned_xy(cmx_ctx *c, size_t n);
+int ensure_pinned_dts(cmx_ctx *c, size_t n);
 
 // kernel_exact = true: the launcher attaches the two events to the kernel itself (hipExtLaunchKernelGGL start / stop:
 // the dispatch's own begin / end timestamps, what rocprofv3 reports); otherwise the events are recorded on the

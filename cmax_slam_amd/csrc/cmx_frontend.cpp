@@ -56,7 +56,9 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     });
     if (out_of_range.load()) return check_events(c, n, x, y, t_ns);  // locate and report the offender
   }
-  std::vector<double> dts((size_t)nb);
+  rc = ensure_pinned_dts(c, (size_t)nb);
+  if (rc) return rc;
+  double *dts = c->h_dts;  // pinned: uploaded asynchronously below (the synchronisation above protects its reuse)
   const double tref = time_to_sec(t_ref_ns);
   std::atomic<int> bad_batch(-1);
   parallel_ranges(nb, [&](int64_t b0, int64_t b1) {
@@ -68,7 +70,6 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     }
   }, /*serial_below=*/4096);
   if (bad_batch.load() >= 0) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", bad_batch.load());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   rc = ensure(c, c->d_xy, c->xy_cap, (size_t)n);
   if (rc) return rc;
   rc = ensure(c, c->d_batch_dt, c->batch_cap, (size_t)nb);
@@ -76,8 +77,9 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   if (n) {
     if (d_raw) HIP_TRY(c, hipMemcpyAsync(c->d_xy, d_raw, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     else HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpy(c->d_batch_dt, dts.data(), (size_t)nb * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // both uploads are stream-ordered in front of everything the evaluations launch; nobody waits for them here (the 4 MB of
+    // a 1M-event packet cross PCIe while the caller is already issuing the first evaluation)
+    HIP_TRY(c, hipMemcpyAsync(c->d_batch_dt, dts, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   c->n_packed = (int)n;
   c->per_batch = event_batch_size;
