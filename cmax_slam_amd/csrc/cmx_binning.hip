@@ -270,7 +270,7 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 constexpr int kRankSortMax = 4096;
 constexpr int kSentinelChunk = 256;  // == cmx_internal.hpp's bound in do_binning (max_chunks)
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start_g, int ntiles, int planes_per_tile, int tiles_x,
-                                                            int margin, int M, Chunk *chunks, int *count) {
+                                                            int margin, int M, Chunk *chunks, int *count, int *count_host) {
   __shared__ int wave_tot[16];
   __shared__ int base_sh;
   __shared__ int rem_sh[kRankSortMax];
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       int tot = 0;
       for (int w = 0; w < 16; w++) tot += wave_tot[w];
       *count = nfull_total + tot;
+      if (count_host) *count_host = nfull_total + tot;  // mapped host copy: read after a later kernel's completion ticket
     }
     return;
   }
@@ -417,12 +418,15 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       __syncthreads();
     }
   }
-  if (tid == 0) *count = base_sh;
+  if (tid == 0) {
+    *count = base_sh;
+    if (count_host) *count_host = base_sh;
+  }
 }
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, hipStream_t s) {
+                         int *count, int *count_host, hipStream_t s) {
   hipLaunchKernelGGL(build_chunks_kernel, dim3(1), dim3(1024), 0, s, tile_start, ntiles, planes_per_tile, tiles_x, margin, M,
-                     chunks, count);
+                     chunks, count, count_host);
 }
 
 // ---------------------------------------------------------------------------------------------- LDS splats

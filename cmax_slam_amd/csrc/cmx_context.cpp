@@ -283,6 +283,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_lut);
   hipFree(c->d_lut2);
   hipFree(c->d_nchunks);
+  if (c->h_nchunks) hipHostFree(c->h_nchunks);
   hipFree(c->d_batch_err);
   hipFree(c->d_xy);
   if (c->h_xy) hipHostFree(c->h_xy);

@@ -164,6 +164,7 @@ struct cmx_ctx {
   size_t chunks_cap = 0;
   int nchunks = 0;          // launch bound of the chunk table (its true length lives in d_nchunks)
   int *d_nchunks = nullptr;
+  int *h_nchunks = nullptr, *d_nchunks_host = nullptr;  // mapped host copy of the table's true length (written by build_chunks)
   bool nchunks_exact = false;  // nchunks has been replaced by the table's true length (read back after the first evaluation)
   unsigned *d_fallback = nullptr;
   int64_t rebin_count = 0;

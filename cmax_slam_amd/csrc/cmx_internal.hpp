@@ -295,7 +295,7 @@ int sobel_blocks(int W, int H);
 // back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
 // chunk table built on the device from the tile offsets (no host round trip): tile_start[ntiles+2] -> chunks, *count
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, hipStream_t s);
+                         int *count, int *count_host, hipStream_t s);
 void launch_be_batch_times(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns, int order, int K,
                            long long *bt, long long *err, hipStream_t s);
 void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,

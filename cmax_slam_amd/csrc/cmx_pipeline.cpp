@@ -95,6 +95,11 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   rc = ensure(c, c->d_chunks, c->chunks_cap, (size_t)max_chunks);
   if (rc) return rc;
   if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
+  if (!c->h_nchunks) {
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_nchunks, sizeof(int), hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_nchunks_host, c->h_nchunks, 0));
+  }
+  *c->h_nchunks = -1;  // (nothing is in flight that writes it: every binning is followed by a collected evaluation)
   if (n > 0) {
     if (counting) {
       // counting sort: keys + per-slice histograms, column prefixes, bin scan, scatter (cmx_binning.hip)
@@ -134,7 +139,8 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
     }
     // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
-    launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->stream);
+    launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->d_nchunks_host,
+                        c->stream);
     HIP_TRY(c, hipGetLastError());
     c->nchunks = max_chunks;
     c->nchunks_exact = false;
@@ -722,8 +728,11 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
     }
   }
   if (!c->nchunks_exact && c->bin_valid && c->d_nchunks) {  // once per binning: launch exactly the chunks that exist
-    int nch = 0;
-    if (hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
+    // the kernel that built the table also stored its length in mapped host memory; a kernel queued behind it has delivered
+    // its completion ticket by now, so that store has landed (no synchronous read-back: ~10 us per packet)
+    int nch = c->h_nchunks ? *reinterpret_cast<volatile int *>(c->h_nchunks) : -1;
+    if (nch < 0 && hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) nch = -1;
+    if (nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
     c->nchunks_exact = true;
   }
   if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[kFallbackSlot] / (double)c->n_packed;
