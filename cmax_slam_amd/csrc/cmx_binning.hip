@@ -264,8 +264,8 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 
 // Chunk table on the device: tile t owns the sorted events [tile_start[t], tile_start[t+1]); it is cut into chunks of at
 // most M events.  One workgroup.  Order of the table = order the workgroups start in = longest-processing-time first:
-// all full chunks, then the remainder chunks by falling size (exact rank sort in LDS for up to kRankSortMax tiles,
-// falling size classes beyond that) -- with an unsorted tail the back-end splat ran 68 us instead of 52.  Entry
+// all full chunks, then the remainder chunks by falling size (64 size classes) -- with an unsorted tail the back-end splat
+// ran 68 us instead of 52.  kRankSortMax: tile offsets up to that many are staged in LDS.  Entry
 // `ntiles` is the sentinel tile of events whose vote is not accepted under the binning parameters: no LDS window.
 constexpr int kRankSortMax = 4096;
 constexpr int kSentinelChunk = 256;  // == cmx_internal.hpp's bound in do_binning (max_chunks)
@@ -273,7 +273,6 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
                                                             int margin, int M, Chunk *chunks, int *count, int *count_host) {
   __shared__ int wave_tot[16];
   __shared__ int base_sh;
-  __shared__ int rem_sh[kRankSortMax];
   __shared__ int ts_sh[kRankSortMax + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = ntiles + 1;  // tiles including the sentinel
@@ -326,101 +325,39 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
     __syncthreads();
   }
   const int nfull_total = base_sh;
-  if (T <= kRankSortMax) {
-    // exact: remainders by falling size (ties: lower tile first) -- bitonic sort in LDS of (remainder << 12 | 4095 - tile)
-    // (a rank sort, every thread against every tile, cost 78 us at 2049 tiles; this is 78 barrier-separated stages)
-    // only tiles with a remainder take part: compact them first (order irrelevant, they are sorted next)
-    uint32_t *key_sh = reinterpret_cast<uint32_t *>(rem_sh);
-    __shared__ int nnz_sh;
-    if (tid == 0) nnz_sh = 0;
-    __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-      int len = tile_start[t + 1] - tile_start[t];
-      if (len < 0) len = 0;
-      const int rem = len % Mof(t);
-      if (rem) key_sh[atomicAdd(&nnz_sh, 1)] = ((uint32_t)rem << 12) | (uint32_t)(4095 - t);
-    }
-    __syncthreads();
-    const int nnz = nnz_sh;
-    int n2 = 64;
-    while (n2 < nnz) n2 <<= 1;
-    for (int t = nnz + tid; t < n2; t += 1024) key_sh[t] = 0u;
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < n2; i += 1024) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const uint32_t x = key_sh[i], y = key_sh[ixj];
-            const bool desc = (i & k) == 0;
-            if (desc ? (x < y) : (x > y)) { key_sh[i] = y; key_sh[ixj] = x; }
-          }
-        }
-        __syncthreads();
-      }
-    int nrem = 0;
-    for (int p = tid; p < n2; p += 1024) {
-      const uint32_t key = key_sh[p];
-      if (key == 0) continue;
-      const int t = 4095 - (int)(key & 4095u);
-      const int beg = tile_start[t], len = tile_start[t + 1] - beg;
-      chunks[nfull_total + p] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
-      nrem++;
-    }
-    // block-wide sum of nrem
-    int incl = nrem;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    __syncthreads();
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int w = 0; w < 16; w++) tot += wave_tot[w];
-      *count = nfull_total + tot;
-      if (count_host) *count_host = nfull_total + tot;  // mapped host copy: read after a later kernel's completion ticket
-    }
-    return;
+  // Remainder chunks (one per tile that has one) in FALLING SIZE order, so that the big ones start first: 64 size classes
+  // (class 0 = the largest sixty-fourth of a chunk), order inside a class arbitrary.  Two passes over the tiles -- count per
+  // class, exclusive scan of the 64 counts, place -- instead of an exact sort: the bitonic sort in LDS this replaces was 78
+  // barrier-separated stages (75 us of a window's first evaluation at 2049 tiles), the five-class form before it cost the
+  // back-end splat 3 us of load balance.  (Which chunk of a class comes first varies from run to run; every sum the splat
+  // makes is order-independent in CMX_OPT_DETERMINISTIC.)
+  __shared__ int ccount[64], cbase[64], cplace[64];
+  if (tid < 64) { ccount[tid] = 0; cplace[tid] = 0; }
+  __syncthreads();
+  auto class_of = [&](int rem, int m) { const int b = (int)(((long long)rem * 64) / m); return 63 - (b > 63 ? 63 : b); };
+  for (int t = tid; t < T; t += 1024) {
+    int len = tile_start[t + 1] - tile_start[t];
+    if (len < 0) len = 0;
+    const int rem = len % Mof(t);
+    if (rem) atomicAdd(&ccount[class_of(rem, Mof(t))], 1);
   }
-  // many tiles (large panoramas): falling size classes (> M/2, > M/4, > M/8, > M/16, rest)
-  for (int pass = 1; pass < 6; pass++) {
-    const int lo = pass == 5 ? 0 : (M >> pass);
-    const int hi = pass == 1 ? M : (M >> (pass - 1));
-    for (int t0 = 0; t0 < T; t0 += 1024) {
-      const int t = t0 + tid;
-      int beg = 0, len = 0, rem = 0;
-      if (t < T) {
-        beg = tile_start[t];
-        len = tile_start[t + 1] - beg;
-        if (len < 0) len = 0;
-        rem = len % Mof(t);
-      }
-      const int mine = (rem > lo && rem <= hi) ? 1 : 0;
-      int incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-      }
-      if (lane == 63) wave_tot[wave] = incl;
-      __syncthreads();
-      int off = base_sh + incl - mine, tot = 0;
-      for (int w = 0; w < 16; w++) {
-        if (w < wave) off += wave_tot[w];
-        tot += wave_tot[w];
-      }
-      if (mine) chunks[off] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
-      __syncthreads();
-      if (tid == 0) base_sh += tot;
-      __syncthreads();
-    }
-  }
+  __syncthreads();
   if (tid == 0) {
-    *count = base_sh;
-    if (count_host) *count_host = base_sh;
+    int run = 0;
+    for (int k = 0; k < 64; k++) { cbase[k] = run; run += ccount[k]; }
+    *count = nfull_total + run;
+    if (count_host) *count_host = nfull_total + run;
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const int beg = tile_start[t];
+    int len = tile_start[t + 1] - beg;
+    if (len < 0) len = 0;
+    const int rem = len % Mof(t);
+    if (rem) {
+      const int k = class_of(rem, Mof(t));
+      chunks[nfull_total + cbase[k] + atomicAdd(&cplace[k], 1)] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
+    }
   }
 }
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
