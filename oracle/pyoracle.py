@@ -80,6 +80,9 @@ def lib():
         L.orc_be_iwe.argtypes = [C.POINTER(BeCfg), C.POINTER(BeState), C.c_int64, c_u16p, c_u16p, c_i64p, c_dp, c_fp, c_fp]
         L.orc_be_eval.argtypes = [C.POINTER(BeCfg), C.POINTER(BeState), C.c_int64, c_u16p, c_u16p, c_i64p, c_dp, c_dp,
                                   c_dp, c_dp, c_fp]
+        L.orc_be_warp_batch.restype = C.c_int
+        L.orc_be_warp_batch.argtypes = [C.POINTER(BeCfg), C.POINTER(BeState), c_u16p, c_u16p, c_i64p, C.c_int64, C.c_int64,
+                                        c_dp, c_fp]
         L.orc_be_alpha.restype = C.c_double
         L.orc_be_alpha.argtypes = [c_fp, c_fp, C.c_int]
         L.orc_equirect_project.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_fp]
@@ -397,6 +400,27 @@ class Backend:
         if rc:
             raise ValueError("oracle back-end failed rc=%d" % rc)
         return (iwe, pl) if planes else iwe
+
+    def accumulate_raw(self, drotv, planes=False):
+        """The vote loop alone (event_pano_warper.cpp:173-196): zero IL_old / IL_new (+ the P derivative planes), warp
+        and accumulate THIS object's events batch by batch -- no cv::add, no alpha, no blur.  What one rank of a sharded
+        window holds before the exchange (tests/test_dist_gloo.py).  Returns (IL_old, IL_new, planes or None)."""
+        k = left_update(self.knots, drotv, self.num_fixed)
+        P = 3 * (self.K - self.num_fixed)
+        n = len(self.x)
+        self.IL_old[...] = 0
+        self.IL_new[...] = 0
+        pl = np.zeros((P, self.Hp, self.Wp), np.float32) if planes else None
+        beg = 0
+        while beg < n - 1:   # :188  a trailing single-event batch is skipped
+            end = beg + self.batch if n - beg > self.batch else n
+            rc = lib().orc_be_warp_batch(C.byref(self.cfg), C.byref(self.state), self.x.ctypes.data_as(c_u16p),
+                                         self.y.ctypes.data_as(c_u16p), self.t.ctypes.data_as(c_i64p), beg, end, _dp(k),
+                                         _fp(pl))
+            if rc:
+                raise ValueError("oracle back-end failed rc=%d" % rc)
+            beg += self.batch
+        return self.IL_old, self.IL_new, pl
 
     def eval(self, drotv, want_grad=True):
         d = _c(drotv, np.float64).reshape(-1)

@@ -152,6 +152,13 @@ def test_config3_full_size(hip, oracle):
     tot = be.get_plane(_lib.PLANE_IL_OLD).sum(dtype=np.float64) + be.get_plane(_lib.PLANE_IL_NEW).sum(dtype=np.float64)
     tot_ref = ref.IL_old.sum(dtype=np.float64) + ref.IL_new.sum(dtype=np.float64)
     assert abs(tot - tot_ref) < 1e-5 * len(w.x)
+    # ... and at non-zero increments: a point of a solve (small) and a large one on every free knot
+    for scale in (0.004, 0.05):
+        d = np.random.default_rng(int(scale * 1000)).normal(0, scale, w.P)
+        c_ref, g_ref = ref.eval(d)
+        c, g = be.eval(d)
+        assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL, (scale, c, c_ref)
+        assert rel_img(be.get_plane(_lib.PLANE_IL_OLD), ref.IL_old) < RTOL
 
 
 @pytest.mark.parametrize("order,K,nf,T", [(2, 16, 1, 0.75), (4, 16, 3, 0.65), (2, 17, 1, 0.8), (4, 24, 3, 1.05)])

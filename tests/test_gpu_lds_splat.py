@@ -117,3 +117,10 @@ def test_backend_config3_fast_path(hip, oracle):
     c, g = be.eval(d)
     assert rel_scalar(c, c_ref) < RTOL
     assert rel_vec(g, g_ref) < RTOL
+    # non-zero increments at full size: a point of a solve, then a large jump (re-sort of the tile order)
+    for scale in (0.004, 0.05):
+        d = np.random.default_rng(int(scale * 1000)).normal(0, scale, w.P)
+        c_ref, g_ref = ref.eval(d)
+        c, g = be.eval(d)
+        assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL, (scale, c, c_ref)
+        assert rel_scalar(be.eval(d, False)[0], c_ref) < RTOL
