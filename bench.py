@@ -78,6 +78,33 @@ def whole_eval_bytes_8d(kind, order, n_events, npix, P):
     return n_events * per_ev + (1 + P) * npix * 4 * 6
 
 
+def csrc_hash():
+    """sha256 over cmax_slam_amd/csrc (the sources libcmaxhip.so is built from); tools/pmc_to_json.py stamps the same hash into
+    profiles/pmc_traffic.json."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cmax_slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def load_pmc():
+    """(per-kernel PMC byte counts, note).  The counts are only reported for the build they were measured on: the file carries
+    the source hash of cmax_slam_amd/csrc at measurement time; on a mismatch `traffic` / `pmc_bytes` are null."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}, "profiles/pmc_traffic.json missing"
+    stamp = pmc.get("_stamp") or {}
+    if stamp.get("src_sha256") != csrc_hash():
+        return {}, ("profiles/pmc_traffic.json was measured on another build (source hash %s..., running %s...): not reported"
+                    % (str(stamp.get("src_sha256"))[:12], csrc_hash()[:12]))
+    return pmc, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (%s, git %s)" % (pmc.get("_source"), str(stamp.get("git_head"))[:12])
+
+
 # ---------------------------------------------------------------------------------------------- measurement core
 class Runner:
     """One evaluator + its exchange path; knows how to run an fdf / cost-only step at a given parameter vector."""
@@ -244,11 +271,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
         # batch there and the 48-byte per-batch partial sums never exist
         a_g, m_g = models["gather"]
         models["gather"] = (a_g + nb * 152, m_g - nb * 48 + nb * 152)
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except Exception:
-        pass
+    pmc, pmc_note = load_pmc()
     kernels = []
     for k in sorted(kernel_ms, key=lambda k: -kernel_ms[k]):
         if k == "comm":
@@ -276,7 +299,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
         "kernel_ms": kernel_ms,
         "kernels": kernels,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)), "traffic_note": pmc_note,
                      "model": "hbm-mandatory bytes per launch (coalesced per-event streams + one pass over each plane + one 4-byte "
                               "write per non-zero IWE pixel) / live kernel duration",
                      "bytes_per_launch": dom_mand, "avg_launch_ms": dms, "events_per_launch": int(n_local),
@@ -452,6 +475,121 @@ def cmax_solves(n_solves, ev, kind, _lib):
             "df_served_in_flight_per_solve": (s1["gated_hits"] - s0["gated_hits"]) / n_solves}
 
 
+def per_packet_pipeline(device, which, n_packets=8):
+    """The per-packet pipeline of the front end (reference: AngVelEstimator's loop, src/frontend/ang_vel_estimator.cpp:68-147:
+    a NEW packet every ~10 ms): hand-over, first evaluation (upload + destination-tile sort + streams), FR-CG solve.
+
+      which = "config2"  : 1M-event packets, 640x480, handed over from host arrays (cmx_frontend_set_packet);
+      which = "store60k" : 60 000-event packets, 240x180 (ecrot_synth), cut from the device-resident event store
+                           (cmx_events_push once, cmx_frontend_set_packet_from per packet).
+    sequential = one context, every packet pays its set-up in front of its solve.  pipelined = two contexts: while packet k
+    is being solved on one, a helper host thread hands packet k+1 to the other and calls cmx_frontend_prepare (upload, sort,
+    streams, chunk table queued on that context's own stream), so the GPU runs the set-up beside the solve."""
+    import queue
+    import threading
+    from cmax_slam_amd import _lib, evaluator, synth
+    if which == "config2":
+        base = [synth.config2(seed=synth.SEED0 + 2 + 17 * k) for k in range(3)]
+        packets = [base[k % 3] for k in range(n_packets)]
+        store = None
+        W, H, lut = base[0].W, base[0].H, base[0].lut
+        cam = (base[0].fx, base[0].fy, base[0].cx, base[0].cy)
+    else:
+        n_ev = 60_000
+        st = synth.event_stream(2.0e6, n_ev * n_packets / 2.0e6 + 1e-4, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=synth.SEED0 + 9)
+        W, H, lut, cam = st.W, st.H, st.lut, (st.fx, st.fy, st.cx, st.cy)
+        store = evaluator.EventStore(W, H, len(st.x) + 1024, device=device)
+        store.push(st.x, st.y, st.t_ns)
+        packets = []
+        for k in range(n_packets):
+            a, b = k * n_ev, (k + 1) * n_ev
+            packets.append((a, n_ev, int((st.t_ns[a] + st.t_ns[b - 1]) // 2)))
+
+    def hand_over(ev, pk):
+        if store is None:
+            ev.set_packet(pk.x, pk.y, pk.t_ns, pk.t_ref_ns, pk.fx, pk.fy, pk.cx, pk.cy, pk.batch, pk.sigma, _lib.VARIANCE)
+        else:
+            ev.set_packet_from(store, pk[0], pk[1], pk[2], *cam, 100, 1.0, _lib.VARIANCE)
+
+    evs = [evaluator.FrontendEvaluator(W, H, lut, device=device) for _ in range(2)]
+    x0 = np.zeros(3)
+    # ---- the parts, one context (every figure the mean over the packets after one untimed pass)
+    t_set = t_first = t_solve_fresh = t_solve_res = 0.0
+    iters = 0
+    for rep in range(2):
+        t_set = t_first = t_solve_fresh = t_solve_res = 0.0
+        iters = 0
+        for pk in packets:
+            t0 = time.perf_counter()
+            hand_over(evs[0], pk)
+            t1 = time.perf_counter()
+            evs[0].eval(x0, True)
+            t2 = time.perf_counter()
+            hand_over(evs[0], pk)        # a fresh packet again: the solve below pays the sort inside its first evaluation
+            t3 = time.perf_counter()
+            _, r = evs[0].setupProblemAndOptimize(x0)
+            t4 = time.perf_counter()
+            evs[0].setupProblemAndOptimize(x0)   # the same packet resident and sorted: the solve alone
+            t5 = time.perf_counter()
+            t_set += t1 - t0
+            t_first += t2 - t1
+            t_solve_fresh += t4 - t3
+            t_solve_res += t5 - t4
+            iters += r["iterations"]
+    n = len(packets)
+    set_ms, first_ms, fresh_ms, solve_ms = (t * 1e3 / n for t in (t_set, t_first, t_solve_fresh, t_solve_res))
+    seq_ms = set_ms + fresh_ms
+    # ---- pipelined: two contexts, a helper thread stages the next packet while this one is being solved
+    jobs = queue.Queue()
+
+    def helper():
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            ev, pk, hint, done = job
+            hand_over(ev, pk)
+            ev.prepare(hint)
+            done.set()
+    th = threading.Thread(target=helper, daemon=True)
+    th.start()
+    best = None
+    for rep in range(3):
+        d0 = threading.Event()
+        jobs.put((evs[0], packets[0], x0, d0))
+        d0.wait()
+        pend = None
+        last = x0
+        t0 = time.perf_counter()
+        for k in range(n):
+            if k + 1 < n:
+                pend = threading.Event()
+                jobs.put((evs[(k + 1) % 2], packets[k + 1], last, pend))
+            last, r = evs[k % 2].setupProblemAndOptimize(x0)
+            if k + 1 < n:
+                pend.wait()
+        el = (time.perf_counter() - t0) * 1e3 / n
+        best = el if best is None else min(best, el)
+    jobs.put(None)
+    th.join()
+    for e in evs:
+        e.close()
+    if store is not None:
+        store.close()
+    n_ev_pk = len(packets[0].x) if store is None else packets[0][1]
+    return {"packet": "%d events, %dx%d, %s" % (n_ev_pk, W, H, "host arrays (cmx_frontend_set_packet)" if store is None else
+                                               "cut from the device event store (cmx_frontend_set_packet_from)"),
+            "packets": n, "set_packet_ms": set_ms, "first_eval_ms": first_ms, "solve_ms": solve_ms,
+            "solve_incl_first_sort_ms": fresh_ms, "iters_per_solve": iters / n,
+            "sequential": {"ms_per_packet": seq_ms, "packets_per_s": 1e3 / seq_ms, "iters_per_s_incl_setup": iters / n / seq_ms * 1e3,
+                           "ratio_to_solve": seq_ms / solve_ms},
+            "pipelined": {"ms_per_packet": best, "packets_per_s": 1e3 / best, "iters_per_s_incl_setup": iters / n / best * 1e3,
+                          "ratio_to_solve": best / solve_ms,
+                          "how": "two contexts; a helper host thread hands packet k+1 over and calls cmx_frontend_prepare (upload, "
+                                 "tile sort, streams, chunk table on that context's stream) while packet k is solved"},
+            "note": "solves start at omega = 0 like `cmax`; solve_ms = the solve on a resident, already-sorted packet"}
+
+
 def host_cpu():
     try:
         for line in open("/proc/cpuinfo"):
@@ -536,7 +674,7 @@ def line(m, world, args, name, n_total, img, comm_used, mode_desc):
     out = {
         "metric": METRIC, "value": m["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 warp / f32 accumulate", "data": "synthetic",
+        "dtype": "f64 warp; votes in 64-bit 2^-30 fixed point (LDS) -> f32 planes; f32 blur (f64-accumulated adjoint operator); f64 moments and gradient sums", "data": "synthetic",
         "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)", "mode": mode_desc,
                    "parameters": "cycled through %d points of a recorded FR-CG solve" % m["trajectory_points"],
                    "parallelism": ("events sharded by contiguous batch range (time slab) x%d, all-reduce of the partial planes + partial "
@@ -565,6 +703,7 @@ def main():
     ap.add_argument("--comm", default="native", choices=["native", "torch"])
     ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-packet", action="store_true", help="N=1: skip the per-packet pipeline measurement")
     ap.add_argument("--no-backend", action="store_true", help="N=1: skip the nested config-3 leg")
     ap.add_argument("--no-config5", action="store_true", help="N>1: skip the nested config-5 leg")
     ap.add_argument("--no-parity", action="store_true", help="N>1: skip the parity check against one GPU")
@@ -607,6 +746,12 @@ def main():
             out = line(m, world, args, name, len(p.x), img, run.comm_used, mode_desc)
             if world == 1 and args.solves > 0:
                 out["cmax"] = cmax_solves(args.solves, ev, "frontend", _lib)
+            if world == 1 and not args.no_per_packet:
+                try:
+                    out["per_packet"] = {"config2": per_packet_pipeline(local_rank, "config2", 6),
+                                         "store60k": per_packet_pipeline(local_rank, "store60k", 16)}
+                except Exception as e:  # must not cost the headline line
+                    out["per_packet"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline("frontend", p, pts[len(pts) // 2], args.cpu_seconds)
         ev.close()

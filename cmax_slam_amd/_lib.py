@@ -41,6 +41,8 @@ SYMBOLS = {
     "cmx_frontend_set_packet": (C.c_int, [ctx_p, C.c_int64, c_u16p, c_u16p, c_i64p, C.c_int64, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.c_int, C.c_double, C.c_int]),
     "cmx_frontend_eval": (C.c_int, [ctx_p, c_dp, c_dp, c_dp]),
+    "cmx_frontend_prepare": (C.c_int, [ctx_p, c_dp]),
+    "cmx_backend_prepare": (C.c_int, [ctx_p, c_dp]),
     "cmx_frontend_eval_many": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
     "cmx_backend_eval_many": (C.c_int, [ctx_p, C.c_int, c_dp, c_dp, c_dp]),
     "cmx_hint_next_df": (C.c_int, [ctx_p, C.c_double, C.c_int]),
@@ -102,7 +104,8 @@ SYMBOLS = {
     "cmx_traj_incremental_update": (C.c_int, [C.c_int, c_dp, C.c_int, C.c_int, c_dp]),
     "cmx_traj_evaluate": (C.c_int, [C.c_int, C.c_int, c_dp, C.c_int64, C.c_int64, C.c_int64, c_dp]),
     "cmx_bearing_lut": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),
-    "cmx_get_stats": (C.c_int, [ctx_p, c_dp]),
+    "cmx_get_stats": (C.c_int, [ctx_p, c_dp, C.c_int]),
+    "cmx_abi_version": (C.c_int, []),
     "cmx_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "cmx_timing_get": (C.c_int, [ctx_p, c_dp, c_i64p]),
 }

@@ -206,15 +206,8 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
                             t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
 }
 
-static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
-  c->timing_tick++;  // see fe_accumulate
-  const size_t np = (size_t)c->Wp * c->Hp;
-  const int Kopt = c->K - c->num_fixed;
-  c->last_adjoint = want_grad && adjoint_ok(c);
-  const bool deriv = want_grad && !c->last_adjoint;
-  const int P = deriv ? 3 * Kopt : 0;
-  int rc = CMX_OK;
-  // knot_i <- exp(drot_i) * knot_i for the non-fixed knots (CopyAndIncrementalUpdate, trajectory.cpp:240-263)
+// knot_i <- exp(drot_i) * knot_i for the non-fixed knots (CopyAndIncrementalUpdate, trajectory.cpp:240-263)
+static void be_update_knots(cmx_ctx *c, const double *drotv) {
   for (int i = 0; i < c->K; i++) {
     Quat q = c->knots0[i];
     if (i >= c->num_fixed) {
@@ -223,6 +216,52 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     }
     c->h_spline->knots[i] = q;
   }
+}
+
+// the time-ordered bearing stream of the gradient gather (once per window)
+int be_ensure_time_bearings(cmx_ctx *c) {
+  if (c->tb_valid || !c->d_lut2 || c->n_packed <= 0) return CMX_OK;
+  int rc = ensure(c, c->d_tb, c->tb_cap, (size_t)2 * c->n_packed);
+  if (rc) return rc;
+  launch_bearing_stream(c->d_xy, c->d_lut2, c->W, c->n_packed, c->d_tb, c->stream);
+  c->tb_valid = true;
+  return CMX_OK;
+}
+
+// The back end's counterpart of cmx_frontend_prepare: pose table at `drotv_hint` (NULL = zero increments), destination-tile
+// sort, chunk table and the bearing streams of a window, queued behind its upload.  A host that owns two contexts prepares
+// window k+1 while window k is being solved (pose_graph_optimizer.cpp:244-376 is the loop this sits in).
+int cmx_backend_prepare(cmx_ctx *c, const double *drotv_hint) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (c->splat_mode != 1 || !adjoint_ok(c) || c->n_packed <= 0) return CMX_OK;
+  std::vector<double> zero((size_t)3 * (c->K - c->num_fixed > 0 ? c->K - c->num_fixed : 1), 0.0);
+  be_update_knots(c, drotv_hint ? drotv_hint : zero.data());
+  launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, false, c->d_poseR, c->d_poses, c->stream);
+  BeSplatArgs a = be_args(c);
+  rc = do_binning(c, nullptr, &a);
+  if (rc) return rc;
+  if (c->per_batch % 4 == 0) {
+    rc = be_ensure_time_bearings(c);
+    if (rc) return rc;
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->x_valid = false;  // (the pose table no longer belongs to the last evaluation's point)
+  c->jt_valid = false;
+  return CMX_OK;
+}
+
+static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
+  c->timing_tick++;  // see fe_accumulate
+  const size_t np = (size_t)c->Wp * c->Hp;
+  const int Kopt = c->K - c->num_fixed;
+  c->last_adjoint = want_grad && adjoint_ok(c);
+  const bool deriv = want_grad && !c->last_adjoint;
+  const int P = deriv ? 3 * Kopt : 0;
+  int rc = CMX_OK;
+  be_update_knots(c, drotv);
   {
     Span sp(c, CMX_T_POSE, /*exact=*/true);
     launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, want_grad || (adjoint_ok(c) && c->reuse_image), c->d_poseR, c->d_poses,
@@ -342,6 +381,7 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (rc) return rc;
   if (grad && c->last_adjoint) {
     bool served = false;
+    c->gate_mode = 0;  // a hint not consumed by a cost-only evaluation does not outlive the next evaluation of any kind
     rc = collect_gated(c, P, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
     if (rc || served) return rc;
     rc = run_adjoint(c, P);

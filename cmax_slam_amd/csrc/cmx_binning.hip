@@ -270,7 +270,8 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
 constexpr int kRankSortMax = 4096;
 constexpr int kSentinelChunk = 256;  // == cmx_internal.hpp's bound in do_binning (max_chunks)
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start_g, int ntiles, int planes_per_tile, int tiles_x,
-                                                            int margin, int M, Chunk *chunks, int *count, int *count_host) {
+                                                            int margin, int M, Chunk *chunks, int *count,
+                                                            unsigned long long *count_host, unsigned binning_id) {
   __shared__ int wave_tot[16];
   __shared__ int base_sh;
   __shared__ int ts_sh[kRankSortMax + 2];
@@ -346,7 +347,8 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
     int run = 0;
     for (int k = 0; k < 64; k++) { cbase[k] = run; run += ccount[k]; }
     *count = nfull_total + run;
-    if (count_host) *count_host = nfull_total + run;
+    // (binning id, count) as ONE 8-byte store: the host accepts the count only with the id of the binning it is waiting for
+    if (count_host) *count_host = ((unsigned long long)binning_id << 32) | (unsigned)(nfull_total + run);
   }
   __syncthreads();
   for (int t = tid; t < T; t += 1024) {
@@ -361,9 +363,9 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
   }
 }
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, int *count_host, hipStream_t s) {
+                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s) {
   hipLaunchKernelGGL(build_chunks_kernel, dim3(1), dim3(1024), 0, s, tile_start, ntiles, planes_per_tile, tiles_x, margin, M,
-                     chunks, count, count_host);
+                     chunks, count, count_host, binning_id);
 }
 
 // ---------------------------------------------------------------------------------------------- LDS splats

@@ -97,7 +97,7 @@ static int exchange_planes(cmx_ctx *c) {
   if (rc) return rc;
   int lo = c->band_lo, hi = c->band_hi;
   if (hi < lo) { lo = 0; hi = tiles_y - 1; }  // no band known yet (first evaluation of a window): the whole plane
-  launch_band(c->d_tflags, tiles_x, tiles_y, lo, hi, c->d_result + kBandSlot, c->stream);
+  launch_band(c->d_tflags, tiles_x, tiles_y, lo, hi, c->d_result + kBandSlot, ++c->band_seq, c->stream);
   HIP_TRY(c, hipGetLastError());
   rc = allreduce_rows(c, lo, hi + 1);
   if (rc) return rc;
@@ -138,6 +138,8 @@ static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad
 // evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
 int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double *grad) {
   int rc = CMX_OK;
+  c->gate_mode = 0;  // (no gated pass with a communicator attached: a hint must not outlive this evaluation)
+  c->gated_pending = false;
   if (exchange) {
     rc = exchange_planes(c);
     if (rc) return rc;
@@ -147,8 +149,25 @@ int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double
   // the results are on the host, and with them what band_kernel found (written by an earlier kernel of the same stream)
   c->band_pending = false;
   const int tiles_y = (c->Hp + kTileY - 1) / kTileY;
-  const int r0 = (int)c->h_result[kBandSlot], r1 = (int)c->h_result[kBandSlot + 1];
-  const bool miss = c->h_result[kBandSlot + 2] != 0.0;
+  // ... in an EARLIER kernel than the finalize whose ticket was waited for, outside its checksummed snapshot: the words carry
+  // their own stamp.  A rank that read a stale band would choose another exchange than its peers (a hang), so a snapshot
+  // that does not verify is re-read, then the stream is synchronised, and only then is it an error.
+  double bw[3] = {0, 0, 0};
+  bool band_ok = false;
+  for (int attempt = 0; attempt < 3 && !band_ok; attempt++) {
+    for (int spin = 0; spin < 20000 && !band_ok; spin++) {
+      const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result + kBandSlot);
+      const unsigned long long b0 = w[0], b1 = w[1], b2 = w[2], st = w[3];
+      if ((b0 ^ b1 ^ b2 ^ (c->band_seq * kTicketMix)) == st) {
+        memcpy(&bw[0], &b0, 8); memcpy(&bw[1], &b1, 8); memcpy(&bw[2], &b2, 8);
+        band_ok = true;
+      }
+    }
+    if (!band_ok) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (!band_ok) return fail(c, CMX_ERR_HIP, "the band kernel's result did not arrive (sequence %llu)", c->band_seq);
+  const int r0 = (int)bw[0], r1 = (int)bw[1];
+  const bool miss = bw[2] != 0.0;
   if (r1 >= r0) {
     c->band_lo = std::max(0, r0 - kBandMargin);
     c->band_hi = std::min(tiles_y - 1, r1 + kBandMargin);

@@ -40,6 +40,7 @@ double time_to_sec(long long t_ns) {  // ros::Time::toSec
 int upload_gt1(cmx_ctx *c) {
   const int r = c->radius;
   c->Mx_radius = -1;
+  int built_axes = 0;  // bit per axis whose banded operator was rebuilt for THIS radius
   for (int axis = 0; axis < 2; axis++) {
     const int L = axis == 0 ? c->imgW : c->imgH;
     if (L <= 0) continue;
@@ -89,9 +90,12 @@ int upload_gt1(cmx_ctx *c) {
       rc = ensure(c, dm, mcap, M.size());
       if (rc) return rc;
       HIP_TRY(c, hipMemcpy(dm, M.data(), M.size() * sizeof(float), hipMemcpyHostToDevice));
-      if (axis == 1) c->Mx_radius = r;  // both axes built
+      built_axes |= 1 << axis;
     }
   }
+  // the image kernels take the composite form only with BOTH tables of this radius: a tiny image (one side <= 4r) keeps
+  // the general passes instead of pairing a fresh table with a stale one of an earlier sigma
+  if (built_axes == 3) c->Mx_radius = r;
   return CMX_OK;
 }
 
@@ -403,9 +407,12 @@ int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
   return CMX_OK;
 }
 
-int cmx_get_stats(cmx_ctx *c, double stats[16]) {
-  if (!c || !stats) return CMX_ERR_INVALID_ARG;
-  for (int i = 0; i < 16; i++) stats[i] = 0;
+int cmx_abi_version(void) { return CMX_ABI_VERSION; }
+
+int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
+  if (!c || !out || n_stats < 0) return CMX_ERR_INVALID_ARG;
+  double stats[CMX_N_STATS];
+  for (int i = 0; i < CMX_N_STATS; i++) stats[i] = 0;
   stats[0] = (double)c->rebin_count;
   stats[1] = c->last_fallback_frac;
   {  // true length of the chunk table (device-resident until the first evaluation after a binning has been collected)
@@ -424,6 +431,7 @@ int cmx_get_stats(cmx_ctx *c, double stats[16]) {
   stats[10] = (double)c->spec_hits;
   stats[11] = (double)c->gated_launches;
   stats[12] = (double)c->gated_hits;
+  for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }
 

@@ -27,10 +27,10 @@ using namespace cmx;  // internal header of one library: the parameter blocks of
 
 enum { KIND_FE = 1, KIND_BE = 2 };
 constexpr long long kMaxPixels = 1LL << 29;  // per plane (sensor or panorama): pixel loops use 32-bit ints, up to 3 planes interleaved
-constexpr long long kMaxEvents = 1LL << 30;
+constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
 // Re-sort the events by destination tile once more than this share of the votes left their LDS windows: a vote on the
 // global-atomic path costs the 1M-event splat ~3.7 us per percent (9.5 % -> 44 us instead of 9.5), a re-sort ~60 us once
-constexpr double kRebinFallbackFrac = 0.03;  // kernels index events with 32-bit ints (grid-stride loops add up to 2^19)
+constexpr double kRebinFallbackFrac = 0.03;
 
 struct TimedSpan { int cls; hipEvent_t a, b; };
 typedef struct ncclComm *ncclComm_t;  // as <rccl/rccl.h> declares it; only cmx_comm.cpp includes that header
@@ -120,6 +120,7 @@ struct cmx_ctx {
   size_t gsum_cap = 0;
   bool gsum_external = false;
   bool finish_pending = false; // finish_begin ran, finish_end has not
+  bool acc_dirty = false;      // a split evaluation added to d_gacc and has not reached the finalize that zeroes it again
   int pending_P = 0;
   bool last_adjoint = false;  // the last accumulate() ran in adjoint mode with a gradient requested
   // back end: image-tile occupancy of the two ping-pong accumulation buffers and of IGp (see ImgArgs::flags_*)
@@ -164,7 +165,10 @@ struct cmx_ctx {
   size_t chunks_cap = 0;
   int nchunks = 0;          // launch bound of the chunk table (its true length lives in d_nchunks)
   int *d_nchunks = nullptr;
-  int *h_nchunks = nullptr, *d_nchunks_host = nullptr;  // mapped host copy of the table's true length (written by build_chunks)
+  // mapped host copy of the table's true length, written by build_chunks as (binning id << 32 | length): a count is only
+  // accepted with the id of the latest binning, so a stale store of an earlier, uncollected binning cannot be mistaken for it
+  unsigned long long *h_nchunks = nullptr, *d_nchunks_host = nullptr;
+  unsigned binning_id = 0;
   bool nchunks_exact = false;  // nchunks has been replaced by the table's true length (read back after the first evaluation)
   unsigned *d_fallback = nullptr;
   int64_t rebin_count = 0;
@@ -207,6 +211,7 @@ struct cmx_ctx {
   // row band of the sparse plane exchange (tile rows, inclusive); band_hi < band_lo: unknown -> whole plane
   int band_lo = 0, band_hi = -1;
   bool band_pending = false;       // the last evaluation ran the band kernel: its result waits in h_result[kBandSlot..]
+  unsigned long long band_seq = 0; // sequence number of that launch (stamped into the result, see kBandSlot)
   int band_used_lo = 0, band_used_hi = -1;  // what that evaluation actually exchanged (whole plane: 0 .. tiles_y-1)
   int64_t sharded_host_syncs = 0, band_misses = 0;
 
@@ -279,8 +284,8 @@ struct Span {
   cmx_ctx *c;
   TimedSpan s{};
   bool on, kernel_exact, used = false;
-  Span(cmx_ctx *ctx, int cls, bool exact = false)
-      : c(ctx), on(ctx->timing && ((ctx->timing_mask >> cls) & 1) && (ctx->timing_tick % ctx->timing_every) == 0),
+  Span(cmx_ctx *ctx, int cls, bool exact = false, bool enable = true)
+      : c(ctx), on(enable && ctx->timing && ((ctx->timing_mask >> cls) & 1) && (ctx->timing_tick % ctx->timing_every) == 0),
         kernel_exact(exact) {
     if (on) {
       s.cls = cls;
@@ -326,6 +331,7 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
 int finish_begin(cmx_ctx *c, int kind, int want_grad);
 int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
+int be_ensure_time_bearings(cmx_ctx *c);  // cmx_backend.cpp: the gather's time-ordered bearing stream (once per window)
 int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the first evaluation of a window
 
 // ---- cmx_comm.cpp

@@ -135,6 +135,27 @@ static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   return CMX_OK;
 }
 
+// Everything a packet's FIRST evaluation would do before its first vote -- the destination-tile sort at `omega_hint`, the
+// tile-ordered bearing / dt streams, the chunk table -- queued now, behind the packet's upload, without waiting for any of
+// it.  With two contexts a host prepares packet k+1 on one while packet k is being solved on the other: the GPU runs the
+// upload and the sort in the shadow of the solve (one context fills < 40 % of the chip), and the solve of packet k+1 starts
+// with its first evaluation at full speed.  The hint only decides which votes find their LDS window (speed); results do
+// not depend on it.  Reference counterpart: the work between getEventSubset and the first cost evaluation of
+// AngVelEstimator::handleEvents' optimisation (src/frontend/ang_vel_estimator.cpp:68-147), which the CPU path does not have.
+int cmx_frontend_prepare(cmx_ctx *c, const double omega_hint[3]) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
+  if (!omega_hint) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (c->splat_mode != 1 || !adjoint_ok(c) || c->n_packed <= 0) return CMX_OK;  // nothing this configuration sorts
+  FeSplatArgs a = fe_args(c, omega_hint);
+  rc = do_binning(c, &a, nullptr);
+  if (rc) return rc;
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
+}
+
 int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
@@ -155,6 +176,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (rc) return rc;
   if (grad && c->last_adjoint) {
     bool served = false;
+    c->gate_mode = 0;  // a hint not consumed by a cost-only evaluation does not outlive the next evaluation of any kind
     rc = collect_gated(c, 3, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
     if (rc || served) return rc;
     rc = run_adjoint(c, 3);

@@ -89,7 +89,8 @@ constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
 constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
 constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
 constexpr int kBandSlot = 4088;      // [0] first, [1] last flagged tile row of the all-reduced occupancy map, [2] = 1 if a flagged
-                                     // row lay outside the band this evaluation exchanged (sharded large panoramas)
+                                     // row lay outside the band this evaluation exchanged (sharded large panoramas), [3] = stamp:
+                                     // bits[0] ^ bits[1] ^ bits[2] ^ (launch sequence number * kTicketMix)
 constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
 
@@ -269,7 +270,7 @@ void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, 
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s);
+void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, unsigned long long seq, hipStream_t s);
 void launch_tile_flags_pair(const float *a, const float *b, int W, int H, unsigned char *flags, hipStream_t s);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);
@@ -295,7 +296,7 @@ int sobel_blocks(int W, int H);
 // back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
 // chunk table built on the device from the tile offsets (no host round trip): tile_start[ntiles+2] -> chunks, *count
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, int *count_host, hipStream_t s);
+                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s);
 void launch_be_batch_times(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns, int order, int K,
                            long long *bt, long long *err, hipStream_t s);
 void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,

@@ -697,7 +697,8 @@ __device__ __forceinline__ bool tail_arrive(const TailArgs &tl, int nblocks, int
 // Sharded large panoramas: first and last tile row that carries a flag in the (all-reduced) occupancy map, written to
 // mapped host memory for the NEXT evaluation's exchange, and whether any flagged row lies outside the band [lo, hi] the
 // host sized THIS evaluation's exchange for (cmx_comm.cpp).  One workgroup.
-__global__ __launch_bounds__(1024) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out) {
+__global__ __launch_bounds__(1024) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out,
+                                                    unsigned long long seq) {
   __shared__ int sh_lo, sh_hi;
   if (threadIdx.x == 0) { sh_lo = tiles_y; sh_hi = -1; }
   __syncthreads();
@@ -732,11 +733,17 @@ __global__ __launch_bounds__(1024) void band_kernel(const unsigned char *flags, 
   if (threadIdx.x == 0) {
     out[0] = (double)sh_lo;
     out[1] = (double)sh_hi;
-    out[2] = (sh_hi >= 0 && (sh_lo < lo || sh_hi > hi)) ? 1.0 : 0.0;
+    const double miss = (sh_hi >= 0 && (sh_lo < lo || sh_hi > hi)) ? 1.0 : 0.0;
+    out[2] = miss;
+    // the three words lie outside the finalize's checksummed snapshot: they carry their own stamp (sequence number of this
+    // launch mixed with their bit patterns), and the host accepts them only when the stamp matches what it read
+    reinterpret_cast<unsigned long long *>(out)[3] =
+        (unsigned long long)__double_as_longlong((double)sh_lo) ^ (unsigned long long)__double_as_longlong((double)sh_hi) ^
+        (unsigned long long)__double_as_longlong(miss) ^ (seq * kTicketMix);
   }
 }
-void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, hipStream_t s) {
-  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(1024), 0, s, flags, tiles_x, tiles_y, lo, hi, out);
+void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(1024), 0, s, flags, tiles_x, tiles_y, lo, hi, out, seq);
 }
 
 size_t image_lds_bytes(int r) {

@@ -6,6 +6,12 @@
 // c->d_accum is all-zero over `nplanes` planes and c->pingpong_planes tells the image pass to clear the partner.
 int begin_accum(cmx_ctx *c, int nplanes, size_t np, bool fast) {
   c->pingpong_planes = 0;
+  if (c->acc_dirty) {  // a split evaluation added to the accumulator rows and never reached its finalize (an error between the
+                       // two phases): every later gradient would carry those sums -- the buffers are all-zero between launches
+    if (c->d_gacc) HIP_TRY(c, hipMemsetAsync(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double), c->stream));
+    if (c->d_tail_counters) HIP_TRY(c, hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream));
+    c->acc_dirty = false;
+  }
   const size_t need = (size_t)nplanes * np;
   if (fast && !c->accum_external) {
     float *before = c->d_accum;
@@ -96,10 +102,12 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   if (rc) return rc;
   if (!c->d_nchunks) HIP_TRY(c, hipMalloc((void **)&c->d_nchunks, sizeof(int)));
   if (!c->h_nchunks) {
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_nchunks, sizeof(int), hipHostMallocMapped));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_nchunks, sizeof(unsigned long long), hipHostMallocMapped));
+    *c->h_nchunks = 0ull;
     HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_nchunks_host, c->h_nchunks, 0));
   }
-  *c->h_nchunks = -1;  // (nothing is in flight that writes it: every binning is followed by a collected evaluation)
+  c->binning_id++;  // a build_chunks of an earlier binning that was never collected may still store its (id, count): ignored
+  if (c->binning_id == 0) c->binning_id = 1;
   if (n > 0) {
     if (counting) {
       // counting sort: keys + per-slice histograms, column prefixes, bin scan, scatter (cmx_binning.hip)
@@ -140,7 +148,7 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
     }
     // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
     launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->d_nchunks_host,
-                        c->stream);
+                        c->binning_id, c->stream);
     HIP_TRY(c, hipGetLastError());
     c->nchunks = max_chunks;
     c->nchunks_exact = false;
@@ -568,8 +576,10 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   if (phase == 2) {
     issue_finalize(c, f, false);
     HIP_TRY(c, hipGetLastError());
+    c->acc_dirty = false;  // that finalize stores the zeros back
     return CMX_OK;
   }
+  if (phase == 1 && acc_split) c->acc_dirty = true;  // until phase 2's finalize has been queued (see begin_accum)
   if (phase == 3) {
     f.gP = 0;
     f.gpartials = nullptr;
@@ -600,7 +610,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   const bool gated = phase == 4;
   bool tailed = false;  // the gather launch carries the finalize
   {
-    Span sp(c, CMX_T_GATHER, /*exact=*/true);
+    // (a gated launch may return on its first instruction: it is not a sample of the gather's duration)
+    Span sp(c, CMX_T_GATHER, /*exact=*/true, /*enable=*/!gated);
     if (c->kind == KIND_FE) {
       FeGatherArgs g{};
       g.ev = fe_args(c, c->last_x);
@@ -647,12 +658,8 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       g.slice_shift = slice_shift;
       g.deterministic = c->deterministic ? 1 : 0;
       if (c->d_lut2 && slice_shift == 8 && c->n_packed > 0) {  // once per window: the events' bearings in time order
-        if (!c->tb_valid) {
-          int rc2 = ensure(c, c->d_tb, c->tb_cap, (size_t)2 * c->n_packed);
-          if (rc2) return rc2;
-          launch_bearing_stream(c->d_xy, c->d_lut2, c->W, c->n_packed, c->d_tb, c->stream);
-          c->tb_valid = true;
-        }
+        const int rc2 = be_ensure_time_bearings(c);
+        if (rc2) return rc2;
         g.tb = c->d_tb;
       }
       if (c->n_packed > 0 && P > 0) {
@@ -730,7 +737,11 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
   if (!c->nchunks_exact && c->bin_valid && c->d_nchunks) {  // once per binning: launch exactly the chunks that exist
     // the kernel that built the table also stored its length in mapped host memory; a kernel queued behind it has delivered
     // its completion ticket by now, so that store has landed (no synchronous read-back: ~10 us per packet)
-    int nch = c->h_nchunks ? *reinterpret_cast<volatile int *>(c->h_nchunks) : -1;
+    int nch = -1;
+    if (c->h_nchunks) {
+      const unsigned long long w = *reinterpret_cast<volatile unsigned long long *>(c->h_nchunks);
+      if ((unsigned)(w >> 32) == c->binning_id) nch = (int)(unsigned)(w & 0xffffffffull);
+    }
     if (nch < 0 && hipMemcpy(&nch, c->d_nchunks, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) nch = -1;
     if (nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
     c->nchunks_exact = true;
@@ -882,6 +893,8 @@ static int eval_many(cmx_ctx *c, int kind, int m, const double *xs, double *cont
   }
   const int reuse = c->reuse_image;
   c->reuse_image = 0;  // every evaluation of the list is a full one; no speculative work for a follow-up call
+  c->gate_mode = 0;    // (a hint belongs to the ONE cost-only evaluation it was given for)
+  c->gated_pending = false;
   for (int i = 0; i < m && rc == CMX_OK; i++) {
     const double *x = xs + (size_t)i * n;
     rc = kind == KIND_FE ? cmx_frontend_accumulate(c, x, grads != nullptr) : cmx_backend_accumulate(c, x, grads != nullptr);

@@ -78,7 +78,7 @@ class _Evaluator:
 
     def stats(self):
         s = np.zeros(16)
-        self._ck(self._L.cmx_get_stats(self._ctx, _dp(s)))
+        self._ck(self._L.cmx_get_stats(self._ctx, _dp(s), 16))
         return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3]),
                 "reuse_hits": int(s[4]), "sharded_host_syncs": int(s[5]), "band_misses": int(s[6]), "band_rows": int(s[7]), "fused_evals": int(s[8]), "spec_images": int(s[9]), "spec_hits": int(s[10]),
                 "gated_launches": int(s[11]), "gated_hits": int(s[12])}
@@ -283,6 +283,12 @@ class FrontendEvaluator(_Evaluator):
                                                       float(blur_sigma), int(contrast_measure)))
         self.n_events = int(count)
 
+    def prepare(self, ang_vel_hint=(0.0, 0.0, 0.0)):
+        """cmx_frontend_prepare: queue the packet's tile sort / streams / chunk table now (non-blocking); results never depend on
+        the hint."""
+        h = np.ascontiguousarray(ang_vel_hint, dtype=np.float64)
+        self._ck(self._L.cmx_frontend_prepare(self._ctx, _dp(h)))
+
     def eval(self, ang_vel, want_grad=True):
         """(contrast, gradient[3] | None) -- what computeContrast returns."""
         self._io_buffers(3)
@@ -376,6 +382,11 @@ class BackendEvaluator(_Evaluator):
             int(contrast_measure),
             C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
         self.K, self.num_fixed = k.shape[0], int(num_fixed)
+
+    def prepare(self, drotv_hint=None):
+        """cmx_backend_prepare: pose table at the hint, tile sort, chunk table and bearing streams of the window, queued now."""
+        h = None if drotv_hint is None else np.ascontiguousarray(drotv_hint, dtype=np.float64)
+        self._ck(self._L.cmx_backend_prepare(self._ctx, _dp(h) if h is not None else None))
 
     def eval(self, drotv, want_grad=True):
         P = self.num_params

@@ -137,6 +137,14 @@ int cmx_frontend_set_packet(cmx_ctx *ctx, int64_t n, const uint16_t *x, const ui
                             int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
                             double blur_sigma, int contrast_measure);
 
+/* Packet pipeline (no reference counterpart: the CPU path has no set-up to hide).  Queues everything the packet's first
+ * evaluation would otherwise do before its first vote -- destination-tile sort at omega_hint, tile-ordered bearing / dt
+ * streams, chunk table -- behind the upload of cmx_frontend_set_packet[_from], and returns without waiting.  A host with
+ * two contexts calls set_packet + prepare for packet k+1 on one of them BEFORE it solves packet k on the other; the GPU
+ * then runs upload and sort beside the solve.  omega_hint: any estimate of the solve's
+ * starting point (the previous packet's result); it affects speed only, never results. */
+int cmx_frontend_prepare(cmx_ctx *ctx, const double omega_hint[3]);
+
 /* local_contrast_fdf body: contrast (and d contrast / d omega if grad != NULL; grad == NULL is the cost-only
  * fast path used by local_contrast_f, src/frontend/local_optim_contrast_gsl.cpp:58-63). */
 int cmx_frontend_eval(cmx_ctx *ctx, const double omega[3], double *contrast, double *grad /* [3] or NULL */);
@@ -187,6 +195,10 @@ int cmx_backend_set_window(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uin
                            int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
                            int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
                            double blur_sigma, int contrast_measure, const float *IG);
+
+/* Window pipeline: the back end's counterpart of cmx_frontend_prepare -- pose table at drotv_hint (NULL = zero increments),
+ * destination-tile sort, chunk table and bearing streams of the window handed over last, queued without waiting. */
+int cmx_backend_prepare(cmx_ctx *ctx, const double *drotv_hint /* [3*(K-num_fixed)] or NULL */);
 
 /* global_contrast_fdf body: drotv = 3*(K-num_fixed) incremental rotation vectors applied by LEFT
  * multiplication to the non-fixed knots (trajectory.cpp:236 / :497); grad has the same length or is NULL. */
@@ -387,7 +399,12 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
  * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [11..15] reserved */
-int cmx_get_stats(cmx_ctx *ctx, double stats[16]);
+#define CMX_N_STATS 16
+int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
+/* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes
+ * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added) */
+#define CMX_ABI_VERSION 3
+int cmx_abi_version(void);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);
 

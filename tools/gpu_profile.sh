@@ -6,12 +6,18 @@ TAG=${1:-r01}; shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# what is being measured: source hash of cmax_slam_amd/csrc + hash of the library, read back by tools/pmc_to_json.py
+python -c "import sys; sys.path.insert(0, '$REPO'); import bench, hashlib; print(bench.csrc_hash()); print(hashlib.sha256(open('$REPO/cmax_slam_amd/libcmaxhip.so','rb').read()).hexdigest())" > $OUT/stamp.txt
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-per-packet $*"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o pmc -- $BENCH > $OUT/pmc_tcc.log 2>&1
+# FETCH_SIZE calibration on known byte counts in the kernels' own access widths (tools/microbench/fetch_calib.hip)
+if [ -x $REPO/tools/microbench/fetch_calib ]; then
+  timeout 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_calib -o pmc -- $REPO/tools/microbench/fetch_calib > $OUT/pmc_calib.log 2>&1
+fi
 cd $REPO
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

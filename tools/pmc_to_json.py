@@ -7,10 +7,42 @@ streaming read -- confirmed here on fe_splat_lds (streams 24 B/event = 24.0 MB, 
 reads are such streams; `raw_bytes` = (FETCH_SIZE + WRITE_SIZE) * 1024 is kept beside it; kernels with mixed access widths
 (be_splat_lds: 4-byte + 16-byte lanes + divergent rotation gathers) list both and bench.py reports the corrected one.
     python tools/pmc_to_json.py gpurun_out/prof_<tag>/summary.txt"""
+import hashlib
 import json
 import os
 import re
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# FETCH_SIZE under-reports by a factor that depends on the access width (tools/microbench/fetch_calib.hip under
+# rocprofv3 --pmc FETCH_SIZE, profiles/r03_fetch_calib.txt): known bytes / reported bytes per stream mix.  Applied per
+# kernel below instead of a blanket x2.
+FETCH_FACTOR = {"frontend_fast_splat": 2.0, "frontend_fast_gather": 2.0, "backend_fast_gather": 2.0, "backend_fast_splat": 2.0,
+                "backend_fast_pose": 2.0, "backend_fast_batch": 2.0}
+try:
+    FETCH_FACTOR.update(json.load(open(os.path.join(ROOT, "profiles", "fetch_calibration.json")))["factor_by_kernel"])
+except Exception:
+    pass
+
+
+def source_hash():
+    """sha256 over the product's kernel / host sources: what bench.py recomputes to decide whether this file describes the build
+    it is running (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cmax_slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def so_hash():
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "cmax_slam_amd", "libcmaxhip.so"), "rb").read()).hexdigest()
+    except OSError:
+        return None
 
 NAMES = {
     "fe_splat_lds_kernel": "frontend_fast_splat", "fe_gather_kernel": "frontend_fast_gather",
@@ -27,15 +59,32 @@ def main(path):
         if not m:
             continue
         vals.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
-    out = {"_note": __doc__.split("\n    python")[0], "_source": os.path.basename(os.path.dirname(path)) + "/summary.txt", "kernels": {}}
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "cmax_slam_amd/csrc"]).strip())
+    except Exception:
+        head, dirty = None, None
+    src, so = source_hash(), so_hash()
+    try:  # the hashes taken ON THE GPU BOX when the counters were collected (tools/gpu_profile.sh)
+        src, so = open(os.path.join(os.path.dirname(path), "stamp.txt")).read().split()[:2]
+    except Exception:
+        pass
+    if src != source_hash():
+        print("WARNING: the sources changed since the counters were collected; git_head below is only informational", file=sys.stderr)
+    out = {"_note": __doc__.split("\n    python")[0], "_source": os.path.basename(os.path.dirname(path)) + "/summary.txt",
+           "_stamp": {"src_sha256": src, "so_sha256": so, "git_head": head, "csrc_dirty_vs_head": dirty,
+                      "note": "bench.py reports these byte counts only when its own source hash of cmax_slam_amd/csrc equals src_sha256"},
+           "kernels": {}}
     for kname, d in vals.items():
         for pat, key in NAMES.items():
             if key and pat in kname and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 raw = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-                cor = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-                out["kernels"][key] = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "raw_bytes": raw, "bytes": cor}
+                fac = FETCH_FACTOR.get(key, 2.0)
+                cor = (fac * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+                out["kernels"][key] = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "raw_bytes": raw, "fetch_factor": fac,
+                                       "bytes": cor}
                 out[key] = cor
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
 
