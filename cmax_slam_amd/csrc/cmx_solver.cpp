@@ -2,14 +2,14 @@
 // cmx_frontend_solve / cmx_backend_solve).  Restates
 //   AngVelEstimator::setupProblemAndOptimize_gsl      src/frontend/local_optim_contrast_gsl.cpp:74-233
 //   PoseGraphOptimizer::setupProblemAndOptimize_gsl   src/backend/global_optim_contrast_gsl.cpp:15-145
-// around cmx::FrcgMinimizer (restated GSL conjugate_fr, cmx_frcg.hpp).  The cost functors below are exactly the
+// around the FR-CG state machine (restated GSL conjugate_fr + the loops above, cmx_frcg_sm.hpp).  The cost functors below are exactly the
 // bodies INTEGRATION.md gives for local_contrast_{f,df,fdf} / global_contrast_{f,df,fdf}.
 #include <math.h>
 
 #include <vector>
 
 #include "../../include/cmax_hip.h"
-#include "cmx_frcg.hpp"
+#include "cmx_frcg_sm.hpp"
 
 namespace {
 
@@ -53,77 +53,32 @@ void contrast_hint(double thr, int mode, void *p) {  // the line search's accept
   (void)cmx_hint_next_df(s->ctx, thr, mode);
 }
 
-// the driver loop shared by both ends (and by cmx_frcg_minimize for arbitrary functors)
-struct Counted {
-  cmx::FunctionFdf inner;
-  int n_f = 0, n_df = 0;
-};
-double counted_f(const double *x, void *p) {
-  Counted *c = static_cast<Counted *>(p);
-  c->n_f++;
-  return c->inner.f(x, c->inner.params);
-}
-void counted_df(const double *x, void *p, double *g) {
-  Counted *c = static_cast<Counted *>(p);
-  c->n_df++;
-  c->inner.df(x, c->inner.params, g);
-}
-void counted_fdf(const double *x, void *p, double *f, double *g) {
-  Counted *c = static_cast<Counted *>(p);
-  c->n_df++;
-  c->inner.fdf(x, c->inner.params, f, g);
-}
-void counted_hint(double thr, int mode, void *p) {
-  Counted *c = static_cast<Counted *>(p);
-  if (c->inner.hint) c->inner.hint(thr, mode, c->inner.params);
-}
-
+// the driver loop shared by both ends (and by cmx_frcg_minimize for arbitrary functors): the state machine of cmx_frcg_sm.hpp
+// fed from the callbacks, one request at a time
 void drive(const cmx::FunctionFdf &user, double *x_inout, double initial_step_size, double tol, double epsabs_grad,
-           double tolfun, int num_max_line_searches, bool extra_iterate, const int *err, cmx_solve_report *rep) {
-  Counted cnt;
-  cnt.inner = user;
-  cmx::FunctionFdf fn{counted_f, counted_df, counted_fdf, user.n, &cnt};
-  fn.hint = counted_hint;
+           double tolfun, int num_max_line_searches, const int *err, cmx_solve_report *rep) {
   const int n = (int)user.n;
-  cmx::FrcgMinimizer solver;
-  solver.set(fn, x_inout, initial_step_size, tol);  // "This call already evaluates the function"
-  const double initial_cost = solver.f;
-  double cost_new = 1e9, cost_old = 1e9;
-  int status = cmx::FRCG_CONTINUE;
-  int iter = 0;
-  if (!err || *err == CMX_OK) {
-    do {
-      iter++;
-      cost_old = cost_new;
-      status = solver.iterate();
-      if (err && *err != CMX_OK) break;
-      if (status == cmx::FRCG_SUCCESS) {
-        // convergence due to stagnation in the value of the function
-        cost_new = solver.f;
-        if (fabs(1 - cost_new / (cost_old + 1e-7)) < tolfun) break;
-        status = cmx::FRCG_CONTINUE;
-      }
-      // convergence due to the absolute norm of the gradient (gsl_multimin_test_gradient)
-      if (cmx::FrcgMinimizer::nrm2(solver.gradient) < epsabs_grad) break;
-      if (status != cmx::FRCG_CONTINUE) break;  // the iteration did not reduce the function value
-    } while (status == cmx::FRCG_CONTINUE && iter < num_max_line_searches);
-  }
-  for (int i = 0; i < n; i++) x_inout[i] = solver.x[i];
-  const double final_cost = solver.f;
-  const int n_f = cnt.n_f, n_df = cnt.n_df;
-  if (extra_iterate && (!err || *err == CMX_OK)) solver.iterate();  // local_optim_contrast_gsl.cpp:225 (result unused)
+  std::vector<double> store((size_t)9 * n, 0.0), g((size_t)n, 0.0);
+  cmx::FrcgSM s{};
+  double *v = store.data();
+  s.x = v; s.gradient = v + n; s.dx = v + 2 * n; s.x1 = v + 3 * n; s.dx1 = v + 4 * n; s.x2 = v + 5 * n; s.dx2 = v + 6 * n;
+  s.p = v + 7 * n; s.g0 = v + 8 * n;
+  for (int i = 0; i < n; i++) s.x[i] = x_inout[i];
+  cmx::sm_begin(s, n, initial_step_size, tol, epsabs_grad, tolfun, num_max_line_searches);
+  cmx::sm_step_host(s, user, g.data());  // gsl_multimin_fdfminimizer_set: "This call already evaluates the function"
+  while (!cmx::sm_done(s) && (!err || *err == CMX_OK)) cmx::sm_step_host(s, user, g.data());
+  for (int i = 0; i < n; i++) x_inout[i] = s.x[i];
   if (rep) {
-    rep->iterations = iter;
-    rep->status = status;
-    rep->n_f = n_f;
-    rep->n_df = n_df;
-    rep->initial_cost = initial_cost;
-    rep->final_cost = final_cost;
+    rep->iterations = s.iter;
+    rep->status = s.status;
+    rep->n_f = s.n_f;
+    rep->n_df = s.n_df;
+    rep->initial_cost = s.initial_cost;
+    rep->final_cost = s.f;
   }
 }
 
-int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double epsabs_grad, bool extra_iterate,
-          cmx_solve_report *rep) {
+int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double epsabs_grad, cmx_solve_report *rep) {
   SolveState st;
   st.ctx = ctx;
   st.backend = backend;
@@ -131,7 +86,7 @@ int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double
   st.g.assign((size_t)(n > 0 ? n : 1), 0.0);
   cmx::FunctionFdf fn{contrast_f, contrast_df, contrast_fdf, (size_t)n, &st};
   fn.hint = contrast_hint;
-  drive(fn, x_inout, 0.1, tol, epsabs_grad, 1e-4, 50, extra_iterate, &st.err, rep);
+  drive(fn, x_inout, 0.1, tol, epsabs_grad, 1e-4, 50, &st.err, rep);
   return st.err;
 }
 
@@ -142,21 +97,21 @@ extern "C" {
 int cmx_frontend_solve(cmx_ctx *ctx, double ang_vel[3], cmx_solve_report *report) {
   if (!ctx || !ang_vel) return CMX_ERR_INVALID_ARG;
   // step 0.1, tol 0.05, <= 50 line searches, |g| < 1e-3, |1 - c_new/c_old| < 1e-4   (:106-122)
-  return solve(ctx, false, 3, ang_vel, 0.05, 1e-3, false, report);
+  return solve(ctx, false, 3, ang_vel, 0.05, 1e-3, report);
 }
 
 int cmx_backend_solve(cmx_ctx *ctx, int n_params, double *drotv, cmx_solve_report *report) {
   if (!ctx || (n_params > 0 && !drotv) || n_params < 0) return CMX_ERR_INVALID_ARG;
   // x0 is whatever the caller passes (the reference starts at 0, global_optim_contrast_gsl.cpp:37);
   // step 0.1, tol 0.1, <= 50 line searches, |g| < 1e-4, tolfun 1e-4   (:41-53)
-  return solve(ctx, true, n_params, drotv, 0.1, 1e-4, false, report);
+  return solve(ctx, true, n_params, drotv, 0.1, 1e-4, report);
 }
 
 int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, int n, double *x, double step_size,
                       double tol, double epsabs_grad, double tolfun, int max_iterations, cmx_solve_report *report) {
   if (!f || !df || !fdf || n <= 0 || !x) return CMX_ERR_INVALID_ARG;
   cmx::FunctionFdf fn{f, df, fdf, (size_t)n, params};
-  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, false, nullptr, report);
+  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, nullptr, report);
   return CMX_OK;
 }
 
@@ -166,7 +121,7 @@ int cmx_frcg_minimize_hinted(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, cmx_hint_
   if (!f || !df || !fdf || n <= 0 || !x) return CMX_ERR_INVALID_ARG;
   cmx::FunctionFdf fn{f, df, fdf, (size_t)n, params};
   fn.hint = hint;
-  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, false, nullptr, report);
+  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, nullptr, report);
   return CMX_OK;
 }
 
