@@ -243,12 +243,11 @@ int cmx_backend_prepare(cmx_ctx *c, const double *drotv_hint) {
   BeSplatArgs a = be_args(c);
   rc = do_binning(c, nullptr, &a);
   if (rc) return rc;
-  if (c->per_batch % 4 == 0 && !(c->tile_gather && c->streams_valid)) {  // (the tile-ordered pass does not read this stream)
+  if (c->per_batch % 4 == 0) {
     rc = be_ensure_time_bearings(c);
     if (rc) return rc;
   }
   HIP_TRY(c, hipGetLastError());
-  c->rec_valid = false;
   c->x_valid = false;  // (the pose table no longer belongs to the last evaluation's point)
   c->jt_valid = false;
   return CMX_OK;
@@ -301,24 +300,9 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
     Span sp(c, CMX_T_SPLAT, /*exact=*/true);
     c->last_used_lds = use_lds;
     if (use_lds) c->fallback_pending = true;
-    c->rec_valid = false;
     if (use_lds) {
       BinnedEvents b = binned(c);
       if (use_flags) { b.tflags = c->d_tflags; b.tflags_tiles_x = (c->Wp + kTileX - 1) / kTileX; }
-      // records for the tile-ordered gradient pass, whenever a gradient evaluation at this point may follow
-      if (c->tile_gather && c->streams_valid && !c->deterministic && adjoint_ok(c) && (want_grad || c->reuse_image) && Kopt > 0) {
-        if ((size_t)c->n_packed > c->rec_cap || !c->d_rec_xy) {
-          if (c->d_rec_xy) HIP_TRY(c, hipFree(c->d_rec_xy));
-          if (c->d_rec_d) HIP_TRY(c, hipFree(c->d_rec_d));
-          c->d_rec_xy = nullptr; c->d_rec_d = nullptr; c->rec_cap = 0;
-          HIP_TRY(c, hipMalloc((void **)&c->d_rec_xy, (size_t)c->n_packed * sizeof(uint32_t)));
-          HIP_TRY(c, hipMalloc((void **)&c->d_rec_d, (size_t)c->n_packed * 2 * sizeof(float)));
-          c->rec_cap = (size_t)c->n_packed;
-        }
-        b.rec_xy = c->d_rec_xy;
-        b.rec_d = c->d_rec_d;
-        c->rec_valid = true;
-      }
       if (c->deterministic) {
         rc = ensure_fixed(c, 2 * np);
         if (rc) return rc;

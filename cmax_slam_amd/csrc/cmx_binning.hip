@@ -574,11 +574,6 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const BeWarp w = be_warp_math<0>(a, e[u], (int)bi[u], b0[u], b1[u], b2[u], R[u]);
-      if (b.rec_xy && act[u]) {  // one record per sorted event, in sorted order (coalesced): consumed by be_gather_tile_kernel
-        const int j = j0 + u * 256;
-        b.rec_xy[j] = w.ok ? ((uint32_t)w.xx | ((uint32_t)w.yy << 16)) : 0xffffffffu;
-        *reinterpret_cast<float2 *>(b.rec_d + 2 * (size_t)j) = make_float2(w.dx, w.dy);
-      }
       if (act[u] && w.ok) {
         const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {

@@ -325,8 +325,6 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
-  hipFree(c->d_rec_xy);
-  hipFree(c->d_rec_d);
   hipFree(c->d_tail_counters);
   hipFree(c->d_gacc);
   if (!c->gsum_external) hipFree(c->d_gsum);
@@ -377,11 +375,6 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_FOLD_BATCH:
       c->fold_batch = value != 0;
-      return CMX_OK;
-    case CMX_OPT_TILE_GATHER:
-      c->tile_gather = value != 0;
-      c->rec_valid = false;
-      c->x_valid = false;  // (a resident image was splatted without / with records: not reused across the switch)
       return CMX_OK;
     case CMX_OPT_COMPOSITE_IMAGE:
       c->composite_image = value != 0;
@@ -438,7 +431,6 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[10] = (double)c->spec_hits;
   stats[11] = (double)c->gated_launches;
   stats[12] = (double)c->gated_hits;
-  stats[13] = (double)c->tile_evals;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

@@ -109,12 +109,6 @@ struct cmx_ctx {
   int Mx_radius = -1;                      // blur radius the tables were built for (-1: none)
   bool composite_image = true;             // CMX_OPT_COMPOSITE_IMAGE
   bool fold_batch = true;                  // CMX_OPT_FOLD_BATCH
-  bool tile_gather = true;                 // CMX_OPT_TILE_GATHER (back end)
-  uint32_t *d_rec_xy = nullptr;            // per tile-ordered event: vote cell of the last splat (BinnedEvents::rec_xy) ...
-  float *d_rec_d = nullptr;                // ... and its bilinear offsets
-  size_t rec_cap = 0;
-  bool rec_valid = false;                  // the records belong to last_x and to the current tile order
-  int64_t tile_evals = 0;                  // gradient evaluations that took the tile-ordered pass
   bool shard_acc = false;                  // set by cmx_comm.cpp around a split evaluation it all-reduces itself (see run_adjoint)
   bool fused_gather = false;               // CMX_OPT_FUSED_GATHER (opt-in: measured slower on MI355X)
   int64_t fused_evals = 0;                 // gradient evaluations that took the fused pass

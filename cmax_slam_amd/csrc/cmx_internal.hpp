@@ -31,10 +31,10 @@ struct FeSplatArgs {
 // the tile-ordered splat reads it at random batch indices, and 3.6 MB for 50k batches stays L2-resident where the
 // 216-byte combined record did not (238 MB fetched per 5M-event launch, profiles/r01c_be_fastpath.txt).
 struct PoseR { double R[9]; };  // so3.matrix(), row-major
-struct alignas(16) PoseEntry {  // 160 B, 16-byte aligned: the tile-ordered gather reads a batch's Jacobian as 16-byte loads
+struct PoseEntry {
   float Jcp[36];    // ddrot_ddrot_cp, 3 x 3n row-major (n<=4)
   int idx_cp_beg;
-  int pad[3];
+  int pad;
 };
 
 struct BeSplatArgs {
@@ -183,14 +183,8 @@ struct BeGatherArgs {
   TailArgs tail;           // be_gather_batch / folded be_gather4: finalize in the last-arriving workgroup (counters == null: separate
                            // launch); tail.fin.gacc set without counters: accumulator rows only (sharded split evaluation)
   int fold;                // 1: fold the per-batch pass into be_gather4 when the launcher's conditions hold (be_gather_folds)
-  // tile-ordered pass (CMX_OPT_TILE_GATHER): the splat's records + the tile-ordered batch index / bearing streams; null = time order
-  const uint32_t *rec_xy;
-  const float *rec_d;
-  const uint32_t *sbatch;
-  const double *sb;
 };
 bool be_gather_folds(const BeGatherArgs &a);
-bool be_gather_tiles(const BeGatherArgs &a);  // the launcher will take the tile-ordered one-kernel form
 
 struct AlphaArgs {
   const float *igp, *il_old, *il_new;
@@ -223,11 +217,6 @@ struct BinnedEvents {
   const double *sb;        // front end, optional: bearing (x, y) of each sorted event (16 B, z == 1) ...
   const double *sdt;       // ... and its batch's dt: coalesced streams instead of two divergent table gathers per event
   unsigned long long *fixed;  // deterministic mode: 2^-30 fixed-point planes every global vote is added to (else nullptr)
-  // back end, optional: the splat leaves one record per sorted event -- vote cell (xx | yy << 16; 0xffffffff = not accepted)
-  // and the fp32 bilinear offsets (dx, dy) -- in the SAME (tile) order, i.e. coalesced: the tile-ordered gradient pass
-  // (be_gather_tile_kernel) consumes them instead of projecting every event a second time
-  uint32_t *rec_xy;
-  float *rec_d;               // [2 n]
 };
 
 // Fused front-end gradient pass (cmx_kernels.hip, fe_fused_gather_kernel): one workgroup per chunk of tile-ordered events

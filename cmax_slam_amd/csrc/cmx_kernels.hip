@@ -1963,130 +1963,6 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
   }
 }
 
-// ---- Tile-ordered gradient pass (CMX_OPT_TILE_GATHER).  The LDS splat walks the events in destination-tile order and has
-// just projected every one of them: it leaves (vote cell, dx, dy) per sorted event -- 12 bytes, coalesced -- and this pass
-// walks the SAME order, so it never evaluates atan2 / asin / the fp64 square root again (about half of be_gather4's 379 VALU
-// instructions per event) and needs no segmented batch reduction (another fifth).  What it pays instead: the batch's
-// rotation and 3 x 3N Jacobian per EVENT (16-byte loads; a wave's tile-ordered events come from few batches, so they are
-// near-broadcasts that hit L1 / L2) and the Jacobian applied per event in fp32 -- which is where the reference applies it
-// (event_pano_warper.cpp:281-285, :316-332).  Each lane keeps 3N fp64 column accumulators for the spline segment of its
-// current events (tile order is time order at slice granularity: a lane changes segment a handful of times per launch) and
-// flushes them to workgroup accumulators in LDS; the workgroup's sums go to the accumulator rows of the tail finalize and
-// the last-arriving workgroup finalizes -- one launch, like the folded be_gather4.
-__device__ __forceinline__ void be_ray_jac32(float fxf, float fyf, double x, double y, double z, float m[6]) {
-  // d(pixel)/d(rotation), 2 x 3, entries in fp32 from the fp64 ray (be_warp_math<2>), rho in fp32 as well
-  const float xf = (float)x, yf = (float)y, zf = (float)z;
-  const float rhof = sqrtf(xf * xf + yf * yf + zf * zf);
-  const float inv_rho = 1.f / rhof, inv_z = 1.f / zf;
-  const float Ydivrho = yf * inv_rho, XdivZ = xf * inv_z;
-  const float tmp1 = fxf * inv_z / (1.f + XdivZ * XdivZ);
-  const float tmp2 = -fyf / sqrtf(1.f - Ydivrho * Ydivrho);
-  const float tmp3 = Ydivrho * inv_rho * inv_rho;
-  const float d00 = tmp1, d02 = -tmp1 * XdivZ;
-  const float d10 = tmp2 * tmp3 * xf, d11 = tmp2 * (tmp3 * yf - inv_rho), d12 = tmp2 * tmp3 * zf;
-  m[0] = d02 * yf;
-  m[1] = d00 * zf + d02 * (-xf);
-  m[2] = d00 * (-yf);
-  m[3] = d11 * (-zf) + d12 * yf;
-  m[4] = d10 * zf + d12 * (-xf);
-  m[5] = d10 * (-yf) + d11 * xf;
-}
-
-constexpr int kTileGatherPerBlock = 4096;  // sorted events per workgroup (contiguous)
-int be_tile_gather_blocks(int n) {
-  const int b = (n + kTileGatherPerBlock - 1) / kTileGatherPerBlock;
-  return b < 1 ? 1 : (b > 4096 ? 4096 : b);
-}
-
-template <int NF>
-__global__ __launch_bounds__(256) void be_gather_tile_kernel(BeGatherArgs g) {
-  constexpr int NC = 3 * NF;           // columns a batch touches
-  constexpr int NQ = (3 * NC + 3) / 4; // 16-byte loads of its 3 x NC Jacobian
-  __shared__ double shG[kMaxGradLDS], shG2[kMaxGradLDS];
-  __shared__ FinSmem fin_sm;
-  if (g.gate && *g.gate == 0) return;  // gated gradient pass (see fe_gather_kernel)
-  const int tid = threadIdx.x;
-  for (int j = tid; j < g.P; j += 256) { shG[j] = 0; shG2[j] = 0; }
-  __syncthreads();
-  const BeSplatArgs &a = g.ev;
-  const float fxf = (float)a.fx, fyf = (float)a.fy;
-  const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
-  const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
-  double acc[NC];
-#pragma unroll
-  for (int c = 0; c < NC; c++) acc[c] = 0.0;
-  int cur = -(1 << 28);  // idx_cp_beg the accumulators belong to
-  auto flush = [&]() {
-    const int jb = 3 * (cur - a.num_fixed);
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-      if (jb + c >= 0 && acc[c] != 0.0) atomicAdd(&shG[jb + c], acc[c]);  // (columns of fixed knots are dropped: the j >= 0 rule, :318)
-      acc[c] = 0.0;
-    }
-  };
-  constexpr int U = 2;  // events in flight per thread
-  for (int i0 = blk_beg + tid; i0 < blk_end; i0 += 256 * U) {
-    uint32_t rc[U], bi[U];
-    float2 d[U];
-    double2 bv[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * 256;
-      const int ii = i < blk_end ? i : blk_beg;
-      rc[u] = i < blk_end ? g.rec_xy[ii] : 0xffffffffu;
-      d[u] = *reinterpret_cast<const float2 *>(g.rec_d + 2 * (size_t)ii);
-      bi[u] = g.sbatch[ii];
-      bv[u] = *reinterpret_cast<const double2 *>(g.sb + 2 * (size_t)ii);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (rc[u] == 0xffffffffu) continue;
-      const int xx = (int)(rc[u] & 0xffffu), yy = (int)(rc[u] >> 16);
-      const double *Rp = a.poseR[bi[u]].R;
-      const PoseEntry &pe = a.poses[bi[u]];
-      float4 q[NQ];
-#pragma unroll
-      for (int k = 0; k < NQ; k++) q[k] = reinterpret_cast<const float4 *>(pe.Jcp)[k];
-      const int idx = pe.idx_cp_beg;
-      const double b0 = bv[u].x, b1 = bv[u].y;  // (z == 1: the streams only exist for such tables)
-      const double x = Rp[0] * b0 + Rp[1] * b1 + Rp[2];
-      const double y = Rp[3] * b0 + Rp[4] * b1 + Rp[5];
-      const double z = Rp[6] * b0 + Rp[7] * b1 + Rp[8];
-      float m[6];
-      be_ray_jac32(fxf, fyf, x, y, z, m);
-      float A, B;
-      bilinear_grad(g.itilde, a.Wp, xx, yy, d[u].x, d[u].y, A, B);
-      const float V0 = __builtin_fmaf(B, m[3], A * m[0]), V1 = __builtin_fmaf(B, m[4], A * m[1]), V2 = __builtin_fmaf(B, m[5], A * m[2]);
-      if (idx != cur) {  // rare: the lane's events moved on to another spline segment
-        flush();
-        cur = idx;
-      }
-      const float *J = reinterpret_cast<const float *>(q);
-#pragma unroll
-      for (int c = 0; c < NC; c++)
-        acc[c] += (double)__builtin_fmaf(V2, J[2 * NC + c], __builtin_fmaf(V1, J[NC + c], V0 * J[c]));
-      float Ac, Bc;
-      border_grad(g.cx, g.cy, a.Wp, a.Hp, g.r, xx, yy, d[u].x, d[u].y, Ac, Bc);
-      if (Ac != 0.f || Bc != 0.f) {  // rare: votes within r of the panorama border (the mu term of the variance gradient)
-        const float U0 = __builtin_fmaf(Bc, m[3], Ac * m[0]), U1 = __builtin_fmaf(Bc, m[4], Ac * m[1]), U2 = __builtin_fmaf(Bc, m[5], Ac * m[2]);
-        const int jb = 3 * (idx - a.num_fixed);
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-          if (jb + c >= 0) atomicAdd(&shG2[jb + c], (double)__builtin_fmaf(U2, J[2 * NC + c], __builtin_fmaf(U1, J[NC + c], U0 * J[c])));
-      }
-    }
-  }
-  flush();
-  __syncthreads();
-  double *row = g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride;
-  for (int j = tid; j < g.P; j += 256) {
-    const double v1 = shG[j], v2 = shG2[j];
-    if (v1 != 0.0) __hip_atomic_fetch_add(row + j, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v2 != 0.0) __hip_atomic_fetch_add(row + g.P + j, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (g.tail.counters && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
-}
-
 // Pass 2: one thread per batch: sum its parts, apply the batch's 3x3N spline Jacobian (events of one batch share it),
 // accumulate S1 / S2 per parameter in LDS, one partial row per workgroup ([column][block]).
 template <int N, bool DET>
@@ -2194,18 +2070,8 @@ bool be_gather_folds(const BeGatherArgs &a) {
   return a.fold && a.slice_shift == 8 && !a.deterministic && a.tail.fin.gacc && a.P > 0 && a.P <= kMaxGradLDS &&
          (a.ev.order == 2 || a.ev.order == 4) && (256 / a.ev.per_batch + 2) * 3 * a.ev.order <= 64;
 }
-bool be_gather_tiles(const BeGatherArgs &a) {
-  return a.rec_xy && a.rec_d && a.sbatch && a.sb && !a.deterministic && a.tail.fin.gacc && a.P > 0 && a.P <= kMaxGradLDS &&
-         (a.ev.order == 2 || a.ev.order == 4);
-}
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0, hipEvent_t t1, hipEvent_t b0, hipEvent_t b1) {
   // (t0, t1) bracket the per-event kernel, (b0, b1) the per-batch pass that follows
-  if (be_gather_tiles(a)) {  // tile order, records from the splat: gather, Jacobian and finalize in one kernel
-    const dim3 gt(be_tile_gather_blocks(a.ev.n));
-    if (a.ev.order == 2) CMX_LAUNCH(be_gather_tile_kernel<2>, gt, dim3(256), 0, s, t0, t1, a);
-    else CMX_LAUNCH(be_gather_tile_kernel<4>, gt, dim3(256), 0, s, t0, t1, a);
-    return 0;
-  }
   if (be_gather_folds(a)) {  // per-batch pass and finalize inside the four-events-per-lane kernel (see be_gather4_kernel)
     const dim3 g4(gather_blocks((a.ev.n + 3) / 4));
     if (a.ev.order == 2) CMX_LAUNCH(be_gather4_kernel<2>, g4, dim3(256), 0, s, t0, t1, a);

@@ -657,35 +657,22 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
       g.parts_per_batch = parts_per_batch;
       g.slice_shift = slice_shift;
       g.deterministic = c->deterministic ? 1 : 0;
-      bool tiles = c->tile_gather && c->rec_valid && c->bin_valid && c->streams_valid && !c->deterministic && c->last_used_lds;
-      if (tiles) {  // tile order: the records the splat of this point left + the sorted batch index / bearing streams
-        g.rec_xy = c->d_rec_xy;
-        g.rec_d = c->d_rec_d;
-        g.sbatch = c->d_sbatch;
-        g.sb = c->d_sb;
+      if (c->d_lut2 && slice_shift == 8 && c->n_packed > 0) {  // once per window: the events' bearings in time order
+        const int rc2 = be_ensure_time_bearings(c);
+        if (rc2) return rc2;
+        g.tb = c->d_tb;
       }
       if (c->n_packed > 0 && P > 0) {
         if (phase == 0 || gated) tailed = arm_tail(c, f, g.tail, gated);
         else if (acc_split) g.tail.fin = f;  // (no counters: accumulators without the tail)
         g.fold = c->fold_batch ? 1 : 0;
-        if (tiles && !be_gather_tiles(g)) {  // no accumulator rows in this configuration: the time-ordered passes
-          tiles = false;
-          g.rec_xy = nullptr;
-          g.rec_d = nullptr;
-        }
-        if (!tiles && c->d_lut2 && slice_shift == 8) {  // once per window: the events' bearings in time order
-          const int rc2 = be_ensure_time_bearings(c);
-          if (rc2) return rc2;
-          g.tb = c->d_tb;
-        }
-        if (gated) {  // only the one-kernel forms can be gated
-          if (!tailed || !(be_gather_folds(g) || be_gather_tiles(g))) return CMX_OK;
+        if (gated) {  // only the one-kernel form can be gated
+          if (!tailed || !be_gather_folds(g)) return CMX_OK;
           g.gate = c->d_gate;
           c->gated_pending = true;
           c->gated_launches++;
         }
-        if (be_gather_tiles(g)) c->tile_evals++;
-        if (be_gather_folds(g) || be_gather_tiles(g)) {  // one kernel: gather, per-batch pass and finalize
+        if (be_gather_folds(g)) {  // one kernel: gather, per-batch pass and finalize
           launch_be_gather(g, c->nb, c->stream, sp.t0(), sp.t1(), nullptr, nullptr);
         } else {
           Span sb(c, CMX_T_BATCH, /*exact=*/true);

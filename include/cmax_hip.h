@@ -104,11 +104,6 @@ enum {
                              deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
                              inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
                              0: separate per-batch kernel */
-  CMX_OPT_TILE_GATHER = 11, /* 1 (default; back end, adjoint gradient, LDS-privatised splat, bearing table with z == 1, not
-                               CMX_OPT_DETERMINISTIC): the splat leaves (vote cell, dx, dy) per tile-ordered event and the gradient
-                               pass walks the same order -- no second projection of the events (atan2 / asin), no segmented batch
-                               reduction; the batch's 3 x 3N spline Jacobian is applied per event in fp32, where the reference
-                               applies it (event_pano_warper.cpp:281-285).  0: the time-ordered passes (be_gather4) */
   CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
@@ -403,8 +398,7 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
  * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
- * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = back-end gradient evaluations that took
- * the tile-ordered pass (CMX_OPT_TILE_GATHER), [14..15] reserved */
+ * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [11..15] reserved */
 #define CMX_N_STATS 16
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes

@@ -92,8 +92,6 @@ def main():
                     ("composite=0", {_lib.OPT_COMPOSITE_IMAGE: 0}), ("composite=1", {_lib.OPT_COMPOSITE_IMAGE: 1})]
     if "fold" in kv:
         variants = [("fold=0", {_lib.OPT_FOLD_BATCH: 0}), ("fold=1", {_lib.OPT_FOLD_BATCH: 1})] * 2
-    if "tile" in kv:
-        variants = [("tile_gather=0", {_lib.OPT_TILE_GATHER: 0}), ("tile_gather=1", {_lib.OPT_TILE_GATHER: 1})] * 2
     if "det" in kv:
         variants = [("deterministic=0", {_lib.OPT_DETERMINISTIC: 0}), ("deterministic=1", {_lib.OPT_DETERMINISTIC: 1})]
     for kind in kinds:
