@@ -35,6 +35,7 @@ __device__ __forceinline__ uint32_t tile_key(int xx, int yy, bool ok, int W, int
 
 __global__ __launch_bounds__(256) void fe_bin_keys_kernel(FeSplatArgs a, int tiles_x, int ntiles, uint32_t *keys,
                                                           uint32_t *idx) {
+  fe_resolve_omega(a);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
     const FeWarp w = fe_warp_event<false>(a, i);
     keys[i] = tile_key(w.xx, w.yy, w.ok, a.W, a.H, tiles_x, (uint32_t)ntiles);
@@ -126,6 +127,7 @@ __device__ __forceinline__ void hist_store_row(int nbins, int *table) {
 }
 __global__ __launch_bounds__(kBinBlock) void fe_bin_hist_kernel(FeSplatArgs a, int tiles_x, int ntiles, int per_block,
                                                                 uint32_t *keys, int *table) {
+  fe_resolve_omega(a);
   hist_zero(ntiles + 1);
   const int beg = blockIdx.x * per_block, end = min(a.n, beg + per_block);
   for (int i = beg + threadIdx.x; i < end; i += kBinBlock) {
@@ -429,6 +431,8 @@ constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -
 template <bool FIXED, bool STREAM>
 __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];
+  if (a.skip && *a.skip) return;  // device-driven solve: finished
+  fe_resolve_omega(a);
   // the launch is sized by an upper bound of the table's length, and so is the table's allocation: the entry is read
   // BEFORE the length is checked, so that the two loads share one memory round trip instead of taking two (~1 us each)
   const Chunk c = b.chunks[blockIdx.x];

@@ -1,0 +1,178 @@
+// cmx_chain.cpp -- device-driven front-end solve: the FR-CG line search runs ahead of the host.
+//
+// A host-driven solve pays, after EVERY evaluation, the way to the host and back: finalize -> completion ticket over PCIe ->
+// the optimiser's arithmetic -> next launch (~5.7 us of a 25-40 us evaluation).  Everything the optimiser
+// does between two evaluations is a closed form of numbers the finalize step has just reduced (GSL's take_step /
+// intermediate_point / minimize, the Fletcher-Reeves direction update, the reference's stopping rules,
+// src/frontend/local_optim_contrast_gsl.cpp:134-215).  So the finalize step runs it: the FR-CG state machine
+// (cmx_frcg_sm.hpp) lives in device memory, the last-arriving workgroup of an evaluation's last kernel feeds it the cost /
+// gradient, and it writes the next evaluation point where the next evaluation's kernels -- queued by the host one slot
+// ahead -- read it.  One SLOT = one evaluation point:
+//     splat (omega from device memory)  ->  image pass + cost finalize + machine step  ->  gradient pass, gated by the machine
+//     (+ its finalize + machine step)
+// The host keeps kAhead slots queued, receives every finalize's result block in mapped memory, REPLAYS the same machine on
+// the reported cost / gradient and compares its next point with the device's, bit for bit.  On agreement the device is simply
+// ahead; on any disagreement (the one known source: pow(r, 2.0) of glibc vs r*r on the device, ~0.08 % of direction updates)
+// the host stops the chain and continues the solve itself from its own state -- results are those of the host-driven solve
+// either way.  Slots queued beyond the end of the solve return on their first instruction (a flag in device memory).
+#include "cmx_context.hpp"
+
+namespace {
+
+constexpr int kAhead = 2;        // slots kept queued ahead of the one whose results the host is waiting for
+constexpr int kRingSlots = 8;    // ring of result blocks (2 per slot); > kAhead + 1
+constexpr int kBlock = 4096;     // doubles per result block (the layout of the one-evaluation result buffer)
+
+struct SlotTickets { unsigned long long a = 0, g = 0; int nout_a = 0, nout_g = 0; bool gated = false; };
+
+int ensure_chain_buffers(cmx_ctx *c) {
+  if (c->d_chain) return CMX_OK;
+  HIP_TRY(c, hipMalloc((void **)&c->d_chain, sizeof(ChainDev)));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_chain_ring, (size_t)2 * kRingSlots * kBlock * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_chain_ring, c->h_chain_ring, 0));
+  memset(c->h_chain_ring, 0, (size_t)2 * kRingSlots * kBlock * sizeof(double));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_chain_init, 2 * sizeof(ChainDev), hipHostMallocDefault));
+  return CMX_OK;
+}
+
+// what the chain needs from the configuration: the production path of a front-end context, whole evaluation on this GPU
+bool chain_eligible(const cmx_ctx *c) {
+  return c->kind == KIND_FE && c->chain_solve && c->have_data && c->n_packed > 0 && c->splat_mode == 1 && adjoint_ok(c) &&
+         !c->deterministic && !c->sharded() && !c->accum_external && !c->gsum_external && c->ticket_wait && c->tail_finalize == 1 &&
+         c->d_tail_counters && c->d_gacc && c->reuse_image && c->gated_df && !c->fused_gather && !c->timing &&
+         c->measure != CMX_GRADIENT_MAGNITUDE;
+}
+
+int queue_slot(cmx_ctx *c, int slot, SlotTickets *t) {
+  const int r = slot % kRingSlots;
+  c->chain_block_a = c->d_chain_ring + (size_t)(2 * r) * kBlock;
+  c->chain_block_g = c->d_chain_ring + (size_t)(2 * r + 1) * kBlock;
+  const double zero[3] = {0, 0, 0};  // (the kernels read omega from device memory; last_x is not meaningful inside a chain)
+  c->last_adjoint = true;
+  int rc = fe_accumulate(c, zero, 1);
+  if (rc) return rc;
+  c->gate_arm = true;
+  rc = run_adjoint(c, 3, /*phase=*/3);  // image pass + cost finalize + machine step (decides the gate)
+  c->gate_arm = false;
+  if (rc) return rc;
+  t->a = c->ticket_issued;
+  t->nout_a = c->ticket_nout;
+  c->gated_pending = false;
+  rc = run_adjoint(c, 3, /*phase=*/4);  // gradient pass behind the gate (+ finalize + machine step)
+  if (rc) return rc;
+  t->gated = c->gated_pending;
+  c->gated_pending = false;
+  t->g = c->ticket2_issued;
+  t->nout_g = c->ticket2_nout;
+  c->chain_slots++;
+  return CMX_OK;
+}
+
+// wait for a result block of the ring; falls back to the stream when the spin budget runs out
+int wait_block(cmx_ctx *c, const double *h_block, unsigned long long ticket, int nout) {
+  if (spin_for_ticket(h_block, ticket, nout)) return CMX_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (spin_for_ticket(h_block, ticket, nout)) return CMX_OK;
+  return fail(c, CMX_ERR_HIP, "a chained evaluation ended without its finalize step (ticket %llu)", ticket);
+}
+
+bool same_bits(const double *a, const double *b, int n) { return memcmp(a, b, sizeof(double) * (size_t)n) == 0; }
+
+}  // namespace
+
+int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
+  *completed = false;
+  if (!c || !chain_eligible(c) || hs.n != 3) return CMX_OK;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  rc = ensure_chain_buffers(c);
+  if (rc) return rc;
+  // a gated pass of an earlier evaluation may still be queued: nothing of it is wanted
+  c->gated_pending = false;
+  c->gate_mode = 0;
+  // ---- the machine's initial state -> device: ONE stream-ordered copy in front of the first slot.  Two pinned staging blocks
+  // alternate, so the copy of the previous solve (long finished: its results were waited for) is never overwritten in flight
+  // by the one after next.
+  {
+    ChainDev *st = c->h_chain_init + (c->chain_init_sel ^= 1);
+    memset(st, 0, sizeof(ChainDev));
+    sm_to_fixed<kChainMaxN>(hs, st->sm);
+    for (int k = 0; k < 3; k++) st->x_req[k] = hs.x[k];
+    st->done = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_chain, st, sizeof(ChainDev), hipMemcpyHostToDevice, c->stream));
+  }
+  SlotTickets tick[kRingSlots];
+  int queued = 0, consumed = 0;
+  bool diverged = false, unsupported = false;
+  c->chain_active = true;
+  c->chain_solves++;
+  double g[3];
+  while (!sm_done(hs)) {
+    while (queued < consumed + kAhead) {
+      rc = queue_slot(c, queued, &tick[queued % kRingSlots]);
+      if (rc) break;
+      if (!tick[queued % kRingSlots].gated) { unsupported = true; }  // no gated gradient pass in this configuration
+      queued++;
+      if (unsupported) break;
+    }
+    if (rc || unsupported) break;
+    const SlotTickets &t = tick[consumed % kRingSlots];
+    const double *ba = c->h_chain_ring + (size_t)(2 * (consumed % kRingSlots)) * kBlock;
+    const double *bg = ba + kBlock;
+    rc = wait_block(c, ba, t.a, t.nout_a);
+    if (rc) break;
+    if (!c->nchunks_exact && c->bin_valid && c->h_nchunks) {  // once per binning: launch exactly the chunks that exist
+      const unsigned long long w = *reinterpret_cast<volatile unsigned long long *>(c->h_nchunks);
+      if ((unsigned)(w >> 32) == c->binning_id) {
+        const int nch = (int)(unsigned)(w & 0xffffffffull);
+        if (nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
+        c->nchunks_exact = true;
+      }
+    }
+    if (c->n_packed > 0) c->last_fallback_frac = ba[kFallbackSlot] / (double)c->n_packed;  // drives the re-sort of the next slot queued
+    c->fallback_pending = false;
+    // ---- replay: the cost stage
+    const int ext_a = t.nout_a - kChainExtra;
+    const bool dev_need = ba[ext_a] != 0.0;
+    const bool need = sm_cost(hs, -ba[0]);
+    if (need != dev_need) { diverged = true; break; }
+    if (c->chain_test == 2 && need && consumed == 2) { diverged = true; break; }  // (test hook: hand over between a cost and its gradient)
+    if (!need) {
+      const bool dev_done = ba[ext_a + 2] != 0.0;
+      if (dev_done != sm_done(hs) || (!dev_done && !same_bits(ba + ext_a + 3, sm_point(hs), 3))) { diverged = true; break; }
+      consumed++;
+      continue;
+    }
+    // ---- the gradient stage
+    rc = wait_block(c, bg, t.g, t.nout_g);
+    if (rc) break;
+    for (int k = 0; k < 3; k++) g[k] = -bg[2 + k];
+    sm_grad(hs, g);
+    const int ext_g = t.nout_g - kChainExtra;
+    const bool dev_done = bg[ext_g + 2] != 0.0;
+    if (dev_done != sm_done(hs) || (!dev_done && !same_bits(bg + ext_g + 3, sm_point(hs), 3))) { diverged = true; consumed++; break; }
+    consumed++;
+    if (c->chain_test == 1 && consumed == 3 && !sm_done(hs)) { diverged = true; break; }  // (test hook: hand over between two points)
+  }
+  c->chain_active = false;
+  // ---- leave the context in a state the ordinary evaluations understand.  Slots queued beyond the last one consumed either
+  // return at once (the device's machine finished where the host's did) or must be stopped (divergence / error).
+  if (rc || diverged || unsupported) {
+    const int one = 1;
+    (void)hipMemcpy(&c->d_chain->done, &one, sizeof(int), hipMemcpyHostToDevice);  // (null stream: overtakes the queued slots)
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_tail_counters) (void)hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream);
+    if (c->d_gacc) (void)hipMemsetAsync(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double), c->stream);
+    if (diverged) c->chain_takeovers++;
+  }
+  c->x_valid = false;
+  c->jt_valid = false;
+  c->accum_clean = false;  // (which of the two ping-pong buffers the last EXECUTED slot used is not tracked: both are cleared
+  c->alt_clean = false;    //  by the next evaluation's memset)
+  c->accumulated = false;
+  c->gated_pending = false;
+  c->gate_mode = 0;
+  if (rc) return rc;
+  *completed = sm_done(hs) && !diverged;
+  return CMX_OK;
+}

@@ -332,6 +332,9 @@ void cmx_destroy(cmx_ctx *c) {
   if (c->h_result2) hipHostFree(c->h_result2);
   if (c->h_dts) hipHostFree(c->h_dts);
   hipFree(c->d_gate);
+  hipFree(c->d_chain);
+  if (c->h_chain_ring) hipHostFree(c->h_chain_ring);
+  if (c->h_chain_init) hipHostFree(c->h_chain_init);
   if (c->h_many) hipHostFree(c->h_many);
   comm_release(c);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -375,6 +378,10 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_FOLD_BATCH:
       c->fold_batch = value != 0;
+      return CMX_OK;
+    case CMX_OPT_CHAIN_SOLVE:
+      c->chain_solve = value != 0;
+      c->chain_test = value == 2 ? 1 : (value == 3 ? 2 : 0);
       return CMX_OK;
     case CMX_OPT_COMPOSITE_IMAGE:
       c->composite_image = value != 0;
@@ -431,6 +438,9 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[10] = (double)c->spec_hits;
   stats[11] = (double)c->gated_launches;
   stats[12] = (double)c->gated_hits;
+  stats[13] = (double)c->chain_solves;
+  stats[14] = (double)c->chain_slots;
+  stats[15] = (double)c->chain_takeovers;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

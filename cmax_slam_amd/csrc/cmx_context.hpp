@@ -198,6 +198,16 @@ struct cmx_ctx {
   unsigned long long ticket2_issued = 0;
   int ticket2_nout = 0;
   unsigned long long gated_launches = 0, gated_hits = 0;
+  // device-driven solve (cmx_chain.cpp): the FR-CG machine lives in device memory and advances inside the finalize steps
+  bool chain_solve = true;            // CMX_OPT_CHAIN_SOLVE (front end)
+  int chain_test = 0;                 // CMX_OPT_CHAIN_SOLVE 2 / 3: the host takes over after a few slots (exercises the hand-over)
+  bool chain_active = false;          // set around the launches of a chain slot: kernels read omega / skip from device memory
+  ChainDev *d_chain = nullptr;        // the machine + next evaluation point + end-of-solve flag
+  double *h_chain_ring = nullptr, *d_chain_ring = nullptr;  // mapped result blocks: 2 per slot (cost stage, gradient stage)
+  ChainDev *h_chain_init = nullptr;   // pinned staging of the machine's initial state (two blocks, alternating per solve)
+  int chain_init_sel = 0;
+  double *chain_block_a = nullptr, *chain_block_g = nullptr;  // device pointers of the blocks of the slot being queued
+  int64_t chain_solves = 0, chain_slots = 0, chain_takeovers = 0;
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
   double *d_gacc = nullptr;             // kTailShards x kGaccStride gradient accumulators of the tail finalize, all-zero between launches
@@ -329,6 +339,12 @@ int collect_gated(cmx_ctx *c, int P, double *contrast, double *grad, bool *serve
 bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
+bool spin_for_ticket(const double *h_block, unsigned long long want, int nout);
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes);  // cmx_frontend.cpp
+// cmx_chain.cpp: run the solve on the device as far as it goes.  `hs` = the host's machine, begun (sm_begin) with x = start;
+// on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
+// host-driven from hs (configuration not eligible, or the device's next point was not bitwise the host's)
+int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed);
 int finish_begin(cmx_ctx *c, int kind, int want_grad);
 int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
 int be_ensure_time_bearings(cmx_ctx *c);  // cmx_backend.cpp: the gather's time-ordered bearing stream (once per window)

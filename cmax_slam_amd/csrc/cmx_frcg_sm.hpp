@@ -43,33 +43,45 @@ enum SmPhase {
 // kinds of request
 enum { SM_REQ_F_GATED = 0, SM_REQ_FDF = 1, SM_REQ_DF = 2 };
 
-struct FrcgSM {
+// everything but the vectors: shared by the two storage forms below
+struct FrcgScalars {
   // configuration
-  int n, max_iter;
+  int max_iter, dir_iter;
   double step_size, tol, epsabs_grad, tolfun;
-  // vectors: 9 x n doubles owned by the caller (host: a std::vector; device: LDS / global memory)
-  double *x, *gradient, *dx, *x1, *dx1, *x2, *dx2, *p, *g0;
   // minimiser state (conjugate_fr_state_t)
   double f, step, max_step, pnorm, g0norm, g1norm;
-  int dir_iter;
   // iterate()'s locals that live across evaluations
   double fa, fb, fc, dir, stepa, stepb, stepc, pg;
   // intermediate_point()'s by-value copies
   double ip_fc, ip_stepc;
   // minimize()'s by-value copies and locals
   double m_stepa, m_stepb, m_stepc, m_fa, m_fb, m_fc, u, v, w, fu, fv, fw, old1, old2, stepm, fm;
-  int m_iter;
   // the reference's driver loop
-  int iter, status, n_f, n_df;
   double cost_new, cost_old, initial_cost;
+  int m_iter, iter, status, n_f, n_df;
   // current request
   int phase, req_kind, gate_mode;  // gate: the test on the cost f that decides whether df follows (1: f < thr, 2: f <= thr, 3: !(f >= thr), 4: always)
-  double gate_thr;
   int req_at_x;                    // 1: the evaluation point is x (SM_INIT), 0: x1
+  int pad_;
+  double gate_thr;
+};
+// host form: any n, the 9 x n vectors owned by the caller (one contiguous block x | gradient | dx | x1 | dx1 | x2 | dx2 | p | g0)
+struct FrcgSM : FrcgScalars {
+  int n;
+  double *x, *gradient, *dx, *x1, *dx1, *x2, *dx2, *p, *g0;
+};
+// device form: n known at compile time, vectors inside the struct -- one block of memory, every access a fixed offset (the
+// finalize step keeps it in LDS while it advances it), every loop unrolled
+template <int N>
+struct FrcgSMFix : FrcgScalars {
+  static constexpr int n = N;
+  double x[N], gradient[N], dx[N], x1[N], dx1[N], x2[N], dx2[N], p[N], g0[N];
 };
 
-CMX_SM_HD inline const double *sm_point(const FrcgSM &s) { return s.req_at_x ? s.x : s.x1; }
-CMX_SM_HD inline bool sm_done(const FrcgSM &s) { return s.phase == SM_DONE; }
+template <class SM>
+CMX_SM_HD inline const double *sm_point(const SM &s) { return s.req_at_x ? s.x : s.x1; }
+template <class SM>
+CMX_SM_HD inline bool sm_done(const SM &s) { return s.phase == SM_DONE; }
 
 // gsl_blas_dnrm2 as GSL's own CBLAS computes it (cblas/source_nrm2_r.h): running scale + scaled sum of squares
 CMX_SM_HD inline double sm_nrm2(const double *v, int n) {
@@ -99,7 +111,8 @@ CMX_SM_HD inline void sm_copy(double *d, const double *s, int n) {
   for (int i = 0; i < n; i++) d[i] = s[i];
 }
 // x1 = x - step*lambda*p ; dx = -step*lambda*p   (take_step: gsl_vector_set_zero, daxpy, memcpy, daxpy)
-CMX_SM_HD inline void sm_take_step(const FrcgSM &s, double step, double lambda, double *xo, double *dxo) {
+template <class SM>
+CMX_SM_HD inline void sm_take_step(const SM &s, double step, double lambda, double *xo, double *dxo) {
   for (int i = 0; i < s.n; i++) dxo[i] = 0.0;
   for (int i = 0; i < s.n; i++) dxo[i] += -step * lambda * s.p[i];
   for (int i = 0; i < s.n; i++) xo[i] = s.x[i] + 1.0 * dxo[i];
@@ -113,7 +126,8 @@ CMX_SM_HD inline double sm_sq(double r) {
 #endif
 }
 
-CMX_SM_HD inline void sm_request(FrcgSM &s, int phase, int kind, int mode, double thr) {
+template <class SM>
+CMX_SM_HD inline void sm_request(SM &s, int phase, int kind, int mode, double thr) {
   s.phase = phase;
   s.req_kind = kind;
   s.gate_mode = mode;
@@ -121,14 +135,17 @@ CMX_SM_HD inline void sm_request(FrcgSM &s, int phase, int kind, int mode, doubl
   s.req_at_x = 0;
 }
 
-CMX_SM_HD inline void sm_finish(FrcgSM &s, int status) {
+template <class SM>
+CMX_SM_HD inline void sm_finish(SM &s, int status) {
   s.status = status;
   s.phase = SM_DONE;
 }
 
 // ---- minimize(): one pass of its loop up to the next evaluation, or its return
-CMX_SM_HD inline void sm_driver_post(FrcgSM &s, int status);
-CMX_SM_HD inline void sm_post_minimize(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_driver_post(SM &s, int status);
+template <class SM>
+CMX_SM_HD inline void sm_post_minimize(SM &s) {
   // back in iterate(): x = x2, new conjugate direction
   sm_copy(s.x, s.x2, s.n);
   s.dir_iter = (s.dir_iter + 1) % s.n;
@@ -145,7 +162,8 @@ CMX_SM_HD inline void sm_post_minimize(FrcgSM &s) {
   sm_copy(s.g0, s.gradient, s.n);
   sm_driver_post(s, FRCG_SUCCESS);
 }
-CMX_SM_HD inline void sm_min_next(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_min_next(SM &s) {
   s.m_iter++;
   if (s.m_iter > 10) {  // MAX ITERATIONS
     sm_post_minimize(s);
@@ -163,7 +181,8 @@ CMX_SM_HD inline void sm_min_next(FrcgSM &s) {
   sm_take_step(s, s.stepm, s.dir / s.pnorm, s.x1, s.dx1);
   sm_request(s, SM_MIN, SM_REQ_F_GATED, 2, s.m_fb);  // df(x1) follows iff fm <= fb
 }
-CMX_SM_HD inline void sm_min_begin(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_min_begin(SM &s) {
   // minimize (p, x, dir / pnorm, stepa, stepb, stepc, fa, fb, fc, tol, x1, dx1, x2, dx, gradient, &step, &f, &g1norm)
   s.m_stepa = s.stepa; s.m_stepb = s.stepb; s.m_stepc = s.stepc;
   s.m_fa = s.fa; s.m_fb = s.fb; s.m_fc = s.fc;
@@ -181,7 +200,8 @@ CMX_SM_HD inline void sm_min_begin(FrcgSM &s) {
 }
 
 // ---- intermediate_point(): one pass of its loop up to the next evaluation
-CMX_SM_HD inline void sm_ip_next(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_ip_next(SM &s) {
   const double lambda = s.dir / s.pnorm;
   const double u = fabs(s.pg * lambda * s.ip_stepc);
   s.stepb = 0.5 * s.ip_stepc * u / ((s.ip_fc - s.fa) + u);
@@ -197,7 +217,8 @@ CMX_SM_HD inline void sm_ip_next(FrcgSM &s) {
 }
 
 // ---- iterate(): from its entry to its first evaluation
-CMX_SM_HD inline void sm_iterate_begin(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_iterate_begin(SM &s) {
   s.fa = s.f;
   s.stepa = 0.0;
   s.stepc = s.step;
@@ -213,12 +234,14 @@ CMX_SM_HD inline void sm_iterate_begin(FrcgSM &s) {
 }
 
 // ---- the reference's loop around gsl_multimin_fdfminimizer_iterate (local_optim_contrast_gsl.cpp:134-215)
-CMX_SM_HD inline void sm_driver_next(FrcgSM &s) {
+template <class SM>
+CMX_SM_HD inline void sm_driver_next(SM &s) {
   s.iter++;
   s.cost_old = s.cost_new;
   sm_iterate_begin(s);
 }
-CMX_SM_HD inline void sm_driver_post(FrcgSM &s, int status) {
+template <class SM>
+CMX_SM_HD inline void sm_driver_post(SM &s, int status) {
   if (status == FRCG_SUCCESS) {
     s.cost_new = s.f;  // convergence due to stagnation in the value of the function
     if (fabs(1 - s.cost_new / (s.cost_old + 1e-7)) < s.tolfun) { sm_finish(s, status); return; }
@@ -250,7 +273,8 @@ CMX_SM_HD inline void sm_begin(FrcgSM &s, int n, double step_size, double tol, d
 
 // The cost f at the requested point (ignored for SM_REQ_DF).  Returns true iff the gradient at the same point is needed next
 // (then call sm_grad); otherwise the machine has already moved on to the next request (or finished).
-CMX_SM_HD inline bool sm_cost(FrcgSM &s, double fval) {
+template <class SM>
+CMX_SM_HD inline bool sm_cost(SM &s, double fval) {
   switch (s.phase) {
     case SM_INIT:
       s.f = fval;
@@ -299,7 +323,8 @@ CMX_SM_HD inline bool sm_cost(FrcgSM &s, double fval) {
 }
 
 // The gradient at the point whose cost was just fed (sm_cost returned true)
-CMX_SM_HD inline void sm_grad(FrcgSM &s, const double *g) {
+template <class SM>
+CMX_SM_HD inline void sm_grad(SM &s, const double *g) {
   s.n_df++;
   switch (s.phase) {
     case SM_INIT: {  // gsl_multimin_fdfminimizer_set: first direction = gradient
@@ -357,6 +382,16 @@ CMX_SM_HD inline void sm_grad(FrcgSM &s, const double *g) {
     }
     default:
       return;
+  }
+}
+
+// the device form of a host machine (front end: N = 3)
+template <int N>
+inline void sm_to_fixed(const FrcgSM &h, FrcgSMFix<N> &d) {
+  static_cast<FrcgScalars &>(d) = static_cast<const FrcgScalars &>(h);
+  for (int i = 0; i < N; i++) {
+    d.x[i] = h.x[i]; d.gradient[i] = h.gradient[i]; d.dx[i] = h.dx[i]; d.x1[i] = h.x1[i]; d.dx1[i] = h.dx1[i];
+    d.x2[i] = h.x2[i]; d.dx2[i] = h.dx2[i]; d.p[i] = h.p[i]; d.g0[i] = h.g0[i];
   }
 }
 

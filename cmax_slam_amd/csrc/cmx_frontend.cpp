@@ -96,7 +96,7 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   return fe_set_packet_impl(c, n, x, y, t_ns, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma, contrast_measure);
 }
 
-static int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
   const size_t np = (size_t)c->W * c->H;
   int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);

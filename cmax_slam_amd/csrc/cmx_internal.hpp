@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "cmx_frcg_sm.hpp"
 #include "cmx_so3.hpp"
 
 namespace cmx {
@@ -25,6 +26,10 @@ struct FeSplatArgs {
   const double *lut;       // W*H*3
   const double *lut2;      // W*H*2 (x, y), 16-byte entries, present when every z == 1 (image_geometry's rays); else null
   float *planes;           // [1 + 3][H][W]: IWE, dI/dwx, dI/dwy, dI/dwz
+  // device-driven solve (cmx_chain.cpp): omega is read from device memory -- written there by the previous evaluation's
+  // finalize step -- instead of (wx, wy, wz); and the kernel returns at once when *skip != 0 (the solve has finished)
+  const double *w_dev;
+  const int *skip;
 };
 
 // per event batch, written by the pose-table kernel.  The rotation lives in its own dense table (72 B per batch):
@@ -52,6 +57,26 @@ struct BeSplatArgs {
   float *planes;  // [2 + P][Hp][Wp]: IL_old, IL_new, derivative planes
 };
 
+// Device-driven solve: the finalize step of an evaluation advances the FR-CG state machine (cmx_frcg_sm.hpp) in device memory
+// with the cost / gradient it has just reduced, writes the NEXT evaluation point to x_req and decides whether the gradient pass
+// queued behind it runs (FinalizeArgs::gate_out) -- the next evaluation's kernels, already queued by the host, start without a
+// round trip to it.  The host replays the same machine on what the result blocks report and takes over on any disagreement.
+constexpr int kChainMaxN = 3;  // parameters of a device-driven solve (front end)
+typedef FrcgSMFix<kChainMaxN> ChainMachine;
+struct ChainDev {  // one device allocation, initialised by one copy
+  ChainMachine sm;
+  double x_req[kChainMaxN];  // evaluation point of the next slot (read by its splat / gather)
+  int done;                  // set once the machine has finished: every later kernel of the chain returns at once
+  int pad;
+};
+struct ChainArgs {
+  ChainMachine *sm;  // the machine in device memory (copied to LDS and back by the finalize that advances it); null = off
+  double *x_req;
+  int *done;
+  int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass
+};
+constexpr int kChainExtra = 3 + kChainMaxN;  // result words appended by a chained finalize: need-gradient flag, phase, done, next point
+
 struct FinalizeArgs {
   int P, nblk, measure;
   double npix;
@@ -77,6 +102,7 @@ struct FinalizeArgs {
   int *gate_out;
   double gate_thr;
   int gate_mode;
+  ChainArgs chain;
 };
 // the condition of the gate, the same expression on the device (finalize) and on the host (which result to expect)
 static inline __host__ __device__ int gate_condition(double contrast, double thr, int mode) {
@@ -132,6 +158,7 @@ struct ImgArgs {
   // the image kernels walk that list with a bounded grid instead of launching one workgroup per panorama tile
   const unsigned *tile_list;
   const unsigned *tile_count;
+  const int *skip;      // optional (device-driven solve): the launch does nothing when *skip != 0
   TailArgs tail;        // image_moments only (cost-only evaluations, P == 0): finalize in the last-arriving workgroup
 };
 constexpr int kTileListMin = 2048, kTileListGrid = 1024;

@@ -460,10 +460,12 @@ struct alignas(16) FinSmem {  // a multiple of 16 bytes: static LDS in front of 
   unsigned long long shchk;
   int is_last;
   int pad[3];
+  // device-driven solve: the FR-CG machine and its vectors while the finalize advances them (ChainArgs)
+  ChainMachine csm;
 };
 static_assert(sizeof(FinSmem) % 16 == 0, "FinSmem must keep the dynamic LDS base 16-byte aligned");
 
-template <int NT>
+template <int NT, bool CHAIN = false>  // CHAIN: the device-driven solve's variant (the machine's step is compiled in)
 __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm) {
   constexpr int NW = NT / 64;   // waves
   constexpr int HALF = NW / 2;  // waves per image-moment row
@@ -471,6 +473,11 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   if (t == 0) sm.shchk = 0ull;
   const double N = a.npix;
+  const bool chain = CHAIN && a.chain.sm != nullptr;
+  constexpr int kSmWords = (int)(sizeof(ChainMachine) / 8);
+  static_assert(sizeof(ChainMachine) % 8 == 0 && kSmWords <= NT, "the machine is copied by one thread per word");
+  if (chain && t < kSmWords)  // the machine's state (written by the previous evaluation's finalize: an earlier launch) -> LDS
+    reinterpret_cast<unsigned long long *>(&sm.csm)[t] = reinterpret_cast<const unsigned long long *>(a.chain.sm)[t];
   // Everything this workgroup reads was written by other CUs: each dependent round of loads is a ~1.2 us trip to memory.
   // The reads that do not depend on one another -- fallback counter, accumulator rows, moment rows -- are issued together.
   unsigned fb_count = 0u;
@@ -599,7 +606,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     }
     sm.outv[0] = c;
     sm.outv[1] = mu;
-    if (a.gate_out) *a.gate_out = gate_condition(c, a.gate_thr, a.gate_mode);  // read by the NEXT launch (kernel boundary)
+    if (a.gate_out && !chain) *a.gate_out = gate_condition(c, a.gate_thr, a.gate_mode);  // read by the NEXT launch (kernel boundary)
     if (a.fallback) {
       sm.shfall = (double)fb_count;
       *a.fallback = 0u;
@@ -628,7 +635,40 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     }
   }
   __syncthreads();
-  const int nout = 2 + (a.P > a.gP ? a.P : a.gP);
+  int nout = 2 + (a.P > a.gP ? a.P : a.gP);
+  if (chain) {
+    // Device-driven solve: thread 0 feeds the machine what this evaluation produced -- f = -contrast after a cost evaluation,
+    // df = -gradient after a gradient pass -- exactly what the host-driven loop feeds it (cmx_solver.cpp: contrast_fdf), and
+    // publishes the next request: the evaluation point for the next slot's kernels, the gate of the gradient pass queued
+    // behind this launch, the end of the solve.  The result block carries need / phase / done / next point behind the
+    // evaluation's own numbers; the host replays the machine on them and compares (cmx_chain.cpp).
+    if (t == 0) {
+      ChainMachine &s = sm.csm;
+      constexpr int n = kChainMaxN;
+      int need = 0;
+      if (a.chain.stage == 0) {
+        need = sm_cost(s, -sm.outv[0]) ? 1 : 0;
+      } else {
+        double g[n];
+        for (int k = 0; k < n; k++) g[k] = -sm.outv[2 + k];
+        sm_grad(s, g);
+      }
+      const int done = sm_done(s) ? 1 : 0;
+      const bool moved = a.chain.stage == 1 || !need;  // the machine has gone on to its next request
+      if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
+      if (done) *a.chain.done = 1;                     // read by every later launch of the chain
+      const double *xn = sm_point(s);
+      sm.outv[nout] = (double)need;
+      sm.outv[nout + 1] = (double)s.phase;
+      sm.outv[nout + 2] = (double)done;
+      for (int k = 0; k < n; k++) sm.outv[nout + 3 + k] = (moved && !done) ? xn[k] : 0.0;
+      if (moved && !done)
+        for (int k = 0; k < n; k++) a.chain.x_req[k] = xn[k];
+    }
+    nout += kChainExtra;
+    __syncthreads();
+    if (t < kSmWords) reinterpret_cast<unsigned long long *>(a.chain.sm)[t] = reinterpret_cast<const unsigned long long *>(&sm.csm)[t];
+  }
   // Results, then a checksum and the completion ticket the host spins on (sync_and_collect): the host accepts the
   // results once the ticket matches AND the checksum over what it read matches, so no system-scope fence (an L2
   // write-back, ~3 us here) is needed to order these stores over PCIe -- a torn read simply fails the check and is
@@ -654,9 +694,11 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   }
 }
 
+template <bool CHAIN>
 __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ FinSmem sm;
-  finalize_body<1024>(a, sm);
+  if (CHAIN && a.chain.sm && *a.chain.done) return;  // device-driven solve: finished (the kernels in front returned as well)
+  finalize_body<1024, CHAIN>(a, sm);
 }
 
 // ---- tail finalize: the evaluation's last kernel runs finalize in its LAST-ARRIVING workgroup instead of handing over to
@@ -939,7 +981,8 @@ void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 + 2 * a.P), dim3(256), 0, s, a);
 }
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  CMX_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, t0, t1, a);
+  if (a.chain.sm) CMX_LAUNCH(finalize_kernel<true>, dim3(1), dim3(1024), 0, s, t0, t1, a);
+  else CMX_LAUNCH(finalize_kernel<false>, dim3(1), dim3(1024), 0, s, t0, t1, a);
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   launch_reduce_partials(a, s);
@@ -975,6 +1018,7 @@ __device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves)
 template <int R, int TX, int TY, int NT, bool LIST>  // LIST: see image_moments_kernel
 __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (g.img.skip && *g.img.skip) return;  // device-driven solve: finished
   const ImgArgs &a = g.img;
   const int r = (R >= 0) ? R : a.r;
   const int W = a.W, H = a.H;
@@ -1117,11 +1161,12 @@ size_t image_adjoint2_lds_bytes(int r) {
 // workgroups fit a CU only at <= 64 VGPRs (8 waves per SIMD), and 300 tiles on 256 CUs need the second one: at 76 VGPRs the
 // pass took 11 us instead of 8.2 -- hence the occupancy bound (the finalize body, run by one workgroup, may spill; the
 // image phases do not) and the compile-time switch.
-template <int R, bool LIST, bool TAIL>
+template <int R, bool LIST, int TAIL>  // TAIL: 0 none, 1 finalize in the last-arriving workgroup, 2 the same with the device-driven solve's step
 __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void image_adjoint2_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ FinSmem fin_sm;
-  constexpr bool tail = TAIL;
+  if (TAIL == 2 && g.img.skip && *g.img.skip) return;  // device-driven solve: finished
+  constexpr bool tail = TAIL != 0;
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads, NTAP = 4 * R + 1;
   constexpr int AW = TX + 4 * R, AH = TY + 4 * R, GH = TY + 2 * R;
   static_assert(NT == TX * TY, "one thread per tile pixel in the column pass");
@@ -1251,7 +1296,7 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
     }
   }
   }  // work loop
-  if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<NT>(a.tail.fin, fin_sm);
+  if (tail && tail_arrive(a.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<NT, TAIL == 2>(a.tail.fin, fin_sm);
 }
 
 // The same three phases for any blur radius (1 <= r <= kMaxRadius; sigma = 2, 3 -> r = 8, 12): loops over the taps at run
@@ -1262,6 +1307,7 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
 template <bool LIST>
 __global__ __launch_bounds__(kAdjThreads) void image_adjoint2g_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (g.img.skip && *g.img.skip) return;  // device-driven solve: finished
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads;
   const ImgArgs &a = g.img;
   const int W = a.W, H = a.H, r = a.r, ntap = 4 * r + 1;
@@ -1367,11 +1413,12 @@ void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hip
     const bool tail = a.img.tail.counters != nullptr;
     if (a.img.tile_list) {
       const dim3 gl(min(a.img.nblk, kTileListGrid));
-      if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, true, true>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
-      else CMX_LAUNCH((image_adjoint2_kernel<4, true, false>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
+      if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, true, 1>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else CMX_LAUNCH((image_adjoint2_kernel<4, true, 0>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
     } else {
-      if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, false, true>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
-      else CMX_LAUNCH((image_adjoint2_kernel<4, false, false>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      if (tail && a.img.tail.fin.chain.sm) CMX_LAUNCH((image_adjoint2_kernel<4, false, 2>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, false, 1>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else CMX_LAUNCH((image_adjoint2_kernel<4, false, 0>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
     }
     return;
   }
@@ -1425,10 +1472,13 @@ int fe_gather_blocks(int n) {
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
 }
 
+template <bool CHAIN>
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   if (g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
+  if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
   __shared__ double red[4 * 6];
   __shared__ FinSmem fin_sm;
+  if (CHAIN) fe_resolve_omega(g.ev);
   const FeSplatArgs &a = g.ev;
   double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
   constexpr int U = 2;  // events in flight per thread (swept on MI355X: 2 -> 11.9 us, 1 -> 12.2, 4 -> 12.9, 8 -> 14.9 per 1M events)
@@ -1525,12 +1575,13 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
     else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
-  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256>(g.tail.fin, fin_sm);
+  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256, CHAIN>(g.tail.fin, fin_sm);
 }
 
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int blocks = fe_gather_blocks(a.ev.n);
-  CMX_LAUNCH(fe_gather_kernel, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  else CMX_LAUNCH(fe_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
   return blocks;
 }
 

@@ -195,6 +195,10 @@ FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]) {
   a.lut = c->d_lut;
   a.lut2 = c->d_lut2;
   a.planes = c->d_accum;
+  if (c->chain_active) {  // device-driven solve: omega and the end-of-solve flag live in device memory
+    a.w_dev = c->d_chain->x_req;
+    a.skip = &c->d_chain->done;
+  }
   return a;
 }
 
@@ -228,7 +232,7 @@ bool adjoint_ok(const cmx_ctx *c) {  // G^T folding assumes single reflections: 
 // (arm_tail) -- which carries the ticket sync_and_collect() waits for
 void issue_finalize(cmx_ctx *c, FinalizeArgs &f, bool with_reduce) {
   f.ticket = ++c->ticket_issued;
-  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+  c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP) + (f.chain.sm ? kChainExtra : 0);
   Span sp(c, CMX_T_FINAL, /*exact=*/true);
   if (with_reduce) launch_finalize(f, c->stream, sp.t0(), sp.t1());
   else launch_finalize_only(f, c->stream, sp.t0(), sp.t1());
@@ -256,10 +260,10 @@ bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail, bool gated) {
   }
   if (gated) {  // the gated pass reports to the second result block with its own ticket sequence
     f.ticket = ++c->ticket2_issued;
-    c->ticket2_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+    c->ticket2_nout = 2 + (f.P > f.gP ? f.P : f.gP) + (f.chain.sm ? kChainExtra : 0);
   } else {
     f.ticket = ++c->ticket_issued;
-    c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP);
+    c->ticket_nout = 2 + (f.P > f.gP ? f.P : f.gP) + (f.chain.sm ? kChainExtra : 0);
   }
   tail.counters = c->d_tail_counters;
   tail.fin = f;
@@ -541,6 +545,14 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   f.partials = c->d_partials;
   f.sums = c->d_sums;
   f.result = phase == 4 ? c->d_result2 : result_ptr(c);
+  if (c->chain_active) {  // device-driven solve: this finalize advances the machine; results go to the slot's blocks of the ring
+    f.result = phase == 4 ? c->chain_block_g : c->chain_block_a;
+    f.chain.sm = &c->d_chain->sm;
+    f.chain.x_req = c->d_chain->x_req;
+    f.chain.done = &c->d_chain->done;
+    f.chain.stage = phase == 4 ? 1 : 0;
+    a.skip = &c->d_chain->done;
+  }
   if (!have_image) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
     rc = maybe_tile_list(c, a, 2 * c->radius);
     if (rc) return rc;
@@ -694,7 +706,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
 }
 
 // spin on a completion ticket in a mapped result block; true once a consistent snapshot carrying `want` has been read
-static bool spin_for_ticket(const double *h_block, unsigned long long want, int nout) {
+bool spin_for_ticket(const double *h_block, unsigned long long want, int nout) {
   const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(h_block);
   const auto t0 = std::chrono::steady_clock::now();
   bool done = false;

@@ -8,8 +8,7 @@
 
 #include <vector>
 
-#include "../../include/cmax_hip.h"
-#include "cmx_frcg_sm.hpp"
+#include "cmx_context.hpp"
 
 namespace {
 
@@ -53,29 +52,46 @@ void contrast_hint(double thr, int mode, void *p) {  // the line search's accept
   (void)cmx_hint_next_df(s->ctx, thr, mode);
 }
 
-// the driver loop shared by both ends (and by cmx_frcg_minimize for arbitrary functors): the state machine of cmx_frcg_sm.hpp
-// fed from the callbacks, one request at a time
-void drive(const cmx::FunctionFdf &user, double *x_inout, double initial_step_size, double tol, double epsabs_grad,
-           double tolfun, int num_max_line_searches, const int *err, cmx_solve_report *rep) {
-  const int n = (int)user.n;
-  std::vector<double> store((size_t)9 * n, 0.0), g((size_t)n, 0.0);
+// the FR-CG state machine of cmx_frcg_sm.hpp with host storage, fed from callbacks one request at a time: the driver loop
+// shared by both ends (and by cmx_frcg_minimize for arbitrary functors)
+struct Machine {
+  std::vector<double> store, g;
   cmx::FrcgSM s{};
-  double *v = store.data();
-  s.x = v; s.gradient = v + n; s.dx = v + 2 * n; s.x1 = v + 3 * n; s.dx1 = v + 4 * n; s.x2 = v + 5 * n; s.dx2 = v + 6 * n;
-  s.p = v + 7 * n; s.g0 = v + 8 * n;
-  for (int i = 0; i < n; i++) s.x[i] = x_inout[i];
-  cmx::sm_begin(s, n, initial_step_size, tol, epsabs_grad, tolfun, num_max_line_searches);
-  cmx::sm_step_host(s, user, g.data());  // gsl_multimin_fdfminimizer_set: "This call already evaluates the function"
-  while (!cmx::sm_done(s) && (!err || *err == CMX_OK)) cmx::sm_step_host(s, user, g.data());
-  for (int i = 0; i < n; i++) x_inout[i] = s.x[i];
-  if (rep) {
-    rep->iterations = s.iter;
-    rep->status = s.status;
-    rep->n_f = s.n_f;
-    rep->n_df = s.n_df;
-    rep->initial_cost = s.initial_cost;
-    rep->final_cost = s.f;
+  Machine(int n, const double *x0, double step, double tol, double epsabs_grad, double tolfun, int max_iter)
+      : store((size_t)9 * n, 0.0), g((size_t)n, 0.0) {
+    double *v = store.data();  // one contiguous block in the order cmx_chain.cpp / the device's finalize step expect
+    s.x = v; s.gradient = v + n; s.dx = v + 2 * n; s.x1 = v + 3 * n; s.dx1 = v + 4 * n; s.x2 = v + 5 * n; s.dx2 = v + 6 * n;
+    s.p = v + 7 * n; s.g0 = v + 8 * n;
+    for (int i = 0; i < n; i++) s.x[i] = x0[i];
+    cmx::sm_begin(s, n, step, tol, epsabs_grad, tolfun, max_iter);
   }
+  void run_host(const cmx::FunctionFdf &fn, const int *err) {
+    // a machine handed back in the middle of a point (the device-driven chain stopped between a cost and its gradient):
+    // the gradient at that very point comes first
+    if (s.phase == cmx::SM_TRIAL_G || s.phase == cmx::SM_IP_G || s.phase == cmx::SM_MIN_G) {
+      fn.df(cmx::sm_point(s), fn.params, g.data());
+      cmx::sm_grad(s, g.data());
+    }
+    while (!cmx::sm_done(s) && (!err || *err == CMX_OK)) cmx::sm_step_host(s, fn, g.data());
+  }
+  void report(double *x_out, cmx_solve_report *rep) const {
+    for (int i = 0; i < s.n; i++) x_out[i] = s.x[i];
+    if (rep) {
+      rep->iterations = s.iter;
+      rep->status = s.status;
+      rep->n_f = s.n_f;
+      rep->n_df = s.n_df;
+      rep->initial_cost = s.initial_cost;
+      rep->final_cost = s.f;
+    }
+  }
+};
+
+void drive(const cmx::FunctionFdf &user, double *x_inout, double initial_step_size, double tol, double epsabs_grad,
+           double tolfun, int num_max_line_searches, cmx_solve_report *rep) {
+  Machine m((int)user.n, x_inout, initial_step_size, tol, epsabs_grad, tolfun, num_max_line_searches);
+  m.run_host(user, nullptr);  // the first request is gsl_multimin_fdfminimizer_set's fdf: "This call already evaluates the function"
+  m.report(x_inout, rep);
 }
 
 int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double epsabs_grad, cmx_solve_report *rep) {
@@ -86,7 +102,14 @@ int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double
   st.g.assign((size_t)(n > 0 ? n : 1), 0.0);
   cmx::FunctionFdf fn{contrast_f, contrast_df, contrast_fdf, (size_t)n, &st};
   fn.hint = contrast_hint;
-  drive(fn, x_inout, 0.1, tol, epsabs_grad, 1e-4, 50, &st.err, rep);
+  Machine m(n, x_inout, 0.1, tol, epsabs_grad, 1e-4, 50);
+  bool completed = false;
+  if (!backend) {  // front end: the line search runs ahead of the host on the device as far as it goes (cmx_chain.cpp)
+    const int rc = chain_run_frontend(ctx, m.s, &completed);
+    if (rc != CMX_OK) return rc;
+  }
+  if (!completed) m.run_host(fn, &st.err);
+  m.report(x_inout, rep);
   return st.err;
 }
 
@@ -111,7 +134,7 @@ int cmx_frcg_minimize(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, void *params, in
                       double tol, double epsabs_grad, double tolfun, int max_iterations, cmx_solve_report *report) {
   if (!f || !df || !fdf || n <= 0 || !x) return CMX_ERR_INVALID_ARG;
   cmx::FunctionFdf fn{f, df, fdf, (size_t)n, params};
-  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, nullptr, report);
+  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, report);
   return CMX_OK;
 }
 
@@ -121,7 +144,7 @@ int cmx_frcg_minimize_hinted(cmx_f_fn f, cmx_df_fn df, cmx_fdf_fn fdf, cmx_hint_
   if (!f || !df || !fdf || n <= 0 || !x) return CMX_ERR_INVALID_ARG;
   cmx::FunctionFdf fn{f, df, fdf, (size_t)n, params};
   fn.hint = hint;
-  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, nullptr, report);
+  drive(fn, x, step_size, tol, epsabs_grad, tolfun, max_iterations, report);
   return CMX_OK;
 }
 

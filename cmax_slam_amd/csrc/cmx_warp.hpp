@@ -27,6 +27,11 @@ __device__ __forceinline__ void load_bearing(const Args &a, int ex, int ey, doub
   }
 }
 
+// device-driven solve: omega lives in device memory (uniform address: scalar loads)
+__device__ __forceinline__ void fe_resolve_omega(FeSplatArgs &a) {
+  if (a.w_dev) { a.wx = a.w_dev[0]; a.wy = a.w_dev[1]; a.wz = a.w_dev[2]; }
+}
+
 struct FeWarp {
   int xx, yy;
   float dx, dy;

@@ -104,6 +104,13 @@ enum {
                              deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
                              inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
                              0: separate per-batch kernel */
+  CMX_OPT_CHAIN_SOLVE = 11, /* 1 (default; front end, production path, no communicator): cmx_frontend_solve runs the FR-CG line
+                               search AHEAD of the host -- the optimiser's state machine lives in device memory, the finalize step
+                               of every evaluation advances it and writes the next evaluation point where the next evaluation's
+                               kernels (queued one slot ahead) read it; the host replays the machine on the reported costs /
+                               gradients and takes over on any disagreement, so the result is that of the host-driven solve.
+                               0: host-driven solve (one round trip to the host per evaluation); 2 / 3: test hooks -- the host takes
+                               over after three points / between a cost and its gradient, as it would after a disagreement */
   CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner
@@ -398,7 +405,8 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
  * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
- * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [11..15] reserved */
+ * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
+ * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement */
 #define CMX_N_STATS 16
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes

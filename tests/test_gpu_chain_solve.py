@@ -1,0 +1,98 @@
+"""-m gpu: the device-driven front-end solve (CMX_OPT_CHAIN_SOLVE, cmx_chain.cpp): the FR-CG state machine advances inside the
+finalize steps on the device, the host replays it on the reported costs / gradients.  The result must be that of the host-driven
+loop (src/frontend/local_optim_contrast_gsl.cpp:74-233 restated in cmx_frcg_sm.hpp) -- the evaluations themselves differ run to
+run by the order of the fp32 atomics, so the two are compared by what they reach, as tests/test_gpu_baseline_configs.py does; the
+hand-over paths (host takes over between two points / between a cost and its gradient) are forced through the test hooks."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import _lib, solver, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _fe(hip, p, chain, sigma=None, measure=_lib.VARIANCE):
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe.set_fast_path()
+    fe.set_option(_lib.OPT_CHAIN_SOLVE, chain)
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma if sigma is None else sigma, measure)
+    return fe
+
+
+def _close(a, b):
+    (xa, ra), (xb, rb) = a, b
+    assert abs(ra["final_cost"] - rb["final_cost"]) < 2e-3 * abs(rb["final_cost"]), (ra, rb)
+    assert np.abs(xa - xb).max() < 0.05, (xa, xb)
+    assert ra["initial_cost"] == pytest.approx(rb["initial_cost"], rel=1e-6)
+    assert ra["final_cost"] <= ra["initial_cost"]
+
+
+@pytest.mark.parametrize("n_events,W,H", [(100_000, 240, 180), (400_000, 640, 480)])
+def test_chain_solve_reaches_what_the_host_driven_solve_reaches(hip, oracle, n_events, W, H):
+    p = synth.frontend_packet(n_events, W, H, 0.9 * W, 0.9 * W, (W - 1) / 2, (H - 1) / 2, seed=77)
+    host = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
+    fe = _fe(hip, p, 1)
+    dev = fe.setupProblemAndOptimize(np.zeros(3))
+    st = fe.stats()
+    assert st["chain_solves"] == 1 and st["chain_takeovers"] == 0 and st["chain_slots"] >= dev[1]["n_f"] + 1
+    _close(dev, host)
+    assert abs(dev[1]["n_f"] - host[1]["n_f"]) <= 12 and dev[1]["iterations"] >= 2
+    # ... and what the same driver reaches over the CPU oracle
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+
+    def fdf(x, wg):
+        c, g = ref.eval(x, wg)
+        return -c, (-g if wg else None)
+    x_ref, rep_ref = solver.frcg_minimize(fdf, np.zeros(3), **solver.FRONTEND)
+    _close(dev, (x_ref, rep_ref))
+    # the context is usable as before: a plain evaluation, a second solve (warm start), a new packet
+    c, g = fe.eval(dev[0])
+    c_ref, g_ref = ref.eval(dev[0])
+    assert abs(c - c_ref) < 1e-5 * abs(c_ref) and np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()
+    again = fe.setupProblemAndOptimize(dev[0])
+    assert again[1]["final_cost"] <= dev[1]["final_cost"] * (1 - 1e-3) or again[1]["iterations"] <= 3
+    assert fe.stats()["chain_solves"] == 2
+
+
+@pytest.mark.parametrize("hook", [2, 3])
+def test_host_takes_over_mid_solve(hip, hook):
+    p = synth.frontend_packet(100_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=78)
+    host = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
+    fe = _fe(hip, p, hook)
+    dev = fe.setupProblemAndOptimize(np.zeros(3))
+    assert fe.stats()["chain_takeovers"] == 1
+    _close(dev, host)
+    assert dev[1]["n_f"] + dev[1]["n_df"] >= 6   # the solve went on after the hand-over
+    c0, _ = fe.eval(np.zeros(3), False)          # accumulators / counters were left clean
+    assert c0 == pytest.approx(-dev[1]["initial_cost"], rel=1e-6)
+
+
+@pytest.mark.parametrize("sigma,measure", [(0.0, _lib.VARIANCE), (0.5, _lib.VARIANCE), (2.0, _lib.VARIANCE), (1.0, _lib.MEAN_SQUARE)])
+def test_chain_solve_other_image_passes(hip, sigma, measure):
+    """Radius 0 / 2 / 8 take the general image kernels with a separate finalize launch (the machine's step runs there)."""
+    p = synth.frontend_packet(80_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=79)
+    host = _fe(hip, p, 0, sigma, measure).setupProblemAndOptimize(np.zeros(3))
+    fe = _fe(hip, p, 1, sigma, measure)
+    dev = fe.setupProblemAndOptimize(np.zeros(3))
+    assert fe.stats()["chain_solves"] == 1 and fe.stats()["chain_takeovers"] == 0
+    _close(dev, host)
+
+
+def test_chain_solve_back_to_back_packets_and_ineligible_configurations(hip):
+    fe = None
+    for k in range(4):
+        p = synth.frontend_packet(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=90 + k)
+        if fe is None:
+            fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+            fe.set_fast_path()
+        fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+        dev = fe.setupProblemAndOptimize(np.zeros(3))
+        host = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
+        _close(dev, host)
+    assert fe.stats()["chain_solves"] == 4 and fe.stats()["chain_takeovers"] == 0
+    # deterministic mode and the reference-shaped path are solved host-driven (and bitwise reproducibly in the former)
+    fe.set_deterministic(True)
+    a = fe.setupProblemAndOptimize(np.zeros(3))
+    b = fe.setupProblemAndOptimize(np.zeros(3))
+    assert fe.stats()["chain_solves"] == 4 and np.array_equal(a[0], b[0])

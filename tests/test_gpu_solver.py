@@ -33,7 +33,12 @@ def test_frontend_solve_matches_the_oracle_solve(hip, oracle, fast):
     assert rep["initial_cost"] == pytest.approx(rep_ref["initial_cost"], rel=1e-6)
     assert np.abs(x[:2] - p.omega_true[:2]).max() < 0.05
     if fast:
-        assert fe.stats()["reuse_hits"] >= rep["iterations"] - 1  # df after f at accepted points reused the image
+        assert fe.stats()["chain_solves"] == 1 and fe.stats()["chain_takeovers"] == 0   # the line search ran ahead on the device
+        from cmax_slam_amd import _lib
+        fe.set_option(_lib.OPT_CHAIN_SOLVE, 0)                                         # ... and host-driven: the same solve
+        x2, rep2 = fe.setupProblemAndOptimize(np.zeros(3))
+        assert abs(rep2["final_cost"] - rep_ref["final_cost"]) < 1e-3 * abs(rep_ref["final_cost"]) and np.abs(x2 - x_ref).max() < 0.02
+        assert fe.stats()["reuse_hits"] >= rep2["iterations"] - 1  # df after f at accepted points reused the image
 
 
 def test_frontend_solve_warm_start_never_worsens(hip):
