@@ -16,7 +16,7 @@ GRAD_PLANES, GRAD_ADJOINT = 0, 1
 DT_U8, DT_F32, DT_F64 = 0, 1, 2
 OP_SUM, OP_MAX = 0, 1
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
-OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE, OPT_FUSED_GATHER = 1, 2, 3, 4, 5, 6, 7
+OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE = 1, 2, 3, 4, 5, 6
 OPT_COMPOSITE_IMAGE, OPT_FOLD_BATCH, OPT_GATED_DF, OPT_CHAIN_SOLVE = 8, 9, 10, 11
 PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
 T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COMM, T_FINAL, T_BATCH, T_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8

@@ -39,7 +39,7 @@ int ensure_chain_buffers(cmx_ctx *c) {
 bool chain_eligible(const cmx_ctx *c) {
   return c->kind == KIND_FE && c->chain_solve && c->have_data && c->n_packed > 0 && c->splat_mode == 1 && adjoint_ok(c) &&
          !c->deterministic && !c->sharded() && !c->accum_external && !c->gsum_external && c->ticket_wait && c->tail_finalize == 1 &&
-         c->d_tail_counters && c->d_gacc && c->reuse_image && c->gated_df && !c->fused_gather && !c->timing &&
+         c->d_tail_counters && c->d_gacc && c->reuse_image && c->gated_df && !c->timing &&
          c->measure != CMX_GRADIENT_MAGNITUDE;
 }
 

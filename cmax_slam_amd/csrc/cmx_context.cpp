@@ -64,7 +64,7 @@ int upload_gt1(cmx_ctx *c) {
     int rc = ensure(c, dst, cap, (size_t)L);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(dst, v.data(), (size_t)L * sizeof(float), hipMemcpyHostToDevice));
-    if (r >= 1 && r <= kMaxRadius && L > 4 * r) {  // (front end: fused gather r = 2..4; both ends: image_adjoint2 / 2g)
+    if (r >= 1 && r <= kMaxRadius && L > 4 * r) {  // (both ends: image_adjoint2 / 2g)
       // banded composite operator M = G^T G of this axis: (M x)[q] = sum_i M[q][i] x[q - 2r + i], where
       // G[p][s] = sum_j taps[r+j] [reflect101(p+j) == s] is the REFLECT_101 blur (the forward pass of the image kernels)
       const int bw = 4 * r + 1;
@@ -369,9 +369,6 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_TAIL_FINALIZE:
       c->tail_finalize = value < 0 ? 0 : (value > 2 ? 2 : value);
       return CMX_OK;
-    case CMX_OPT_FUSED_GATHER:
-      c->fused_gather = value != 0;
-      return CMX_OK;
     case CMX_OPT_GATED_DF:
       c->gated_df = value != 0;
       c->gated_pending = false;
@@ -433,7 +430,6 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[5] = (double)c->sharded_host_syncs;
   stats[6] = (double)c->band_misses;
   stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
-  stats[8] = (double)c->fused_evals;
   stats[9] = (double)c->spec_images;
   stats[10] = (double)c->spec_hits;
   stats[11] = (double)c->gated_launches;

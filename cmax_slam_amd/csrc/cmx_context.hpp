@@ -104,14 +104,12 @@ struct cmx_ctx {
   size_t itilde_cap = 0;
   float *d_cx = nullptr, *d_cy = nullptr;  // G^T 1 = cx(x)*cy(y): column sums of the REFLECT_101 blur operator
   size_t cx_cap = 0, cy_cap = 0;
-  float *d_Mx = nullptr, *d_My = nullptr;  // banded G^T G per axis, [L][4r+1] (fused front-end gather: out-of-window votes)
+  float *d_Mx = nullptr, *d_My = nullptr;  // banded G^T G per axis, [L][4r+1] (composite image pass)
   size_t Mx_cap = 0, My_cap = 0;
   int Mx_radius = -1;                      // blur radius the tables were built for (-1: none)
   bool composite_image = true;             // CMX_OPT_COMPOSITE_IMAGE
   bool fold_batch = true;                  // CMX_OPT_FOLD_BATCH
   bool shard_acc = false;                  // set by cmx_comm.cpp around a split evaluation it all-reduces itself (see run_adjoint)
-  bool fused_gather = false;               // CMX_OPT_FUSED_GATHER (opt-in: measured slower on MI355X)
-  int64_t fused_evals = 0;                 // gradient evaluations that took the fused pass
   double *d_gpartials = nullptr;
   size_t gpartials_cap = 0;
   double *d_vparts = nullptr;  // back end: per-batch partial V sums of the gather pass

@@ -90,7 +90,6 @@ struct FinalizeArgs {
   int direct;              // 1: sum rows 0,1 of `partials` inside finalize (no reduce_partials launch)
   const unsigned *nvalid;  // direct mode: device count of valid entries per row (tile work list); null = nblk
   int mu_free;             // 1: gpartials rows hold [S1 (gP) | S2 (gP)], grad = (2/N)(S1 - mu*S2)
-  int moment_cols;         // 1: two more columns follow -- sum B^2, sum B -- and the image moments are taken from them
   unsigned long long ticket;  // written after the results to result[kTicketSlot]: the host polls it
   // tail finalize of the back-end gradient: instead of a [column][workgroup] table the per-batch pass adds its column sums to
   // kTailShards rows of accumulators (device-scope fp64 atomics, row = workgroup % kTailShards); the finalize sums the rows
@@ -245,28 +244,6 @@ struct BinnedEvents {
   const double *sdt;       // ... and its batch's dt: coalesced streams instead of two divergent table gathers per event
   unsigned long long *fixed;  // deterministic mode: 2^-30 fixed-point planes every global vote is added to (else nullptr)
 };
-
-// Fused front-end gradient pass (cmx_kernels.hip, fe_fused_gather_kernel): one workgroup per chunk of tile-ordered events
-// builds Jt = G^T G I on the chunk's 64x64 vote window in LDS (raw window + 2r halo from the vote plane) and gathers from
-// it -- no image_adjoint launch, no Jt plane, no kernel boundary between them; the image moments come from the same pass
-// (sum B = <I, G^T 1>, sum B^2 = <I, Jt>, both as sums over the events' votes).
-constexpr int kFusedMaxRadius = 6;  // radius up to which the banded operator tables are built; LDS of the kernel:
-                                    // (64+4r)^2 + (64+4r)*64 floats per workgroup (r = 4: 46 KB, three per CU)
-struct FeFusedArgs {
-  FeSplatArgs ev;          // camera, omega, vote plane (ev.planes)
-  BinnedEvents bin;        // chunk table + the tile-ordered bearing / dt streams (required)
-  int r;
-  const float *cx, *cy;    // G^T 1 factors (W and H floats)
-  const float *Mx, *My;    // banded composite operator G^T G per axis: [L][4r+1] (votes that left their window)
-  double *gpartials;       // [8][grid]: S1 (3), S2 (3), sum B^2, sum B
-  float *zero_ptr;         // ping-pong partner plane to clear (null: nothing to clear)
-  int nchunk_blocks;       // blocks [0, nchunk_blocks) walk the chunk table, blocks beyond clear one 32x32 tile each
-  int zero_tiles_x;
-  TailArgs tail;
-};
-size_t fe_fused_lds_bytes(int r);
-bool fe_fused_radius_ok(int r);  // radii the kernel is instantiated for (sigma 0.5 .. 1: r = 2, 3, 4)
-int launch_fe_fused_gather(const FeFusedArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the grid size
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
 void launch_fe_bin_keys(const FeSplatArgs &a, int tiles_x, int ntiles, uint32_t *keys, uint32_t *idx, hipStream_t s);

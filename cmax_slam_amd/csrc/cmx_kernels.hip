@@ -494,7 +494,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     // matters is how many are in flight.  Many rows, few columns (front end: ~1000 x 6): all threads stride over the rows
     // with one accumulator per column -- every thread's loads go out in one round.  Few rows, many columns (back end:
     // ~200 x 42): each wave takes whole columns, four at a time.
-    const int ncol = (a.mu_free ? 2 * a.gP : a.gP) + (a.moment_cols ? 2 : 0);
+    const int ncol = a.mu_free ? 2 * a.gP : a.gP;
     if (a.gP > 0 && ncol <= 8) {
       double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int b0 = 0; b0 < a.gblocks; b0 += 2 * NT) {
@@ -553,13 +553,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     }
     __syncthreads();
   }
-  if (a.moment_cols) {  // fused front-end pass: sum B^2 and sum B arrive as two more columns of the gather table
-    if (t == 0) {
-      const int base = a.mu_free ? 2 * a.gP : a.gP;
-      sm.sh[1] = sm.cols[base];
-      sm.sh[0] = sm.cols[base + 1];
-    }
-  } else if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
+  if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
     // this is ONE workgroup reading tables other CUs just wrote (L2-remote): keep many independent loads in flight
     const int row = wave & 1, part = wave >> 1;
     double p = 0;
@@ -1583,250 +1577,6 @@ int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEve
   if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
   else CMX_LAUNCH(fe_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
   return blocks;
-}
-
-// ---------------------------------------------------------------------------------------------- fused front-end pass
-// One workgroup per chunk of tile-ordered events (the chunk table of the LDS splat): Jt = G^T G I on the chunk's 64x64
-// vote window is built in LDS from the vote plane (window + 2r halo), then the chunk's events are re-warped and gather
-// from it.  Replaces image_adjoint + fe_gather (two launches, one boundary, one plane written and re-read) in the
-// gradient evaluation of the front end.  The image moments come from the same pass:
-//     sum B   = <I, G^T 1> = sum over votes  w_c * c(p_c)          (c = cx(x) cy(y), 1 in the interior)
-//     sum B^2 = <I, G^T G I> = sum over votes  w_c * Jt(p_c)
-// G^T G is applied as ONE banded operator per axis, M = G^T G with rows Mx[x][0..4r] / My[y][0..4r] built on the host from
-// the REFLECT_101 blur matrix (cmx_context.cpp: reflections and the restriction to the image are inside the rows, every
-// interior row is the 4r+1-tap autocorrelation of the Gaussian): two passes instead of the four of image_adjoint_kernel,
-// and a form that can be register-blocked -- the four-pass scalar version of this window (one LDS read per tap) took
-// 60 us for 651 windows; here a thread produces 4 (row pass) / 4x4 (column pass) outputs from 16-byte LDS reads with its
-// coefficient rows in registers.  LDS: X = raw window (64+4r)^2, T = row pass (64+4r) x 64; Jt (64 x 64) reuses X.
-// Votes that left their window (parameters drifted since the tile sort) apply the same operator at their four pixels
-// directly on the vote plane: exact for any parameters, ~300 loads per vote, rare by policy (host side).
-size_t fe_fused_lds_bytes(int r) {
-  const size_t aw = 64 + 4 * r;
-  return sizeof(float) * (aw * aw + aw * 64) + sizeof(double) * 32;
-}
-
-__device__ __forceinline__ float jt_direct(const FeFusedArgs &g, int x, int y) {
-  const int W = g.ev.W, H = g.ev.H, r2 = 2 * g.r, nb = 4 * g.r + 1;
-  const float *mx = g.Mx + (size_t)x * nb, *my = g.My + (size_t)y * nb;
-  float s = 0.f;
-  for (int j = 0; j < nb; j++) {
-    const int yy = y - r2 + j;
-    if (yy < 0 || yy >= H) continue;
-    const float *I = g.ev.planes + (size_t)yy * W;
-    float row = 0.f;
-    for (int i = 0; i < nb; i++) {
-      const int xx = x - r2 + i;
-      if (xx >= 0 && xx < W) row += mx[i] * I[xx];
-    }
-    s += my[j] * row;
-  }
-  return s;
-}
-
-template <int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void fe_fused_gather_kernel(FeFusedArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int NT = 256, TW = 64, AW = TW + 4 * R, NTAP = 4 * R + 1, NIN = 4 + 4 * R;
-  static_assert(AW % 4 == 0, "16-byte LDS rows");
-  float *X = reinterpret_cast<float *>(smem_raw);       // raw window AW x AW, later Jt TW x TW
-  float *T = X + AW * AW;                               // row pass AW x TW
-  double *red = reinterpret_cast<double *>(T + AW * TW);
-  const FeSplatArgs &a = g.ev;
-  const int tid = threadIdx.x, W = a.W, H = a.H;
-  double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0}, s0 = 0, sb = 0;
-  const int blk = (int)blockIdx.x;
-  if (blk >= g.nchunk_blocks) {
-    if (g.zero_ptr) {  // clear one 32x32 tile of the ping-pong partner (nobody reads or writes it during this launch)
-      const int z = blk - g.nchunk_blocks;
-      const int zx = (z % g.zero_tiles_x) * 32, zy = (z / g.zero_tiles_x) * 32;
-      for (int q = tid; q < 1024; q += NT) {
-        const int x = zx + (q & 31), y = zy + (q >> 5);
-        if (x < W && y < H) g.zero_ptr[(size_t)y * W + x] = 0.f;
-      }
-    }
-  } else if (blk < *g.bin.nchunks_dev) {
-    const Chunk c = g.bin.chunks[blk];
-    const bool has_win = c.wx0 > -100000000;
-    const int x0 = c.wx0, y0 = c.wy0;
-    if (has_win) {
-      const int xg = tid & 15, yq = tid >> 4;  // this thread's column group (4 columns) and row phase / row group
-      // ---- raw window + 2r halo, zero beyond the image (the operator rows carry the reflections)
-      if ((W & 3) == 0 && ((x0 - 2 * R) & 3) == 0) {  // 16-byte loads: rows of the plane and the window start are 16-byte aligned
-        for (int idx = tid; idx < AW * (AW / 4); idx += NT) {
-          const int ly = idx / (AW / 4), q4 = idx - ly * (AW / 4);
-          const int gx = x0 + 4 * q4 - 2 * R, gy = y0 + ly - 2 * R;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (gx >= 0 && gx + 3 < W && gy >= 0 && gy < H) v = *reinterpret_cast<const float4 *>(a.planes + (size_t)gy * W + gx);
-          *reinterpret_cast<float4 *>(X + ly * AW + 4 * q4) = v;
-        }
-      } else {
-        for (int idx = tid; idx < AW * AW; idx += NT) {
-          const int ly = idx / AW, lx = idx - ly * AW;
-          const int gx = x0 + lx - 2 * R, gy = y0 + ly - 2 * R;
-          X[idx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? a.planes[(size_t)gy * W + gx] : 0.f;
-        }
-      }
-      // ---- row pass: T[ly][lx] = sum_i Mx[x0+lx][i] * X[ly][lx+i]; this thread: columns 4xg..4xg+3, rows yq, yq+16, ...
-      // Every operator row at least 2r away from the image border is the same 4r+1-tap kernel: a window that stays that
-      // far inside reads ONE row through the scalar path; only border windows fetch a row per column (divergent loads)
-      float cf[4][NTAP];
-      if (x0 >= 2 * R && x0 + TW - 1 <= W - 1 - 2 * R) {
-        const float *row = g.Mx + (size_t)(2 * R) * NTAP;  // wave-uniform address: scalar loads
-#pragma unroll
-        for (int i = 0; i < NTAP; i++) {
-          const float k = row[i];
-          cf[0][i] = k; cf[1][i] = k; cf[2][i] = k; cf[3][i] = k;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int gx = min(max(x0 + 4 * xg + q, 0), W - 1);  // (columns beyond the image: any row, their outputs are never read)
-#pragma unroll
-          for (int i = 0; i < NTAP; i++) cf[q][i] = g.Mx[(size_t)gx * NTAP + i];
-        }
-      }
-      __syncthreads();
-      for (int ly = yq; ly < AW; ly += 16) {
-        float in[NIN];
-        const float4 *src = reinterpret_cast<const float4 *>(X + ly * AW + 4 * xg);
-#pragma unroll
-        for (int q = 0; q < NIN / 4; q++) {
-          const float4 v = src[q];
-          in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
-        }
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          float s = cf[q][0] * in[q];
-#pragma unroll
-          for (int i = 1; i < NTAP; i++) s += cf[q][i] * in[q + i];
-          o[q] = s;
-        }
-        *reinterpret_cast<float4 *>(T + ly * TW + 4 * xg) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-      // ---- column pass: Jt[ly][lx] = sum_j My[y0+ly][j] * T[ly+j][lx]; this thread: the 4x4 block at (4yq, 4xg)
-      if (y0 >= 2 * R && y0 + TW - 1 <= H - 1 - 2 * R) {
-        const float *row = g.My + (size_t)(2 * R) * NTAP;
-#pragma unroll
-        for (int i = 0; i < NTAP; i++) {
-          const float k = row[i];
-          cf[0][i] = k; cf[1][i] = k; cf[2][i] = k; cf[3][i] = k;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int gy = min(max(y0 + 4 * yq + q, 0), H - 1);
-#pragma unroll
-          for (int i = 0; i < NTAP; i++) cf[q][i] = g.My[(size_t)gy * NTAP + i];
-        }
-      }
-      __syncthreads();
-      float o[4][4];
-#pragma unroll
-      for (int d = 0; d < 4; d++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) o[d][q] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NIN; j++) {
-        const float4 v = *reinterpret_cast<const float4 *>(T + (4 * yq + j) * TW + 4 * xg);
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const int i = j - d;  // tap of output row d that meets input row j
-          if (i >= 0 && i < NTAP) {
-            o[d][0] += cf[d][i] * v.x; o[d][1] += cf[d][i] * v.y; o[d][2] += cf[d][i] * v.z; o[d][3] += cf[d][i] * v.w;
-          }
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < 4; d++)  // X is dead since the barrier above: Jt goes there
-        *reinterpret_cast<float4 *>(X + (4 * yq + d) * TW + 4 * xg) = make_float4(o[d][0], o[d][1], o[d][2], o[d][3]);
-      __syncthreads();
-    }
-    constexpr int U = 2;
-    for (int j0 = c.beg + tid; j0 < c.end; j0 += NT * U) {
-      bool act[U];
-      double px[U], py[U], dt[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = j0 + u * NT;
-        act[u] = j < c.end;
-        const int jj = act[u] ? j : c.beg;
-        const double2 v = *reinterpret_cast<const double2 *>(g.bin.sb + 2 * (size_t)jj);
-        px[u] = v.x; py[u] = v.y;
-        dt[u] = g.bin.sdt[jj];
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const FeWarp w = fe_warp_math<true>(a, px[u], py[u], 1.0, dt[u]);
-        if (act[u] && w.ok) {
-          const int lx = w.xx - x0, ly = w.yy - y0;
-          float i00, i01, i10, i11;
-          if (has_win && lx >= 0 && lx < TW - 1 && ly >= 0 && ly < TW - 1) {
-            const float *q = X + ly * TW + lx;
-            i00 = q[0]; i01 = q[1]; i10 = q[TW]; i11 = q[TW + 1];
-          } else {  // the vote left its window: the same operator at its four pixels, straight from the vote plane
-            i00 = jt_direct(g, w.xx, w.yy); i01 = jt_direct(g, w.xx + 1, w.yy);
-            i10 = jt_direct(g, w.xx, w.yy + 1); i11 = jt_direct(g, w.xx + 1, w.yy + 1);
-          }
-          const float dx = w.dx, dy = w.dy;
-          const float A = (1.f - dy) * (i01 - i00) + dy * (i11 - i10);
-          const float B = (1.f - dx) * (i10 - i00) + dx * (i11 - i01);
-#pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] += (double)w.r0[k] * (double)A + (double)w.r1[k] * (double)B;
-          // the four fp32 vote weights, as the splat forms them
-          const float w00 = (1.f - dx) * (1.f - dy), w01 = dx * (1.f - dy), w10 = (1.f - dx) * dy, w11 = dx * dy;
-          s0 += (double)w00 * (double)i00 + (double)w01 * (double)i01 + (double)w10 * (double)i10 + (double)w11 * (double)i11;
-          if (w.xx <= R || w.xx + 1 >= W - 1 - R || w.yy <= R || w.yy + 1 >= H - 1 - R) {  // border band: c = G^T 1 differs from 1
-            const float c00 = g.cx[w.xx] * g.cy[w.yy], c01 = g.cx[w.xx + 1] * g.cy[w.yy], c10 = g.cx[w.xx] * g.cy[w.yy + 1],
-                        c11 = g.cx[w.xx + 1] * g.cy[w.yy + 1];
-            const float Ac = (1.f - dy) * (c01 - c00) + dy * (c11 - c10);
-            const float Bc = (1.f - dx) * (c10 - c00) + dx * (c11 - c01);
-#pragma unroll
-            for (int k = 0; k < 3; k++) acc2[k] += (double)w.r0[k] * (double)Ac + (double)w.r1[k] * (double)Bc;
-            sb += (double)w00 * (double)c00 + (double)w01 * (double)c01 + (double)w10 * (double)c10 + (double)w11 * (double)c11;
-          } else {
-            sb += ((double)w00 + (double)w01) + ((double)w10 + (double)w11);
-          }
-        }
-      }
-    }
-  }
-  // [column][block] partial table: S1 (3), S2 (3), sum B^2, sum B -- one barrier for all eight sums
-  double v[8];
-#pragma unroll
-  for (int k = 0; k < 3; k++) v[k] = wave_sum(acc[k]);
-  const bool any2 = __any(acc2[0] != 0.0 || acc2[1] != 0.0 || acc2[2] != 0.0);
-#pragma unroll
-  for (int k = 0; k < 3; k++) v[3 + k] = any2 ? wave_sum(acc2[k]) : 0.0;
-  v[6] = wave_sum(s0);
-  v[7] = wave_sum(sb);
-  const int wave = tid >> 6, lane = tid & 63;
-  __syncthreads();  // every thread is done with X: the finalize scratch may alias it from here on
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
-  }
-  __syncthreads();
-  const bool tail = g.tail.counters != nullptr;
-  if (tid < 8) {
-    const double t = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
-    if (tail) st_sc1(g.gpartials + (size_t)tid * gridDim.x + blk, t);
-    else g.gpartials[(size_t)tid * gridDim.x + blk] = t;
-  }
-  FinSmem &fin_sm = *reinterpret_cast<FinSmem *>(smem_raw);
-  if (tail && tail_arrive(g.tail, (int)gridDim.x, blk, fin_sm)) finalize_body<NT>(g.tail.fin, fin_sm);
-}
-
-bool fe_fused_radius_ok(int r) { return r == 2 || r == 3 || r == 4; }
-int launch_fe_fused_gather(const FeFusedArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  const int zero_tiles = a.zero_ptr ? a.zero_tiles_x * ((a.ev.H + 31) / 32) : 0;
-  const int grid = a.nchunk_blocks + zero_tiles;
-  if (grid <= 0 || !fe_fused_radius_ok(a.r)) return 0;
-  const size_t lds = fe_fused_lds_bytes(a.r);
-  if (a.r == 4) CMX_LAUNCH((fe_fused_gather_kernel<4>), dim3(grid), dim3(256), lds, s, t0, t1, a);
-  else if (a.r == 3) CMX_LAUNCH((fe_fused_gather_kernel<3>), dim3(grid), dim3(256), lds, s, t0, t1, a);
-  else CMX_LAUNCH((fe_fused_gather_kernel<2>), dim3(grid), dim3(256), lds, s, t0, t1, a);
-  return grid;
 }
 
 // back end: per event V = (dItilde/dx, dItilde/dy) * dpm_ddrot (3-vector); events of one batch share the 3x3N

@@ -254,7 +254,7 @@ bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail, bool gated) {
     f.gacc_stride = kGaccStride;
   }
   // front end: the same accumulators instead of the ~1000 x 6 table (gather + tail 14.9 -> 13.2 us); value 2 keeps the table
-  if (c->kind == KIND_FE && f.gP > 0 && !f.moment_cols && c->tail_finalize < 2 && !c->deterministic && c->d_gacc) {
+  if (c->kind == KIND_FE && f.gP > 0 && c->tail_finalize < 2 && !c->deterministic && c->d_gacc) {
     f.gacc = c->d_gacc;
     f.gacc_stride = kGaccStride;
   }
@@ -414,71 +414,20 @@ int run_image_and_finalize(cmx_ctx *c, int P, float *out_blur0, float *out_blurd
   return CMX_OK;
 }
 
-// adjoint gradient: fused image pass (B = G*A with its moments, Jt = G^T B^) -> gather over the events (S1, and S2 for
-// the votes next to the border) -> finalize: contrast from the moments, grad = (2/N)(S1 - mu*S2).
-// phase 0 = everything; 1 = up to the per-rank partial sums (d_gsum, 2P doubles); 2 = finalize from d_gsum.
-// Front end, whole evaluation on this GPU: the gradient pass with the image pass fused in (fe_fused_gather_kernel).
-// Only while the tile sort still fits the parameters: votes that left their window cost ~300 loads each there.
-static bool use_fused_gather(const cmx_ctx *c, int phase) {
-  return c->kind == KIND_FE && phase == 0 && c->fused_gather && c->splat_mode == 1 && c->bin_valid && c->streams_valid &&
-         c->last_used_lds && !c->deterministic && !c->sharded() && !c->accum_external && fe_fused_radius_ok(c->radius) && c->Mx_radius == c->radius && c->d_Mx &&
-         c->d_My && c->n_packed > 0 && c->nchunks > 0 && c->last_fallback_frac <= 0.02 && c->measure != CMX_GRADIENT_MAGNITUDE;
-}
-
-static int run_fused_gather(cmx_ctx *c) {
-  const int W = c->imgW, H = c->imgH;
-  FeFusedArgs g{};
-  g.ev = fe_args(c, c->last_x);
-  g.bin = binned(c);
-  g.r = c->radius;
-  g.cx = c->d_cx; g.cy = c->d_cy;
-  g.Mx = c->d_Mx; g.My = c->d_My;
-  g.nchunk_blocks = c->nchunks;
-  g.zero_tiles_x = (W + 31) / 32;
-  if (c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
-    g.zero_ptr = c->d_accum_alt;  // (front end: one plane)
-    c->alt_clean = true;          // stream-ordered: clean by the time the next accumulate's splat runs
-  }
-  const int grid = g.nchunk_blocks + (g.zero_ptr ? g.zero_tiles_x * ((H + 31) / 32) : 0);
-  int rc = ensure(c, c->d_gpartials, c->gpartials_cap, (size_t)8 * grid);
-  if (rc) return rc;
-  g.gpartials = c->d_gpartials;
-  FinalizeArgs f{};
-  f.P = 0;
-  f.measure = c->measure;
-  f.npix = (double)W * H;
-  f.result = result_ptr(c);
-  f.gpartials = c->d_gpartials;
-  f.gblocks = grid;
-  f.gP = 3;
-  f.mu_free = 1;
-  f.moment_cols = 1;
-  f.direct = 1;  // (no reduce_partials pass: the moments are columns of the same table)
-  f.fallback = c->d_fallback;
-  bool tailed;
-  {
-    Span sp(c, CMX_T_GATHER, /*exact=*/true);
-    tailed = arm_tail(c, f, g.tail);
-    launch_fe_fused_gather(g, c->stream, sp.t0(), sp.t1());
-  }
-  if (!tailed) issue_finalize(c, f, false);
-  HIP_TRY(c, hipGetLastError());
-  c->fused_evals++;
-  return CMX_OK;
-}
-
 // A cost-only evaluation that a gradient evaluation at the same parameters is likely to follow (the optimiser's f-then-df
 // pattern, CMX_OPT_REUSE_IMAGE): run the fused adjoint image pass instead of the moments-only pass, so that the df finds
 // Jt and the moment rows ready and launches its gather straight away (phase 3 of run_adjoint; +3..4 us per f, -12 us per df).
 bool speculative_jt_ok(const cmx_ctx *c) {
-  return c->reuse_image && adjoint_ok(c) && !c->accum_external && !c->sharded() && c->last_P == 0 && c->n_packed > 0 &&
-         !(c->fused_gather && use_fused_gather(c, 0));
+  return c->reuse_image && adjoint_ok(c) && !c->accum_external && !c->sharded() && c->last_P == 0 && c->n_packed > 0;
 }
 
+// adjoint gradient: fused image pass (B = G*A with its moments, Jt = G^T B^) -> gather over the events (S1, and S2 for
+// the votes next to the border) -> finalize: contrast from the moments, grad = (2/N)(S1 - mu*S2).
+// phase 0 = everything; 1 = up to the per-rank partial sums (d_gsum, 2P doubles); 2 = finalize from d_gsum.
+// (3: image pass + cost-only finalize, Jt kept; 4: the gated gradient pass behind it.)
 int run_adjoint(cmx_ctx *c, int P, int phase) {
   const int W = c->imgW, H = c->imgH;
   const size_t np = (size_t)W * H;
-  if (phase != 3 && use_fused_gather(c, phase)) return run_fused_gather(c);
   // image pass already done for these very planes (phase 2: by finish_begin; phase 0 after a speculative cost-only pass)
   // phase 4: the gated gradient pass queued behind a cost-only evaluation (phase 3) of the same point -- gather + tail finalize
   // into the second result block, running only if that evaluation's finalize opens the gate (cmx_hint_next_df)

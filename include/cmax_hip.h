@@ -86,14 +86,7 @@ enum {
                              gradient evaluations keep the separate launch (the 42-column table made the tail slower).
                              2: tail with the table form everywhere (back-end gradient included).
                              0: separate finalize launch (the round-1 flow) */
-  CMX_OPT_FUSED_GATHER = 7, /* 1 (default 0; front end, adjoint gradient, LDS-privatised splat, blur radius 2..4, no communicator,
-                             not deterministic): the gradient pass builds Jt = G^T G I on each chunk's 64x64 vote window in
-                             LDS (banded composite operator, register-blocked) and gathers from it -- the image_adjoint launch,
-                             its kernel boundary and the Jt plane disappear, the image moments come out of the same pass.
-                             Votes that left their window apply the operator directly on the vote plane; above 2 % of such
-                             votes an evaluation takes the separate-image-pass flow.  Exact, tested, and SLOWER on MI355X at
-                             BASELINE config 2 (45.9 vs 41.5 us per fdf: 651 windows of 64x64 are 8.7x the pixels of the one
-                             image pass), hence opt-in */
+  /* 7: retired (round 2's opt-in fused gradient pass: measured slower, removed; profiles/r02_pmc_fe_fused_gather.txt) */
   CMX_OPT_COMPOSITE_IMAGE = 8, /* 1 (default): the image pass of the adjoint gradient applies G^T G as one banded operator per
                              axis, its 4r+1-term sums accumulated in fp64: three barrier-separated phases per tile instead
                              of five (radius 4 = the reference's blur_sigma 1 has a register-resident form), and a gradient
@@ -404,7 +397,7 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane), [8] = gradient evaluations that took the fused front-end pass (CMX_OPT_FUSED_GATHER), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
+ * (-1: whole plane), [8] = reserved, [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
  * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement */
 #define CMX_N_STATS 16

@@ -84,9 +84,7 @@ def main():
             kv[k] = int(v)
     variants = [("default", {})]
     if "variants" in kv:
-        variants = [("fused=1 tail=1", {_lib.OPT_FUSED_GATHER: 1, _lib.OPT_TAIL_FINALIZE: 1}),
-                    ("fused=0 tail=1", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 1}),
-                    ("fused=0 tail=0", {_lib.OPT_FUSED_GATHER: 0, _lib.OPT_TAIL_FINALIZE: 0})]
+        variants = [("tail=1", {_lib.OPT_TAIL_FINALIZE: 1}), ("tail=0", {_lib.OPT_TAIL_FINALIZE: 0})]
     if "composite" in kv:
         variants = [("composite=0", {_lib.OPT_COMPOSITE_IMAGE: 0}), ("composite=1", {_lib.OPT_COMPOSITE_IMAGE: 1}),
                     ("composite=0", {_lib.OPT_COMPOSITE_IMAGE: 0}), ("composite=1", {_lib.OPT_COMPOSITE_IMAGE: 1})]
