@@ -457,6 +457,7 @@ def cmax_solves(n_solves, ev, kind, _lib):
     start (front end: omega = 0; back end: zero increments on the perturbed knots), image reuse on as in production."""
     ev.set_option(_lib.OPT_REUSE_IMAGE, 1)
     iters = evals = 0
+    (ev.setupProblemAndOptimize(np.zeros(3)) if kind == "frontend" else ev.setupProblemAndOptimize())  # one untimed solve (warm-up)
     s0 = ev.stats()
     t0 = time.perf_counter()
     for _ in range(n_solves):
@@ -472,7 +473,12 @@ def cmax_solves(n_solves, ev, kind, _lib):
             # gradient evaluations that found the resident image (df after f) / that found their result already in flight
             # (the gradient pass gated on the device behind the cost-only evaluation, cmx_hint_next_df), per solve
             "df_on_resident_image_per_solve": (s1["spec_hits"] - s0["spec_hits"]) / n_solves,
-            "df_served_in_flight_per_solve": (s1["gated_hits"] - s0["gated_hits"]) / n_solves}
+            "df_served_in_flight_per_solve": (s1["gated_hits"] - s0["gated_hits"]) / n_solves,
+            # solves whose line search ran ahead of the host on the device (CMX_OPT_CHAIN_SOLVE; front end), slots they queued,
+            # solves the host took over after a disagreement with the device's machine
+            "device_driven_solves": s1["chain_solves"] - s0["chain_solves"],
+            "device_driven_slots_per_solve": (s1["chain_slots"] - s0["chain_slots"]) / n_solves,
+            "host_takeovers": s1["chain_takeovers"] - s0["chain_takeovers"]}
 
 
 def per_packet_pipeline(device, which, n_packets=8):
@@ -701,7 +707,7 @@ def main():
                     help="fast = adjoint gradient + LDS-privatised splat (production path); faithful = derivative planes + "
                          "one global atomic per vote (the reference's data flow)")
     ap.add_argument("--comm", default="native", choices=["native", "torch"])
-    ap.add_argument("--solves", type=int, default=5, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
+    ap.add_argument("--solves", type=int, default=20, help="FR-CG solves timed for the CMax iters/s figure (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-packet", action="store_true", help="N=1: skip the per-packet pipeline measurement")
     ap.add_argument("--no-backend", action="store_true", help="N=1: skip the nested config-3 leg")

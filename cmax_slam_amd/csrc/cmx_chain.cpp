@@ -80,6 +80,8 @@ bool same_bits(const double *a, const double *b, int n) { return memcmp(a, b, si
 
 }  // namespace
 
+int chain_prealloc(cmx_ctx *c) { return ensure_chain_buffers(c); }
+
 int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   *completed = false;
   if (!c || !chain_eligible(c) || hs.n != 3) return CMX_OK;

@@ -14,6 +14,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -31,6 +33,8 @@ RcclApi &rccl() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");  // optional: fuses the per-plane band collectives
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
     return a;
   }();
@@ -38,6 +42,8 @@ RcclApi &rccl() {
 }
 int comm_allreduce(cmx_ctx *c, void *buf, size_t count, int dt /* CMX_DT_* */, int op = CMX_OP_SUM) {
   if (!c->sharded() || count == 0) return CMX_OK;
+  c->comm_bytes_eval += (int64_t)count * (dt == CMX_DT_U8 ? 1 : (dt == CMX_DT_F32 ? 4 : 8));
+  c->comm_calls_eval++;
   Span sp(c, CMX_T_COMM);  // on the stream: the collective itself plus the wait for the slowest rank
   if (c->comm_fn) {
     const int r = c->comm_fn(c->comm_user, buf, count, dt, op, (void *)c->stream);
@@ -68,11 +74,15 @@ static int allreduce_rows(cmx_ctx *c, int tile_row0, int tile_row1 /* exclusive 
   const size_t np = (size_t)c->Wp * c->Hp;
   const size_t row0 = (size_t)tile_row0 * kTileY, row1 = std::min((size_t)tile_row1 * kTileY, (size_t)c->Hp);
   if (row1 <= row0) return CMX_OK;
-  for (int plane = 0; plane < 2; plane++) {
-    int rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, CMX_DT_F32);
-    if (rc) return rc;
-  }
-  return CMX_OK;
+  // the two planes' bands are two regions of memory: one RCCL group = one launch instead of two (native communicator only;
+  // a caller-supplied transport sees the two calls)
+  const bool group = c->comm && rccl().GroupStart && rccl().GroupEnd;
+  if (group) rccl().GroupStart();
+  int rc = CMX_OK;
+  for (int plane = 0; plane < 2 && !rc; plane++)
+    rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, CMX_DT_F32);
+  if (group && rccl().GroupEnd() != ncclSuccess && !rc) rc = fail(c, CMX_ERR_HIP, "ncclGroupEnd failed");
+  return rc;
 }
 static int exchange_planes(cmx_ctx *c) {
   const size_t np = (size_t)c->Wp * c->Hp;
@@ -138,6 +148,8 @@ static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad
 // evaluation with an attached communicator: the two exchange points of SURVEY.md section 8e, in place, on the stream
 int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double *grad) {
   int rc = CMX_OK;
+  c->comm_bytes_eval = 0;  // what THIS evaluation exchanges (cmx_get_stats [8], [9]... see the header)
+  c->comm_calls_eval = 0;
   c->gate_mode = 0;  // (no gated pass with a communicator attached: a hint must not outlive this evaluation)
   c->gated_pending = false;
   if (exchange) {

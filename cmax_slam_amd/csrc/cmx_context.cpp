@@ -430,6 +430,7 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[5] = (double)c->sharded_host_syncs;
   stats[6] = (double)c->band_misses;
   stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
+  stats[8] = (double)c->comm_bytes_eval;
   stats[9] = (double)c->spec_images;
   stats[10] = (double)c->spec_hits;
   stats[11] = (double)c->gated_launches;

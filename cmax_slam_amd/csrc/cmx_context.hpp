@@ -222,6 +222,7 @@ struct cmx_ctx {
   unsigned long long band_seq = 0; // sequence number of that launch (stamped into the result, see kBandSlot)
   int band_used_lo = 0, band_used_hi = -1;  // what that evaluation actually exchanged (whole plane: 0 .. tiles_y-1)
   int64_t sharded_host_syncs = 0, band_misses = 0;
+  int64_t comm_bytes_eval = 0, comm_calls_eval = 0;  // bytes / collectives of the last sharded evaluation
 
   // timing
   bool timing = false;
@@ -343,6 +344,7 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes);  // cmx_front
 // on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
 // host-driven from hs (configuration not eligible, or the device's next point was not bitwise the host's)
 int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed);
+int chain_prealloc(cmx_ctx *c);  // the chain's device / mapped buffers (front-end contexts: at creation, so that no solve pays for them)
 int finish_begin(cmx_ctx *c, int kind, int want_grad);
 int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
 int be_ensure_time_bearings(cmx_ctx *c);  // cmx_backend.cpp: the gather's time-ordered bearing stream (once per window)

@@ -7,7 +7,7 @@ int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *l
   if (rc) return rc;
   (*out)->imgW = W;
   (*out)->imgH = H;
-  return CMX_OK;
+  return chain_prealloc(*out);
 }
 
 // d_raw != nullptr: the events are already on the device (event store), x / y are unused and t_ns is the store's

@@ -397,7 +397,7 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane), [8] = reserved, [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
+ * (-1: whole plane), [8] = bytes the last sharded evaluation exchanged (all collectives, this rank's buffers), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
  * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement */
 #define CMX_N_STATS 16

@@ -119,6 +119,11 @@ def test_two_ranks_large_panorama_band_exchange_and_recovery(hip):
     s = evs[0].stats()
     tiles_y = (w.Hp + 15) // 16
     assert 0 < s["band_rows"] < tiles_y // 2 and s["band_misses"] == 0 and s["sharded_host_syncs"] == 0
+    # bytes the last (banded, cost-only) evaluation exchanged: the tile flags + a band of both planes -- a fraction of the
+    # 2 x 32 MB the whole planes would have been; both ranks count the same
+    plane_bytes = w.Wp * w.Hp * 4
+    assert 0 < s["comm_bytes"] < 0.6 * 2 * plane_bytes and s["comm_bytes"] == evs[1].stats()["comm_bytes"]
+    assert s["comm_bytes"] >= 2 * s["band_rows"] * 16 * w.Wp * 4 * 0.5
     n_before = len(ar.calls[0])
     _check_sequence(ar, evs, one, seq[3:4])            # the jump: detected, repaired, results still right
     s = evs[0].stats()
