@@ -43,50 +43,27 @@ bool chain_eligible(const cmx_ctx *c) {
          c->measure != CMX_GRADIENT_MAGNITUDE;
 }
 
-// the splat of the chain's FIRST point: a launch of its own (with the tile sort in front of it when one is due)
-int queue_first_splat(cmx_ctx *c) {
-  const double zero[3] = {0, 0, 0};  // (the kernels read omega from device memory; last_x is not meaningful inside a chain)
-  c->last_adjoint = true;
-  return fe_accumulate(c, zero, 1);
-}
-
-// One slot = the rest of evaluation point `slot` (its splat is already queued) + the splat of the next point:
-//     image pass + cost finalize + machine step   ->   [gradient pass (gated) + finalize + machine step | splat of the next point]
-// The bracket is ONE launch (fe_gather_splat_kernel) unless the next splat needs a re-sort of the events first; then it is a
-// gated gather, the sort, and a plain splat.
 int queue_slot(cmx_ctx *c, int slot, SlotTickets *t) {
   const int r = slot % kRingSlots;
   c->chain_block_a = c->d_chain_ring + (size_t)(2 * r) * kBlock;
   c->chain_block_g = c->d_chain_ring + (size_t)(2 * r + 1) * kBlock;
+  const double zero[3] = {0, 0, 0};  // (the kernels read omega from device memory; last_x is not meaningful inside a chain)
   c->last_adjoint = true;
+  int rc = fe_accumulate(c, zero, 1);
+  if (rc) return rc;
   c->gate_arm = true;
-  int rc = run_adjoint(c, 3, /*phase=*/3);  // image pass + cost finalize + machine step (decides the gate)
+  rc = run_adjoint(c, 3, /*phase=*/3);  // image pass + cost finalize + machine step (decides the gate)
   c->gate_arm = false;
   if (rc) return rc;
   t->a = c->ticket_issued;
   t->nout_a = c->ticket_nout;
-  const bool resort = !c->bin_valid || c->last_fallback_frac > kRebinFallbackFrac || !c->streams_valid || c->nchunks <= 0;
-  c->chain_fuse = !resort && c->chain_fuse_ok;
-  if (c->chain_fuse) {
-    rc = fe_prepare_splat(c, &c->chain_next_a, &c->chain_next_b);  // (swaps the ping-pong buffers: the gather below reads Jt only)
-    if (rc) return rc;
-    c->chain_ready_want = (unsigned)slot + 1u;
-    c->jt_valid = true;  // (of the CURRENT point: the gradient pass of this slot consumes it)
-  }
   c->gated_pending = false;
-  rc = run_adjoint(c, 3, /*phase=*/4);  // gradient pass behind the gate (+ finalize + machine step) [+ the next point's splat]
-  const bool fused = c->chain_fuse;
-  c->chain_fuse = false;
+  rc = run_adjoint(c, 3, /*phase=*/4);  // gradient pass behind the gate (+ finalize + machine step)
   if (rc) return rc;
   t->gated = c->gated_pending;
   c->gated_pending = false;
   t->g = c->ticket2_issued;
   t->nout_g = c->ticket2_nout;
-  c->jt_valid = false;
-  if (!fused) {
-    rc = queue_first_splat(c);  // plain splat of the next point (re-sorts first when due)
-    if (rc) return rc;
-  }
   c->chain_slots++;
   return CMX_OK;
 }
@@ -132,8 +109,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   c->chain_active = true;
   c->chain_solves++;
   double g[3];
-  rc = queue_first_splat(c);
-  while (!rc && !sm_done(hs)) {
+  while (!sm_done(hs)) {
     while (queued < consumed + kAhead) {
       rc = queue_slot(c, queued, &tick[queued % kRingSlots]);
       if (rc) break;
@@ -159,13 +135,12 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     c->fallback_pending = false;
     // ---- replay: the cost stage
     const int ext_a = t.nout_a - kChainExtra;
-    if (((int)ba[ext_a + 2] & 2) != 0) { diverged = true; break; }  // a splat gave up waiting for the machine: this cost means nothing
     const bool dev_need = ba[ext_a] != 0.0;
     const bool need = sm_cost(hs, -ba[0]);
     if (need != dev_need) { diverged = true; break; }
     if (c->chain_test == 2 && need && consumed == 2) { diverged = true; break; }  // (test hook: hand over between a cost and its gradient)
     if (!need) {
-      const bool dev_done = ((int)ba[ext_a + 2] & 1) != 0;
+      const bool dev_done = ba[ext_a + 2] != 0.0;
       if (dev_done != sm_done(hs) || (!dev_done && !same_bits(ba + ext_a + 3, sm_point(hs), 3))) { diverged = true; break; }
       consumed++;
       continue;
@@ -176,7 +151,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     for (int k = 0; k < 3; k++) g[k] = -bg[2 + k];
     sm_grad(hs, g);
     const int ext_g = t.nout_g - kChainExtra;
-    const bool dev_done = ((int)bg[ext_g + 2] & 1) != 0;
+    const bool dev_done = bg[ext_g + 2] != 0.0;
     if (dev_done != sm_done(hs) || (!dev_done && !same_bits(bg + ext_g + 3, sm_point(hs), 3))) { diverged = true; consumed++; break; }
     consumed++;
     if (c->chain_test == 1 && consumed == 3 && !sm_done(hs)) { diverged = true; break; }  // (test hook: hand over between two points)

@@ -205,11 +205,6 @@ struct cmx_ctx {
   ChainDev *h_chain_init = nullptr;   // pinned staging of the machine's initial state (two blocks, alternating per solve)
   int chain_init_sel = 0;
   double *chain_block_a = nullptr, *chain_block_g = nullptr;  // device pointers of the blocks of the slot being queued
-  bool chain_fuse_ok = true;          // CMX_OPT_CHAIN_SOLVE 4: never fuse (A/B of the gather + splat launch)
-  bool chain_fuse = false;            // the gradient pass being queued carries the NEXT point's splat (gather + splat launch)
-  FeSplatArgs chain_next_a{};         // ... whose arguments were prepared by fe_prepare_splat
-  BinnedEvents chain_next_b{};
-  unsigned chain_ready_want = 0;
   int64_t chain_solves = 0, chain_slots = 0, chain_takeovers = 0;
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
@@ -345,7 +340,6 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
 bool spin_for_ticket(const double *h_block, unsigned long long want, int nout);
 int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes);  // cmx_frontend.cpp
-int fe_prepare_splat(cmx_ctx *c, FeSplatArgs *a, BinnedEvents *b);  // everything fe_accumulate does for the LDS splat but the launch
 // cmx_chain.cpp: run the solve on the device as far as it goes.  `hs` = the host's machine, begun (sm_begin) with x = start;
 // on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
 // host-driven from hs (configuration not eligible, or the device's next point was not bitwise the host's)

@@ -156,25 +156,6 @@ int cmx_frontend_prepare(cmx_ctx *c, const double omega_hint[3]) {
   return CMX_OK;
 }
 
-// Device-driven solve: the accumulation buffer and the arguments of the next point's LDS splat, WITHOUT launching it -- the
-// launch is the second half of the gather + splat kernel (cmx_chain.cpp).  The tile sort is taken as it is (the caller
-// queues a plain splat instead when a re-sort is due).  Jt and its moment rows (the current point's) stay valid.
-int fe_prepare_splat(cmx_ctx *c, FeSplatArgs *a, BinnedEvents *b) {
-  c->timing_tick++;
-  const size_t np = (size_t)c->W * c->H;
-  int rc = begin_accum(c, 1, np, true);
-  if (rc) return rc;
-  const double zero[3] = {0, 0, 0};
-  *a = fe_args(c, zero);
-  *b = binned(c);
-  c->last_used_lds = true;
-  c->fallback_pending = true;
-  c->accum_count = np;
-  c->last_P = 0;
-  c->accumulated = true;
-  return CMX_OK;
-}
-
 int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");

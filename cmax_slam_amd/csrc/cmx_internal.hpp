@@ -61,25 +61,19 @@ struct BeSplatArgs {
 // with the cost / gradient it has just reduced, writes the NEXT evaluation point to x_req and decides whether the gradient pass
 // queued behind it runs (FinalizeArgs::gate_out) -- the next evaluation's kernels, already queued by the host, start without a
 // round trip to it.  The host replays the same machine on what the result blocks report and takes over on any disagreement.
-constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
-constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kChainMaxN = 3;  // parameters of a device-driven solve (front end)
 typedef FrcgSMFix<kChainMaxN> ChainMachine;
 struct ChainDev {  // one device allocation, initialised by one copy
   ChainMachine sm;
   double x_req[kChainMaxN];  // evaluation point of the next slot (read by its splat / gather)
   int done;                  // set once the machine has finished: every later kernel of the chain returns at once
-  int abort_flag;            // a splat workgroup of a gather + splat launch gave up waiting for the machine's step (never expected)
-  unsigned ready[kTailShards * kTailStride];  // per shard: sequence number of the last gradient-stage step published (gather + splat launches)
+  int pad;
 };
 struct ChainArgs {
   ChainMachine *sm;  // the machine in device memory (copied to LDS and back by the finalize that advances it); null = off
   double *x_req;
   int *done;
   int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass
-  unsigned *ready;   // gather + splat launch (stage 1): words to set to ready_want once x_req / done are out; null otherwise
-  unsigned ready_want;
-  const int *abort_flag;  // reported in every result block (a splat workgroup gave up waiting: the host takes the solve over)
 };
 constexpr int kChainExtra = 3 + kChainMaxN;  // result words appended by a chained finalize: need-gradient flag, phase, done, next point
 
@@ -128,6 +122,8 @@ constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 // Tail finalize (cmx_kernels.hip, tail_arrive): the LAST kernel of an evaluation -- image_moments / image_adjoint2 (cost-only),
 // fe_gather / be_gather4 with the per-batch pass folded in / be_gather_batch (adjoint gradient) -- runs the finalize step in
 // its last-arriving workgroup, so an evaluation ends without the one-workgroup finalize launch and the boundary in front of it.
+constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
+constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kTailCounterWords = (kTailShards + 1) * kTailStride;
 constexpr int kGaccStride = 2 * 3 * kMaxKnots + 2;  // doubles per accumulator row: S1 | S2 columns (+ spare), see FinalizeArgs::gacc
 struct TailArgs {
@@ -285,9 +281,7 @@ void launch_alpha(const AlphaArgs &a, hipStream_t s);
 void launch_reduce_partials(const FinalizeArgs &a, hipStream_t s);
 void launch_reduce_gpartials(const double *gpartials, int gblocks, int P, double *gsum, hipStream_t s);
 void launch_finalize_only(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-void launch_fe_gather_splat(const FeGatherArgs &g, const FeSplatArgs &a, const BinnedEvents &b, const unsigned *ready,
-                            unsigned ready_want, int *abort_flag, hipStream_t s);  // device-driven solve: gather of point k + splat of point k+1  // returns the number of blocks (rows of gpartials)
+int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // returns the number of blocks (rows of gpartials)
 int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, hipEvent_t b0 = nullptr,
                      hipEvent_t b1 = nullptr);  // returns the rows of gpartials (batch-kernel blocks)
 int be_batch_blocks(int nb);

@@ -17,7 +17,6 @@
 #include "../../include/cmax_hip.h"
 #include "cmx_internal.hpp"
 #include "cmx_warp.hpp"
-#include "cmx_splat_body.hpp"
 
 // launch with optional kernel-exact timing events (null, null = plain launch)
 #define CMX_LAUNCH(kernel, grid, block, lds, stream, t0, t1, ...)                                            \
@@ -651,19 +650,14 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
       const int done = sm_done(s) ? 1 : 0;
       const bool moved = a.chain.stage == 1 || !need;  // the machine has gone on to its next request
       if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
-      if (done) __hip_atomic_store(a.chain.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by every later launch of the chain
+      if (done) *a.chain.done = 1;                     // read by every later launch of the chain
       const double *xn = sm_point(s);
       sm.outv[nout] = (double)need;
       sm.outv[nout + 1] = (double)s.phase;
-      sm.outv[nout + 2] = (double)(done | ((a.chain.abort_flag && *a.chain.abort_flag) ? 2 : 0));
+      sm.outv[nout + 2] = (double)done;
       for (int k = 0; k < n; k++) sm.outv[nout + 3 + k] = (moved && !done) ? xn[k] : 0.0;
       if (moved && !done)
-        for (int k = 0; k < n; k++) st_sc1(a.chain.x_req + k, xn[k]);  // write-through: the splat of the SAME launch may read it
-      if (a.chain.ready) {  // gradient stage of a gather + splat launch: release the splat's workgroups (one word per shard)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int q = 0; q < kTailShards; q++)
-          __hip_atomic_store(a.chain.ready + q * kTailStride, a.chain.ready_want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+        for (int k = 0; k < n; k++) a.chain.x_req[k] = xn[k];
     }
     nout += kChainExtra;
     __syncthreads();
@@ -1472,17 +1466,19 @@ int fe_gather_blocks(int n) {
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
 }
 
-// the body of the front-end gradient pass for workgroup `blk` of `nblk` (red: 24 doubles of LDS); shared by fe_gather_kernel and
-// the device-driven solve's gather + splat launch
 template <bool CHAIN>
-__device__ __forceinline__ void fe_gather_body(FeGatherArgs &g, const int blk, const int nblk, double *red, FinSmem &fin_sm) {
+__global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
+  if (g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
+  if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
+  __shared__ double red[4 * 6];
+  __shared__ FinSmem fin_sm;
   if (CHAIN) fe_resolve_omega(g.ev);
   const FeSplatArgs &a = g.ev;
   double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
   constexpr int U = 2;  // events in flight per thread (swept on MI355X: 2 -> 11.9 us, 1 -> 12.2, 4 -> 12.9, 8 -> 14.9 per 1M events)
   // every workgroup walks ONE contiguous slice of the event list (in tile order that keeps its LUT / Itilde reads local)
-  const int per_block = ((a.n + nblk - 1) / nblk + 255) / 256 * 256;
-  const int blk_beg = blk * per_block, blk_end = min(a.n, blk_beg + per_block);
+  const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+  const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
   const int stride = 256;
   for (int i0 = blk_beg + threadIdx.x; i0 < blk_end; i0 += stride * U) {
     double dt[U], px[U], py[U], pz[U];
@@ -1568,76 +1564,12 @@ __device__ __forceinline__ void fe_gather_body(FeGatherArgs &g, const int blk, c
     const double v = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
     if (g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc); with or without the tail
       if (v != 0.0)
-        __hip_atomic_fetch_add(g.tail.fin.gacc + (size_t)(blk % kTailShards) * g.tail.fin.gacc_stride + k, v, __ATOMIC_RELAXED,
+        __hip_atomic_fetch_add(g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride + k, v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tail) st_sc1(g.gpartials + (size_t)k * nblk + blk, v);  // write-through: read by the last arriver
-    else g.gpartials[(size_t)k * nblk + blk] = v;
+    } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
+    else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
-  if (tail && tail_arrive(g.tail, nblk, blk, fin_sm)) finalize_body<256, CHAIN>(g.tail.fin, fin_sm);
-}
-
-template <bool CHAIN>
-__global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
-  if (g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
-  if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
-  __shared__ double red[4 * 6];
-  __shared__ FinSmem fin_sm;
-  fe_gather_body<CHAIN>(g, (int)blockIdx.x, (int)gridDim.x, red, fin_sm);
-}
-
-// Device-driven solve: the gradient pass of evaluation point k and the splat of point k+1 in ONE launch.  Workgroups
-// [0, n_gather) are the gather's (they return at once when the machine decided against the gradient), the rest are the
-// splat's chunks.  A gated-off gather used to be a launch of its own -- ~4-5 us of a 25 us cost-only point (977 workgroups that
-// load a flag and leave, plus the boundary); here the splat's workgroups are dispatched right behind them.  When the gradient
-// IS needed, the next point is only known once the gather's last-arriving workgroup has run the finalize and the machine's
-// step: the splat's workgroups then wait for the `ready` word of their shard (written after x_req, both write-through; polled
-// with sc1 loads and s_sleep, bounded).  They can wait inside the launch because workgroups are dispatched in index order:
-// every gather workgroup is resident or finished before the first splat workgroup starts, so the waiting ones can never keep
-// a gather workgroup from running.  A wait that runs out (it never should) sets *abort and leaves the splat out: the host
-// sees a result it cannot reproduce and takes the solve over.
-__global__ __launch_bounds__(256) void fe_gather_splat_kernel(FeGatherArgs g, FeSplatArgs a, BinnedEvents b, int n_gather,
-                                                              const unsigned *ready, unsigned ready_want, int *abort_flag) {
-  __shared__ fix_t win[kBinWindow * kBinStride];
-  __shared__ unsigned sfall;
-  __shared__ double red[4 * 6];
-  __shared__ FinSmem fin_sm;
-  if (*a.skip) return;       // the machine finished in an earlier launch: nothing of this one is wanted (and nobody would publish `ready`)
-  const int need = *g.gate;  // written by the cost stage's finalize (an earlier launch)
-  if ((int)blockIdx.x < n_gather) {
-    if (need == 0) return;
-    fe_gather_body<true>(g, (int)blockIdx.x, n_gather, red, fin_sm);
-    return;
-  }
-  if (need != 0) {  // the next point comes out of this launch's gather: wait for the machine's step
-    __shared__ int ok_sh;
-    if (threadIdx.x == 0) {
-      const unsigned *w = ready + (blockIdx.x % kTailShards) * kTailStride;
-      unsigned spins = 0;
-      int ok = 1;
-      while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ready_want) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > 400000u) { ok = 0; *abort_flag = 1; break; }
-      }
-      ok_sh = ok;
-    }
-    __syncthreads();
-    if (!ok_sh) return;
-    // x_req / done were stored write-through before the ready words: read them past the caches
-    const unsigned long long *xr = reinterpret_cast<const unsigned long long *>(a.w_dev);
-    if (__hip_atomic_load(reinterpret_cast<const unsigned *>(a.skip), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    a.wx = __longlong_as_double((long long)__hip_atomic_load(xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    a.wy = __longlong_as_double((long long)__hip_atomic_load(xr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    a.wz = __longlong_as_double((long long)__hip_atomic_load(xr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else {
-    fe_resolve_omega(a);
-  }
-  fe_splat_lds_body<false, true>(a, b, (int)blockIdx.x - n_gather, win, sfall);
-}
-void launch_fe_gather_splat(const FeGatherArgs &g, const FeSplatArgs &a, const BinnedEvents &b, const unsigned *ready,
-                            unsigned ready_want, int *abort_flag, hipStream_t s) {
-  const int n_gather = fe_gather_blocks(g.ev.n);
-  hipLaunchKernelGGL(fe_gather_splat_kernel, dim3(n_gather + (b.nchunks > 0 ? b.nchunks : 0)), dim3(256), 0, s, g, a, b, n_gather, ready,
-                     ready_want, abort_flag);
+  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256, CHAIN>(g.tail.fin, fin_sm);
 }
 
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {

@@ -500,11 +500,6 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     f.chain.x_req = c->d_chain->x_req;
     f.chain.done = &c->d_chain->done;
     f.chain.stage = phase == 4 ? 1 : 0;
-    f.chain.abort_flag = &c->d_chain->abort_flag;
-    if (phase == 4 && c->chain_fuse) {  // gather + splat launch: the gradient stage releases the splat's workgroups
-      f.chain.ready = c->d_chain->ready;
-      f.chain.ready_want = c->chain_ready_want;
-    }
     a.skip = &c->d_chain->done;
   }
   if (!have_image) {  // large panoramas: compact work list (a pre-pass kernel; partial rows become compact too)
@@ -608,9 +603,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
           c->gated_pending = true;
           c->gated_launches++;
         }
-        if (gated && c->chain_active && c->chain_fuse)
-          launch_fe_gather_splat(g, c->chain_next_a, c->chain_next_b, c->d_chain->ready, c->chain_ready_want, &c->d_chain->abort_flag, c->stream);
-        else launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
+        launch_fe_gather(g, c->stream, sp.t0(), sp.t1());
       } else {
         HIP_TRY(c, hipMemsetAsync(c->d_gpartials, 0, (size_t)gb * P2 * sizeof(double), c->stream));
       }
