@@ -96,3 +96,38 @@ def test_chain_solve_back_to_back_packets_and_ineligible_configurations(hip):
     a = fe.setupProblemAndOptimize(np.zeros(3))
     b = fe.setupProblemAndOptimize(np.zeros(3))
     assert fe.stats()["chain_solves"] == 4 and np.array_equal(a[0], b[0])
+
+
+def test_chain_solve_resorts_the_events_mid_solve_and_runs_beside_another_context(hip):
+    """A fast rotation: the tile sort taken at omega = 0 no longer fits a few points into the solve (> 3 % of the votes leave
+    their windows), so the chain re-sorts at the device's current point (the sort kernels read omega from device memory too).
+    Two contexts solved from two host threads at once reach what they reach alone."""
+    import threading
+    p = synth.frontend_packet(150_000, 320, 240, 300.0, 300.0, 159.5, 119.5, T=0.12, omega_true=(2.5, -3.5, 1.5), seed=81)
+    x0 = 0.3 * np.array(p.omega_true)   # (from omega = 0 this packet is a flat start: both drivers stop after 472 halvings)
+    host = _fe(hip, p, 0).setupProblemAndOptimize(x0)
+    fe = _fe(hip, p, 1)
+    dev = fe.setupProblemAndOptimize(x0)
+    st = fe.stats()
+    assert st["chain_solves"] == 1 and st["chain_takeovers"] == 0 and st["rebins"] >= 2, st
+    _close(dev, host)
+    assert np.abs(dev[0][:2] - p.omega_true[:2]).max() < 0.5
+    flat = _fe(hip, p, 1).setupProblemAndOptimize(np.zeros(3))   # the flat start: intermediate_point halves the step until
+    flat_h = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))  # the point stops moving -- hundreds of chained cost-only slots
+    assert flat[1]["n_f"] == flat_h[1]["n_f"] > 100 and flat[1]["status"] == flat_h[1]["status"] == 27 and np.array_equal(flat[0], flat_h[0])
+    q = synth.frontend_packet(90_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=82)
+    alone = [_fe(hip, pk, 1).setupProblemAndOptimize(np.zeros(3)) for pk in (p, q)]
+    evs = [_fe(hip, pk, 1) for pk in (p, q)]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(5):
+            out[i] = evs[i].setupProblemAndOptimize(np.zeros(3))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(2):
+        _close(out[i], alone[i])
+        assert evs[i].stats()["chain_solves"] == 5 and evs[i].stats()["chain_takeovers"] == 0
