@@ -44,8 +44,15 @@ def so_hash():
     except OSError:
         return None
 
+# coalesced per-event STREAM bytes one launch of each kernel reads at the bench's sizes (1M front-end / 5M back-end events): the
+# part of FETCH_SIZE that is known to be reported at half (profiles/r03_fetch_calib.txt).  What is left of FETCH_SIZE after it is
+# table-gather traffic (L2 misses of divergent 8-byte loads) whose request size -- hence factor, 1 or 2 -- is not known:
+# `bytes_lower` counts it once, `bytes` twice; for the stream-only kernels the two coincide.
+STREAM_BYTES = {"frontend_fast_splat": 24e6, "frontend_fast_gather": 24e6, "backend_fast_splat": 120e6, "backend_fast_gather": 100e6}
+
 NAMES = {
-    "fe_splat_lds_kernel": "frontend_fast_splat", "fe_gather_kernel": "frontend_fast_gather",
+    "fe_splat_lds_kernel": "frontend_fast_splat",
+    "fe_gather_kernel<false>": "frontend_fast_gather",  # the evaluations bench.py times (<true>: the device-driven solves, incl. gated-off launches)
     "image_adjoint_kernel<4, 64, 16, 1024, false>": None,  # shared by both ends in one run: split by call order is not possible
     "be_splat_lds_kernel": "backend_fast_splat", "be_gather4_kernel": "backend_fast_gather",
     "be_gather_batch_kernel": "backend_fast_batch", "be_pose_table_pre_kernel<4, true>": "backend_fast_pose",
@@ -81,8 +88,13 @@ def main(path):
                 raw = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
                 fac = FETCH_FACTOR.get(key, 2.0)
                 cor = (fac * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-                out["kernels"][key] = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "raw_bytes": raw, "fetch_factor": fac,
-                                       "bytes": cor}
+                row = {"fetch_kib": d["FETCH_SIZE"], "write_kib": d["WRITE_SIZE"], "raw_bytes": raw, "fetch_factor": fac, "bytes": cor}
+                if key in STREAM_BYTES:
+                    fetch = d["FETCH_SIZE"] * 1024
+                    stream_raw = min(STREAM_BYTES[key] / 2, fetch)
+                    row["stream_bytes_known"] = STREAM_BYTES[key]
+                    row["bytes_lower"] = 2 * stream_raw + (fetch - stream_raw) + d["WRITE_SIZE"] * 1024
+                out["kernels"][key] = row
                 out[key] = cor
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
