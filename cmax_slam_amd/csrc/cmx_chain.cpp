@@ -23,7 +23,7 @@ constexpr int kAhead = 2;        // slots kept queued ahead of the one whose res
 constexpr int kRingSlots = 8;    // ring of result blocks (2 per slot); > kAhead + 1
 constexpr int kBlock = 4096;     // doubles per result block (the layout of the one-evaluation result buffer)
 
-struct SlotTickets { unsigned long long a = 0, g = 0; int nout_a = 0, nout_g = 0; bool gated = false; };
+struct SlotTickets { unsigned long long a = 0, g = 0; int nout_a = 0, nout_g = 0; bool gated = false, self_gating = false; };
 
 int ensure_chain_buffers(cmx_ctx *c) {
   if (c->d_chain) return CMX_OK;
@@ -64,6 +64,86 @@ int queue_slot(cmx_ctx *c, int slot, SlotTickets *t) {
   c->gated_pending = false;
   t->g = c->ticket2_issued;
   t->nout_g = c->ticket2_nout;
+  c->chain_slots++;
+  return CMX_OK;
+}
+
+// Self-gating slots (the production shape: blur radius 4, composite image pass, per-event streams): the image pass runs NO
+// finalize -- its tiles' moments go to accumulator rows -- and the launch behind it decides by itself whether it is the gradient
+// pass (fe_gather_kernel<2>).  One result block per slot: contrast, [gradient], the machine's decisions and next point.
+bool self_gating_ok(const cmx_ctx *c) {
+  return c->chain_self_gating && c->radius == 4 && c->composite_image && c->d_Mx && c->d_My && c->Mx_radius == 4 && c->d_lut2 &&
+         c->d_cx && c->d_cy;
+}
+int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
+  const int W = c->imgW, H = c->imgH;
+  const size_t np = (size_t)W * H;
+  const int r = slot % kRingSlots;
+  const double zero[3] = {0, 0, 0};
+  c->last_adjoint = true;
+  int rc = fe_accumulate(c, zero, 1);  // splat (omega from device memory; re-sorts first when due)
+  if (rc) return rc;
+  if (!c->streams_valid || !c->bin_valid) return fail(c, CMX_ERR_STATE, "self-gating slot without the tile-ordered streams");
+  float *jt_before = c->d_itilde;
+  rc = ensure(c, c->d_itilde, c->itilde_cap, np);
+  if (rc) return rc;
+  if (c->d_itilde != jt_before) HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
+  // ---- image pass: B = G*I moments -> accumulator rows of buffer (slot & 1), Jt = G^T G I, clears the ping-pong partner
+  ImgAdjArgs ia{};
+  ImgArgs &a = ia.img;
+  ia.Mx = c->d_Mx; ia.My = c->d_My;
+  ia.jt = c->d_itilde;
+  a.W = W; a.H = H; a.r = c->radius;
+  memcpy(a.taps, c->taps, sizeof(a.taps));
+  a.src_a = c->d_accum;
+  a.P = 0;
+  a.tiles_x = image_adjoint_tiles_x(W);
+  a.nblk = image_adjoint_tiles(W, H);
+  a.tiles_y = (H + kTileY - 1) / kTileY;
+  if (c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+    a.zero_ptr = c->d_accum_alt;
+    a.zero_planes = c->pingpong_planes;
+    c->alt_clean = true;
+  }
+  a.skip = &c->d_chain->done;
+  a.macc = &c->d_chain->macc[slot & 1][0][0];
+  launch_image_adjoint(ia, c->stream);
+  // ---- the self-gating launch: cost finalize + machine step, and the gradient pass when the machine's test says so
+  FeGatherArgs g{};
+  g.ev = fe_args(c, zero);
+  g.itilde = c->d_itilde;
+  g.gpartials = nullptr;
+  g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
+  g.sxy = c->d_sxy; g.sbatch = c->d_sbatch; g.sb = c->d_sb; g.sdt = c->d_sdt;
+  FinalizeArgs &f = g.tail.fin;
+  f.P = 0;
+  f.nblk = a.nblk;
+  f.measure = c->measure;
+  f.npix = (double)np;
+  f.result = c->d_chain_ring + (size_t)(2 * r) * kBlock;
+  f.gP = 3;
+  f.mu_free = 1;
+  f.direct = 1;
+  f.gacc = c->d_gacc;
+  f.gacc_stride = kGaccStride;
+  f.fallback = c->d_fallback;
+  f.macc = a.macc;
+  f.macc_clear = &c->d_chain->macc[(slot + 1) & 1][0][0];
+  f.nout_pad = 2 + 3;
+  f.chain.sm = &c->d_chain->sm;
+  f.chain.x_req = c->d_chain->x_req;
+  f.chain.done = &c->d_chain->done;
+  f.chain.abort_flag = &c->d_chain->abort_flag;
+  f.chain.stage = 2;
+  f.ticket = ++c->ticket_issued;
+  g.tail.counters = c->d_tail_counters;
+  launch_fe_gather(g, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  t->a = f.ticket;
+  t->nout_a = f.nout_pad + kChainExtra;
+  t->self_gating = true;
+  t->gated = true;
+  c->jt_valid = false;
   c->chain_slots++;
   return CMX_OK;
 }
@@ -111,7 +191,8 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   double g[3];
   while (!sm_done(hs)) {
     while (queued < consumed + kAhead) {
-      rc = queue_slot(c, queued, &tick[queued % kRingSlots]);
+      tick[queued % kRingSlots] = SlotTickets{};
+      rc = self_gating_ok(c) ? queue_slot_self_gating(c, queued, &tick[queued % kRingSlots]) : queue_slot(c, queued, &tick[queued % kRingSlots]);
       if (rc) break;
       if (!tick[queued % kRingSlots].gated) { unsupported = true; }  // no gated gradient pass in this configuration
       queued++;
@@ -133,6 +214,23 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     }
     if (c->n_packed > 0) c->last_fallback_frac = ba[kFallbackSlot] / (double)c->n_packed;  // drives the re-sort of the next slot queued
     c->fallback_pending = false;
+    if (t.self_gating) {  // one block: contrast, gradient (when the launch computed it), decisions, next point
+      const int ext = t.nout_a - kChainExtra;
+      if (((int)ba[ext + 2] & 2) != 0) { diverged = true; break; }  // the launch's workgroups and the machine disagreed: nothing fed
+      const bool dev_need = ba[ext] != 0.0;
+      const bool need = sm_cost(hs, -ba[0]);
+      if (need != dev_need) { diverged = true; break; }
+      if (c->chain_test == 2 && need && consumed == 2) { diverged = true; break; }  // (test hook: hand over between a cost and its gradient)
+      if (need) {
+        for (int k = 0; k < 3; k++) g[k] = -ba[2 + k];
+        sm_grad(hs, g);
+      }
+      const bool dev_done = ((int)ba[ext + 2] & 1) != 0;
+      if (dev_done != sm_done(hs) || (!dev_done && !same_bits(ba + ext + 3, sm_point(hs), 3))) { diverged = true; consumed++; break; }
+      consumed++;
+      if (c->chain_test == 1 && consumed == 3 && !sm_done(hs)) { diverged = true; break; }  // (test hook)
+      continue;
+    }
     // ---- replay: the cost stage
     const int ext_a = t.nout_a - kChainExtra;
     const bool dev_need = ba[ext_a] != 0.0;

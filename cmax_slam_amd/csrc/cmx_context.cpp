@@ -379,6 +379,7 @@ int cmx_set_option(cmx_ctx *c, int key, int value) {
     case CMX_OPT_CHAIN_SOLVE:
       c->chain_solve = value != 0;
       c->chain_test = value == 2 ? 1 : (value == 3 ? 2 : 0);
+      c->chain_self_gating = value != 4;
       return CMX_OK;
     case CMX_OPT_COMPOSITE_IMAGE:
       c->composite_image = value != 0;

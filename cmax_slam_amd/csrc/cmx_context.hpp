@@ -198,6 +198,7 @@ struct cmx_ctx {
   unsigned long long gated_launches = 0, gated_hits = 0;
   // device-driven solve (cmx_chain.cpp): the FR-CG machine lives in device memory and advances inside the finalize steps
   bool chain_solve = true;            // CMX_OPT_CHAIN_SOLVE (front end)
+  bool chain_self_gating = true;      // CMX_OPT_CHAIN_SOLVE 4: slots with a finalize behind the image pass and a flag-gated gradient pass (A/B)
   int chain_test = 0;                 // CMX_OPT_CHAIN_SOLVE 2 / 3: the host takes over after a few slots (exercises the hand-over)
   bool chain_active = false;          // set around the launches of a chain slot: kernels read omega / skip from device memory
   ChainDev *d_chain = nullptr;        // the machine + next evaluation point + end-of-solve flag

@@ -61,19 +61,26 @@ struct BeSplatArgs {
 // with the cost / gradient it has just reduced, writes the NEXT evaluation point to x_req and decides whether the gradient pass
 // queued behind it runs (FinalizeArgs::gate_out) -- the next evaluation's kernels, already queued by the host, start without a
 // round trip to it.  The host replays the same machine on what the result blocks report and takes over on any disagreement.
+constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
+constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kChainMaxN = 3;  // parameters of a device-driven solve (front end)
 typedef FrcgSMFix<kChainMaxN> ChainMachine;
 struct ChainDev {  // one device allocation, initialised by one copy
   ChainMachine sm;
   double x_req[kChainMaxN];  // evaluation point of the next slot (read by its splat / gather)
   int done;                  // set once the machine has finished: every later kernel of the chain returns at once
-  int pad;
+  int abort_flag;            // the workgroups of a self-gating gradient pass and the machine disagreed (never expected)
+  // self-gating slots: the image pass adds its tiles' two moments (sum B, sum B^2) to 8 shard rows of buffer (slot & 1) with
+  // fp64 atomics instead of handing a table to a finalize of its own; rows 128 B apart
+  double macc[2][kTailShards][16];
 };
 struct ChainArgs {
   ChainMachine *sm;  // the machine in device memory (copied to LDS and back by the finalize that advances it); null = off
   double *x_req;
   int *done;
-  int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass
+  int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass, 2: a self-gating slot (cost, then the gradient
+                     //    if the launch computed one: FinalizeArgs::gP > 0)
+  int *abort_flag;
 };
 constexpr int kChainExtra = 3 + kChainMaxN;  // result words appended by a chained finalize: need-gradient flag, phase, done, next point
 
@@ -102,7 +109,23 @@ struct FinalizeArgs {
   double gate_thr;
   int gate_mode;
   ChainArgs chain;
+  // self-gating slots of the device-driven solve: image moments from accumulator rows (ChainDev::macc) instead of a table; the
+  // finalize zeroes the OTHER buffer (the next slot's); nout_pad: result words before the chain's extension whatever gP is
+  const double *macc;
+  double *macc_clear;
+  int nout_pad;
 };
+// contrast from the two image moments: the one expression shared by the finalize step and by the workgroups of a self-gating
+// gradient pass (they must take the machine's decision from bitwise the same number)
+static inline __host__ __device__ double contrast_from_sums(double s0, double s1, double N, int measure, double *mu_out) {
+  const double mu = s0 / N;
+  *mu_out = mu;
+  if (measure == 1) return s1 / N;
+  double var = s1 / N - mu * mu;
+  if (var < 0) var = 0;
+  const double sd = sqrt(var);
+  return sd * sd;
+}
 // the condition of the gate, the same expression on the device (finalize) and on the host (which result to expect)
 static inline __host__ __device__ int gate_condition(double contrast, double thr, int mode) {
   const double f = -contrast;
@@ -122,8 +145,6 @@ constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 // Tail finalize (cmx_kernels.hip, tail_arrive): the LAST kernel of an evaluation -- image_moments / image_adjoint2 (cost-only),
 // fe_gather / be_gather4 with the per-batch pass folded in / be_gather_batch (adjoint gradient) -- runs the finalize step in
 // its last-arriving workgroup, so an evaluation ends without the one-workgroup finalize launch and the boundary in front of it.
-constexpr int kTailShards = 8;   // ticket counters sharded by blockIdx % 8 (the XCD of a workgroup, for speed only)
-constexpr int kTailStride = 32;  // counters 128 B apart; [kTailShards] shard counters, then the top counter
 constexpr int kTailCounterWords = (kTailShards + 1) * kTailStride;
 constexpr int kGaccStride = 2 * 3 * kMaxKnots + 2;  // doubles per accumulator row: S1 | S2 columns (+ spare), see FinalizeArgs::gacc
 struct TailArgs {
@@ -158,6 +179,7 @@ struct ImgArgs {
   const unsigned *tile_list;
   const unsigned *tile_count;
   const int *skip;      // optional (device-driven solve): the launch does nothing when *skip != 0
+  double *macc;         // optional (device-driven solve, self-gating slots): moment accumulator rows instead of `partials`
   TailArgs tail;        // image_moments only (cost-only evaluations, P == 0): finalize in the last-arriving workgroup
 };
 constexpr int kTileListMin = 2048, kTileListGrid = 1024;

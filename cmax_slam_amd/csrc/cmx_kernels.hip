@@ -465,6 +465,18 @@ struct alignas(16) FinSmem {  // a multiple of 16 bytes: static LDS in front of 
 };
 static_assert(sizeof(FinSmem) % 16 == 0, "FinSmem must keep the dynamic LDS base 16-byte aligned");
 
+// the two image moments of a self-gating slot from their 8 accumulator rows, always in this order
+__device__ __forceinline__ void chain_moment_sums(const double *macc, double &s0, double &s1) {
+  double a0 = 0, a1 = 0;
+#pragma unroll
+  for (int q = 0; q < kTailShards; q++) {
+    a0 += macc[(size_t)q * 16];
+    a1 += macc[(size_t)q * 16 + 1];
+  }
+  s0 = a0;
+  s1 = a1;
+}
+
 template <int NT, bool CHAIN = false>  // CHAIN: the device-driven solve's variant (the machine's step is compiled in)
 __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm) {
   constexpr int NW = NT / 64;   // waves
@@ -553,7 +565,10 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     }
     __syncthreads();
   }
-  if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
+  if (CHAIN && a.macc) {  // self-gating slot: the moments are 8 accumulator rows (summed in the order chain_moment_sums uses)
+    if (t == 0) chain_moment_sums(a.macc, sm.sh[0], sm.sh[1]);
+    if (t < 2 * kTailShards) a.macc_clear[(size_t)(t >> 1) * 16 + (t & 1)] = 0.0;  // the NEXT slot's buffer (nobody reads it now)
+  } else if (a.direct) {  // few tiles: sum the image kernel's per-tile moments here instead of a separate launch
     // this is ONE workgroup reading tables other CUs just wrote (L2-remote): keep many independent loads in flight
     const int row = wave & 1, part = wave >> 1;
     double p = 0;
@@ -589,15 +604,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   const double s0 = sm.sh[0], s1 = sm.sh[1];
   const double mu = s0 / N;
   if (t == 0) {
-    double c;
-    if (a.measure == 1) {
-      c = s1 / N;
-    } else {
-      double var = s1 / N - mu * mu;
-      if (var < 0) var = 0;
-      const double sd = sqrt(var);
-      c = sd * sd;
-    }
+    double mu_unused;
+    const double c = contrast_from_sums(s0, s1, N, a.measure, &mu_unused);
     sm.outv[0] = c;
     sm.outv[1] = mu;
     if (a.gate_out && !chain) *a.gate_out = gate_condition(c, a.gate_thr, a.gate_mode);  // read by the NEXT launch (kernel boundary)
@@ -630,6 +638,11 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   }
   __syncthreads();
   int nout = 2 + (a.P > a.gP ? a.P : a.gP);
+  if (CHAIN && nout < a.nout_pad) {  // (a fixed layout for the host whatever this launch computed)
+    if (t >= nout && t < a.nout_pad) sm.outv[t] = 0.0;
+    nout = a.nout_pad;
+    __syncthreads();
+  }
   if (chain) {
     // Device-driven solve: thread 0 feeds the machine what this evaluation produced -- f = -contrast after a cost evaluation,
     // df = -gradient after a gradient pass -- exactly what the host-driven loop feeds it (cmx_solver.cpp: contrast_fdf), and
@@ -639,22 +652,38 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     if (t == 0) {
       ChainMachine &s = sm.csm;
       constexpr int n = kChainMaxN;
-      int need = 0;
+      int need = 0, disagree = 0;
       if (a.chain.stage == 0) {
         need = sm_cost(s, -sm.outv[0]) ? 1 : 0;
-      } else {
+      } else if (a.chain.stage == 1) {
         double g[n];
         for (int k = 0; k < n; k++) g[k] = -sm.outv[2 + k];
         sm_grad(s, g);
+      } else {  // self-gating slot: the launch's workgroups decided from the same contrast whether to compute the gradient
+        const bool have_grad = a.gP > 0;
+        if ((gate_condition(sm.outv[0], s.gate_thr, s.gate_mode) != 0) != have_grad) {
+          disagree = 1;  // (cannot happen: same number, same expression) -- the machine is left where it was, the host takes over
+          __hip_atomic_store(a.chain.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          need = sm_cost(s, -sm.outv[0]) ? 1 : 0;
+          if (need != (have_grad ? 1 : 0)) {
+            disagree = 1;
+            __hip_atomic_store(a.chain.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (need) {
+            double g[n];
+            for (int k = 0; k < n; k++) g[k] = -sm.outv[2 + k];
+            sm_grad(s, g);
+          }
+        }
       }
-      const int done = sm_done(s) ? 1 : 0;
-      const bool moved = a.chain.stage == 1 || !need;  // the machine has gone on to its next request
+      const int done = (sm_done(s) || disagree) ? 1 : 0;
+      const bool moved = a.chain.stage != 0 || !need;  // the machine has gone on to its next request
       if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
       if (done) *a.chain.done = 1;                     // read by every later launch of the chain
       const double *xn = sm_point(s);
       sm.outv[nout] = (double)need;
       sm.outv[nout + 1] = (double)s.phase;
-      sm.outv[nout + 2] = (double)done;
+      sm.outv[nout + 2] = (double)(done | (disagree ? 2 : 0));
       for (int k = 0; k < n; k++) sm.outv[nout + 3 + k] = (moved && !done) ? xn[k] : 0.0;
       if (moved && !done)
         for (int k = 0; k < n; k++) a.chain.x_req[k] = xn[k];
@@ -1155,12 +1184,13 @@ size_t image_adjoint2_lds_bytes(int r) {
 // workgroups fit a CU only at <= 64 VGPRs (8 waves per SIMD), and 300 tiles on 256 CUs need the second one: at 76 VGPRs the
 // pass took 11 us instead of 8.2 -- hence the occupancy bound (the finalize body, run by one workgroup, may spill; the
 // image phases do not) and the compile-time switch.
-template <int R, bool LIST, int TAIL>  // TAIL: 0 none, 1 finalize in the last-arriving workgroup, 2 the same with the device-driven solve's step
+template <int R, bool LIST, int TAIL>  // TAIL: 0 none, 1 finalize in the last-arriving workgroup, 2 the same with the device-driven solve's
+                                       // step, 3 no finalize: the tile's moments go to accumulator rows (self-gating slots)
 __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void image_adjoint2_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ FinSmem fin_sm;
-  if (TAIL == 2 && g.img.skip && *g.img.skip) return;  // device-driven solve: finished
-  constexpr bool tail = TAIL != 0;
+  if (TAIL >= 2 && g.img.skip && *g.img.skip) return;  // device-driven solve: finished
+  constexpr bool tail = TAIL == 1 || TAIL == 2;
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads, NTAP = 4 * R + 1;
   constexpr int AW = TX + 4 * R, AH = TY + 4 * R, GH = TY + 2 * R;
   static_assert(NT == TX * TY, "one thread per tile pixel in the column pass");
@@ -1280,7 +1310,11 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
     double t0, t1;
     block_sum2(sI, sII, red, NT / 64, t0, t1);
     if (tid == 0) {
-      if (tail) {  // write-through: the last-arriving workgroup of this launch reads them
+      if (TAIL == 3) {  // accumulator rows: read by every workgroup of the gradient pass queued behind this launch
+        double *row = a.macc + (size_t)(slot % kTailShards) * 16;
+        if (t0 != 0.0) __hip_atomic_fetch_add(row, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t1 != 0.0) __hip_atomic_fetch_add(row + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (tail) {  // write-through: the last-arriving workgroup of this launch reads them
         st_sc1(a.partials + (size_t)0 * a.nblk + slot, t0);
         st_sc1(a.partials + (size_t)1 * a.nblk + slot, t1);
       } else {
@@ -1410,7 +1444,8 @@ void launch_image_adjoint(const ImgAdjArgs &a, hipStream_t s, hipEvent_t t0, hip
       if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, true, 1>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
       else CMX_LAUNCH((image_adjoint2_kernel<4, true, 0>), gl, dim3(kAdjThreads), lds2, s, t0, t1, a);
     } else {
-      if (tail && a.img.tail.fin.chain.sm) CMX_LAUNCH((image_adjoint2_kernel<4, false, 2>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      if (a.img.macc) CMX_LAUNCH((image_adjoint2_kernel<4, false, 3>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
+      else if (tail && a.img.tail.fin.chain.sm) CMX_LAUNCH((image_adjoint2_kernel<4, false, 2>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
       else if (tail) CMX_LAUNCH((image_adjoint2_kernel<4, false, 1>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
       else CMX_LAUNCH((image_adjoint2_kernel<4, false, 0>), dim3(a.img.nblk), dim3(kAdjThreads), lds2, s, t0, t1, a);
     }
@@ -1466,12 +1501,32 @@ int fe_gather_blocks(int n) {
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
 }
 
-template <bool CHAIN>
+// CHAIN: 0 plain; 1 device-driven solve, gated by the flag the cost stage's finalize wrote; 2 device-driven solve, SELF-GATING:
+// the image pass in front left the image's two moments in accumulator rows and ran no finalize -- every workgroup of this
+// launch forms the contrast from them (16 loads, the same expression the finalize uses) and evaluates the machine's
+// acceptance test itself.  Test passed: the launch is the gradient pass, its last-arriving workgroup runs the finalize and
+// BOTH machine steps (cost, then gradient).  Test failed: workgroup 0 alone runs the cost finalize and the machine's step, the
+// others leave.  The image pass loses its tail (last-arriver protocol + finalize + step: ~4 us of its 13) at every point.
+template <int CHAIN>
 __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
-  if (g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
+  if (CHAIN != 2 && g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
   if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
   __shared__ double red[4 * 6];
   __shared__ FinSmem fin_sm;
+  if (CHAIN == 2) {
+    const FinalizeArgs &fa = g.tail.fin;
+    double s0, s1, mu;
+    chain_moment_sums(fa.macc, s0, s1);
+    const double c = contrast_from_sums(s0, s1, fa.npix, fa.measure, &mu);
+    if (!gate_condition(c, fa.chain.sm->gate_thr, fa.chain.sm->gate_mode)) {
+      if (blockIdx.x != 0) return;
+      FinalizeArgs f = fa;  // cost only: no gradient sums to read
+      f.gP = 0;
+      f.gacc = nullptr;
+      finalize_body<256, true>(f, fin_sm);
+      return;
+    }
+  }
   if (CHAIN) fe_resolve_omega(g.ev);
   const FeSplatArgs &a = g.ev;
   double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
@@ -1569,13 +1624,14 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
     else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
-  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256, CHAIN>(g.tail.fin, fin_sm);
+  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256, CHAIN != 0>(g.tail.fin, fin_sm);
 }
 
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int blocks = fe_gather_blocks(a.ev.n);
-  if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
-  else CMX_LAUNCH(fe_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  if (a.tail.fin.chain.sm && a.tail.fin.chain.stage == 2) CMX_LAUNCH(fe_gather_kernel<2>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  else if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<1>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  else CMX_LAUNCH(fe_gather_kernel<0>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
   return blocks;
 }
 

@@ -103,7 +103,9 @@ enum {
                                kernels (queued one slot ahead) read it; the host replays the machine on the reported costs /
                                gradients and takes over on any disagreement, so the result is that of the host-driven solve.
                                0: host-driven solve (one round trip to the host per evaluation); 2 / 3: test hooks -- the host takes
-                               over after three points / between a cost and its gradient, as it would after a disagreement */
+                               over after three points / between a cost and its gradient, as it would after a disagreement; 4: the first form of
+                               the slots (a finalize behind the image pass, a flag-gated gradient pass) also where the self-gating
+                               form applies (A/B) */
   CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
   CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
                              that kernel writes to mapped host memory after the results (a few microseconds sooner

@@ -13,7 +13,7 @@ from cmax_slam_amd import _lib, evaluator, synth  # noqa: E402
 
 
 def run(p, n_solves, label):
-    for chain in (0, 1, 0, 1):
+    for chain in (0, 4, 1, 0, 4, 1):
         fe = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
         fe.set_option(_lib.OPT_CHAIN_SOLVE, chain)
         fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)

@@ -52,7 +52,7 @@ STREAM_BYTES = {"frontend_fast_splat": 24e6, "frontend_fast_gather": 24e6, "back
 
 NAMES = {
     "fe_splat_lds_kernel": "frontend_fast_splat",
-    "fe_gather_kernel<false>": "frontend_fast_gather",  # the evaluations bench.py times (<true>: the device-driven solves, incl. gated-off launches)
+    "fe_gather_kernel<0>": "frontend_fast_gather",  # the evaluations bench.py times (<1>, <2>: the device-driven solves, incl. gated-off launches)
     "image_adjoint_kernel<4, 64, 16, 1024, false>": None,  # shared by both ends in one run: split by call order is not possible
     "be_splat_lds_kernel": "backend_fast_splat", "be_gather4_kernel": "backend_fast_gather",
     "be_gather_batch_kernel": "backend_fast_batch", "be_pose_table_pre_kernel<4, true>": "backend_fast_pose",
