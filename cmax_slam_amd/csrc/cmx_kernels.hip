@@ -477,6 +477,49 @@ __device__ __forceinline__ void chain_moment_sums(const double *macc, double &s0
   s1 = a1;
 }
 
+// One step of the device-driven solve's machine inside a finalize (thread 0): feed it what this evaluation produced -- f =
+// -contrast after a cost evaluation, df = -gradient after a gradient pass, exactly what the host-driven loop feeds it
+// (cmx_solver.cpp: contrast_fdf) -- and publish the next request: the evaluation point for the next slot's kernels, the gate of
+// a flag-gated gradient pass, the end of the solve.  outv[nout ..]: need / phase / done (| 2: disagreement) / next point.
+__device__ __forceinline__ void chain_step(const FinalizeArgs &a, ChainMachine &s, double *outv, int nout) {
+  constexpr int n = kChainMaxN;
+  int need = 0, disagree = 0;
+  if (a.chain.stage == 0) {
+    need = sm_cost(s, -outv[0]) ? 1 : 0;
+  } else if (a.chain.stage == 1) {
+    double g[n];
+    for (int k = 0; k < n; k++) g[k] = -outv[2 + k];
+    sm_grad(s, g);
+  } else {  // self-gating slot: the launch's workgroups decided from the same contrast whether to compute the gradient
+    const bool have_grad = a.gP > 0;
+    if ((gate_condition(outv[0], s.gate_thr, s.gate_mode) != 0) != have_grad) {
+      disagree = 1;  // (cannot happen: same number, same expression) -- the machine is left where it was, the host takes over
+    } else {
+      need = sm_cost(s, -outv[0]) ? 1 : 0;
+      if (need != (have_grad ? 1 : 0)) {
+        disagree = 1;
+      } else if (need) {
+        double g[n];
+        for (int k = 0; k < n; k++) g[k] = -outv[2 + k];
+        sm_grad(s, g);
+      }
+    }
+    if (disagree) __hip_atomic_store(a.chain.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int done = (sm_done(s) || disagree) ? 1 : 0;
+  const bool moved = a.chain.stage != 0 || !need;  // the machine has gone on to its next request
+  if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
+  if (done) *a.chain.done = 1;                     // read by every later launch of the chain
+  outv[nout] = (double)need;
+  outv[nout + 1] = (double)s.phase;
+  outv[nout + 2] = (double)(done | (disagree ? 2 : 0));
+  for (int k = 0; k < n; k++) {
+    const double xk = s.req_at_x ? s.x[k] : s.x1[k];
+    outv[nout + 3 + k] = (moved && !done) ? xk : 0.0;
+    if (moved && !done) a.chain.x_req[k] = xk;
+  }
+}
+
 template <int NT, bool CHAIN = false>  // CHAIN: the device-driven solve's variant (the machine's step is compiled in)
 __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm) {
   constexpr int NW = NT / 64;   // waves
@@ -650,43 +693,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
     // behind this launch, the end of the solve.  The result block carries need / phase / done / next point behind the
     // evaluation's own numbers; the host replays the machine on them and compares (cmx_chain.cpp).
     if (t == 0) {
-      ChainMachine &s = sm.csm;
-      constexpr int n = kChainMaxN;
-      int need = 0, disagree = 0;
-      if (a.chain.stage == 0) {
-        need = sm_cost(s, -sm.outv[0]) ? 1 : 0;
-      } else if (a.chain.stage == 1) {
-        double g[n];
-        for (int k = 0; k < n; k++) g[k] = -sm.outv[2 + k];
-        sm_grad(s, g);
-      } else {  // self-gating slot: the launch's workgroups decided from the same contrast whether to compute the gradient
-        const bool have_grad = a.gP > 0;
-        if ((gate_condition(sm.outv[0], s.gate_thr, s.gate_mode) != 0) != have_grad) {
-          disagree = 1;  // (cannot happen: same number, same expression) -- the machine is left where it was, the host takes over
-          __hip_atomic_store(a.chain.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          need = sm_cost(s, -sm.outv[0]) ? 1 : 0;
-          if (need != (have_grad ? 1 : 0)) {
-            disagree = 1;
-            __hip_atomic_store(a.chain.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else if (need) {
-            double g[n];
-            for (int k = 0; k < n; k++) g[k] = -sm.outv[2 + k];
-            sm_grad(s, g);
-          }
-        }
-      }
-      const int done = (sm_done(s) || disagree) ? 1 : 0;
-      const bool moved = a.chain.stage != 0 || !need;  // the machine has gone on to its next request
-      if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
-      if (done) *a.chain.done = 1;                     // read by every later launch of the chain
-      const double *xn = sm_point(s);
-      sm.outv[nout] = (double)need;
-      sm.outv[nout + 1] = (double)s.phase;
-      sm.outv[nout + 2] = (double)(done | (disagree ? 2 : 0));
-      for (int k = 0; k < n; k++) sm.outv[nout + 3 + k] = (moved && !done) ? xn[k] : 0.0;
-      if (moved && !done)
-        for (int k = 0; k < n; k++) a.chain.x_req[k] = xn[k];
+      // (the machine stays in LDS: a register copy of its ~60 words for the step took the gather to 256 VGPRs + scratch)
+      chain_step(a, sm.csm, sm.outv, nout);
     }
     nout += kChainExtra;
     __syncthreads();
