@@ -1,5 +1,6 @@
 // cmx_pipeline.cpp -- one evaluation on the context's stream: accumulation buffers (ping-pong), destination-tile sort,
 // image passes, gather, finalize and the completion ticket.  Shared by the front end and the back end.
+#include <cstdlib>
 #include "cmx_context.hpp"
 
 // Fast path: swap to the partner buffer if it is known clean, otherwise clear the current one.  After this call
@@ -92,9 +93,14 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   }
   rc = ensure(c, c->d_tile_start, c->tile_start_cap, (size_t)ntiles + 2);
   if (rc) return rc;
-  // chunk size: hot tiles are split so that ~3 workgroups per CU exist; big chunks amortise the window flush
-  int M = n / 768;
-  M = M < 1536 ? 1536 : (M > 32768 ? 32768 : M);  // floor swept on MI355X (1M events: 1536 -> 11.8 us, 2048 -> 12.9, 1024 -> 15.3)
+  // chunk size: hot tiles are split so that the chunks fill the chip in ONE resident round; big chunks amortise the window
+  // zeroing and flush.  Back end: 135 VGPRs = 3 workgroups per CU, so n / 768 (swept at 5M events, splat us: 512 -> 50,
+  // 640 -> 51, 768 -> 44, 1152 -> 50, 1536 -> 48, 3072 -> 53: anything that needs a second round loses more than it gains in
+  // latency hiding; 128 VGPRs + 4 per CU and one event per thread + 4 per CU: no gain, 72 vs 81 us per cost evaluation).
+  // Front end (50 VGPRs, LDS-bound at 4 per CU): n / 512 (1M events, splat us: 256 -> 10.0, 384 -> 8.4, 512 -> 8.2, 640 -> 8.5,
+  // 768 -> 8.8; a 1M-event solve 0.567 -> 0.559 ms).
+  int M = n / (fe ? 512 : 768);
+  M = M < 1536 ? 1536 : (M > 32768 ? 32768 : M);  // floor swept on MI355X (1M events: 1536 -> 11.8 us, 1024 -> 15.3)
   M = (M + 255) / 256 * 256;
   // every tile contributes floor(len/M) full chunks and at most one remainder: an upper bound known on the host
   const int max_chunks = (n / M) + ntiles + 2 + n / 256;  // (+ the sentinel's events in chunks of 256: bound for 'all events rejected')
