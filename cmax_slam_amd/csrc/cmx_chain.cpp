@@ -31,7 +31,8 @@ int ensure_chain_buffers(cmx_ctx *c) {
   HIP_TRY(c, hipHostMalloc((void **)&c->h_chain_ring, (size_t)2 * kRingSlots * kBlock * sizeof(double), hipHostMallocMapped));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_chain_ring, c->h_chain_ring, 0));
   memset(c->h_chain_ring, 0, (size_t)2 * kRingSlots * kBlock * sizeof(double));
-  HIP_TRY(c, hipHostMalloc((void **)&c->h_chain_init, 2 * sizeof(ChainDev), hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_chain_init, 2 * sizeof(ChainDev), hipHostMallocMapped));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_chain_init, c->h_chain_init, 0));
   return CMX_OK;
 }
 
@@ -80,8 +81,11 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   const size_t np = (size_t)W * H;
   const int r = slot % kRingSlots;
   const double zero[3] = {0, 0, 0};
+  const bool first = c->chain_first;              // warm start: omega as kernel arguments, no end-of-solve flag, machine from the host
+  const double *x = first ? c->chain_x0 : zero;
+  const unsigned par = (c->chain_seq + (unsigned)slot) & 1u;  // moment rows this slot adds to (cleared by the slot before it)
   c->last_adjoint = true;
-  int rc = fe_accumulate(c, zero, 1);  // splat (omega from device memory; re-sorts first when due)
+  int rc = fe_accumulate(c, x, 1);  // splat (omega from device memory; re-sorts first when due)
   if (rc) return rc;
   if (!c->streams_valid || !c->bin_valid) return fail(c, CMX_ERR_STATE, "self-gating slot without the tile-ordered streams");
   float *jt_before = c->d_itilde;
@@ -105,12 +109,12 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
     a.zero_planes = c->pingpong_planes;
     c->alt_clean = true;
   }
-  a.skip = &c->d_chain->done;
-  a.macc = &c->d_chain->macc[slot & 1][0][0];
+  a.skip = first ? nullptr : &c->d_chain->done;
+  a.macc = &c->d_chain->macc[par][0][0];
   launch_image_adjoint(ia, c->stream);
   // ---- the self-gating launch: cost finalize + machine step, and the gradient pass when the machine's test says so
   FeGatherArgs g{};
-  g.ev = fe_args(c, zero);
+  g.ev = fe_args(c, x);
   g.itilde = c->d_itilde;
   g.gpartials = nullptr;
   g.cx = c->d_cx; g.cy = c->d_cy; g.r = c->radius;
@@ -128,13 +132,14 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   f.gacc_stride = kGaccStride;
   f.fallback = c->d_fallback;
   f.macc = a.macc;
-  f.macc_clear = &c->d_chain->macc[(slot + 1) & 1][0][0];
+  f.macc_clear = &c->d_chain->macc[par ^ 1u][0][0];
   f.nout_pad = 2 + 3;
   f.chain.sm = &c->d_chain->sm;
   f.chain.x_req = c->d_chain->x_req;
   f.chain.done = &c->d_chain->done;
   f.chain.abort_flag = &c->d_chain->abort_flag;
   f.chain.stage = 2;
+  f.chain.sm_src = first ? &c->d_chain_init[c->chain_init_sel].sm : nullptr;
   f.ticket = ++c->ticket_issued;
   g.tail.counters = c->d_tail_counters;
   launch_fe_gather(g, c->stream);
@@ -175,14 +180,25 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   // ---- the machine's initial state -> device: ONE stream-ordered copy in front of the first slot.  Two pinned staging blocks
   // alternate, so the copy of the previous solve (long finished: its results were waited for) is never overwritten in flight
   // by the one after next.
+  // Warm start (the previous device-driven solve ended normally on self-gating slots): no copy at all -- the first slot's kernels
+  // take omega as arguments and its finalizing workgroup reads the machine's ~60 words from the pinned block (one PCIe read,
+  // ~1.5 us inside the slot's tail, against a 4 us copy kernel and a launch boundary in front of the solve).
+  const bool warm = c->chain_warm && self_gating_ok(c) && hs.gate_mode == 4 && hs.req_at_x;
+  c->chain_warm = false;  // true again only if THIS solve ends normally
   {
     ChainDev *st = c->h_chain_init + (c->chain_init_sel ^= 1);
     memset(st, 0, sizeof(ChainDev));
     sm_to_fixed<kChainMaxN>(hs, st->sm);
-    for (int k = 0; k < 3; k++) st->x_req[k] = hs.x[k];
+    for (int k = 0; k < 3; k++) st->x_req[k] = c->chain_x0[k] = hs.x[k];
     st->done = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_chain, st, sizeof(ChainDev), hipMemcpyHostToDevice, c->stream));
+    if (!warm) {
+      HIP_TRY(c, hipMemcpyAsync(c->d_chain, st, sizeof(ChainDev), hipMemcpyHostToDevice, c->stream));
+      c->chain_seq = 0;
+    } else {
+      c->chain_warm_starts++;
+    }
   }
+  bool all_self_gating = true;
   SlotTickets tick[kRingSlots];
   int queued = 0, consumed = 0;
   bool diverged = false, unsupported = false;
@@ -192,8 +208,11 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   while (!sm_done(hs)) {
     while (queued < consumed + kAhead) {
       tick[queued % kRingSlots] = SlotTickets{};
+      c->chain_first = warm && queued == 0;
       rc = self_gating_ok(c) ? queue_slot_self_gating(c, queued, &tick[queued % kRingSlots]) : queue_slot(c, queued, &tick[queued % kRingSlots]);
+      c->chain_first = false;
       if (rc) break;
+      all_self_gating = all_self_gating && tick[queued % kRingSlots].self_gating;
       if (!tick[queued % kRingSlots].gated) { unsupported = true; }  // no gated gradient pass in this configuration
       queued++;
       if (unsupported) break;
@@ -267,8 +286,25 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   }
   c->x_valid = false;
   c->jt_valid = false;
-  c->accum_clean = false;  // (which of the two ping-pong buffers the last EXECUTED slot used is not tracked: both are cleared
-  c->alt_clean = false;    //  by the next evaluation's memset)
+  if (!rc && !diverged && !unsupported && sm_done(hs) && all_self_gating && consumed >= 1 && c->pingpong_planes > 0 && c->d_accum_alt) {
+    // Normal end: slots [0, consumed) ran, the ones queued behind them return on their first instruction and touch nothing.
+    // So the planes of slot consumed-1 are the only dirty ones (its image pass cleared the partner), the moment rows it did not
+    // add to are clear, accumulator rows and tickets are zero -- exactly what the next solve's first slot needs.  The host's
+    // bookkeeping went on through the skipped slots: put it back on the buffer the last EXECUTED slot wrote.
+    if ((queued - consumed) & 1) {
+      std::swap(c->d_accum, c->d_accum_alt);
+      std::swap(c->accum_cap, c->accum_alt_cap);
+      std::swap(c->d_tflags, c->d_tflags_alt);
+      std::swap(c->accum_flagged, c->alt_flagged);
+    }
+    c->accum_clean = false;
+    c->alt_clean = true;
+    c->chain_seq += (unsigned)consumed;
+    c->chain_warm = true;
+  } else {
+    c->accum_clean = false;  // which of the two ping-pong buffers the last executed slot used is not known: both are cleared
+    c->alt_clean = false;    // by the next evaluation's memset
+  }
   c->accumulated = false;
   c->gated_pending = false;
   c->gate_mode = 0;

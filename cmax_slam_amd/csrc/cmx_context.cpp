@@ -439,6 +439,7 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[13] = (double)c->chain_solves;
   stats[14] = (double)c->chain_slots;
   stats[15] = (double)c->chain_takeovers;
+  stats[16] = (double)c->chain_warm_starts;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

@@ -205,8 +205,15 @@ struct cmx_ctx {
   double *h_chain_ring = nullptr, *d_chain_ring = nullptr;  // mapped result blocks: 2 per slot (cost stage, gradient stage)
   ChainDev *h_chain_init = nullptr;   // pinned staging of the machine's initial state (two blocks, alternating per solve)
   int chain_init_sel = 0;
+  ChainDev *d_chain_init = nullptr;   // the same two blocks as the device sees them
+  bool chain_warm = false;            // the last device-driven solve ended normally on self-gating slots: d_chain's flags and moment
+                                      // rows, the ping-pong planes and the accumulator rows are in the state the next solve's first
+                                      // slot expects -- it starts without the initial copy and without clearing anything
+  bool chain_first = false;           // set while the first slot of a warm-started solve is being queued
+  unsigned chain_seq = 0;             // slots executed so far on d_chain (parity = which moment rows the next slot adds to)
+  double chain_x0[3] = {0, 0, 0};
   double *chain_block_a = nullptr, *chain_block_g = nullptr;  // device pointers of the blocks of the slot being queued
-  int64_t chain_solves = 0, chain_slots = 0, chain_takeovers = 0;
+  int64_t chain_solves = 0, chain_slots = 0, chain_takeovers = 0, chain_warm_starts = 0;
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
   double *d_gacc = nullptr;             // kTailShards x kGaccStride gradient accumulators of the tail finalize, all-zero between launches

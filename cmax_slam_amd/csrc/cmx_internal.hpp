@@ -81,6 +81,9 @@ struct ChainArgs {
   int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass, 2: a self-gating slot (cost, then the gradient
                      //    if the launch computed one: FinalizeArgs::gP > 0)
   int *abort_flag;
+  const ChainMachine *sm_src;  // first slot of a warm-started solve: the machine's INITIAL state, read from pinned host memory by the
+                               // one finalizing workgroup (no copy in front of the solve); the slot's kernels get omega as arguments,
+                               // no end-of-solve flag, and take the machine's first request for what it always is (cost + gradient)
 };
 constexpr int kChainExtra = 3 + kChainMaxN;  // result words appended by a chained finalize: need-gradient flag, phase, done, next point
 

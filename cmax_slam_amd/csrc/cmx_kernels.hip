@@ -510,6 +510,7 @@ __device__ __forceinline__ void chain_step(const FinalizeArgs &a, ChainMachine &
   const bool moved = a.chain.stage != 0 || !need;  // the machine has gone on to its next request
   if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
   if (done) *a.chain.done = 1;                     // read by every later launch of the chain
+  else if (a.chain.sm_src) *a.chain.done = 0;      // (first slot of a warm start: the flag still says the previous solve ended)
   outv[nout] = (double)need;
   outv[nout + 1] = (double)s.phase;
   outv[nout + 2] = (double)(done | (disagree ? 2 : 0));
@@ -532,7 +533,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, FinSmem &sm
   constexpr int kSmWords = (int)(sizeof(ChainMachine) / 8);
   static_assert(sizeof(ChainMachine) % 8 == 0 && kSmWords <= NT, "the machine is copied by one thread per word");
   if (chain && t < kSmWords)  // the machine's state (written by the previous evaluation's finalize: an earlier launch) -> LDS
-    reinterpret_cast<unsigned long long *>(&sm.csm)[t] = reinterpret_cast<const unsigned long long *>(a.chain.sm)[t];
+    reinterpret_cast<unsigned long long *>(&sm.csm)[t] =
+        reinterpret_cast<const unsigned long long *>(a.chain.sm_src ? a.chain.sm_src : a.chain.sm)[t];
   // Everything this workgroup reads was written by other CUs: each dependent round of loads is a ~1.2 us trip to memory.
   // The reads that do not depend on one another -- fallback counter, accumulator rows, moment rows -- are issued together.
   unsigned fb_count = 0u;
@@ -1526,7 +1528,8 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     double s0, s1, mu;
     chain_moment_sums(fa.macc, s0, s1);
     const double c = contrast_from_sums(s0, s1, fa.npix, fa.measure, &mu);
-    if (!gate_condition(c, fa.chain.sm->gate_thr, fa.chain.sm->gate_mode)) {
+    // (first slot of a warm start: the machine's first request is cost + gradient, gate mode 4 -- its state is still on the host)
+    if (!fa.chain.sm_src && !gate_condition(c, fa.chain.sm->gate_thr, fa.chain.sm->gate_mode)) {
       if (blockIdx.x != 0) return;
       FinalizeArgs f = fa;  // cost only: no gradient sums to read
       f.gP = 0;

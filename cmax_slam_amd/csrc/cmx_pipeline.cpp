@@ -201,7 +201,7 @@ FeSplatArgs fe_args(const cmx_ctx *c, const double omega[3]) {
   a.lut = c->d_lut;
   a.lut2 = c->d_lut2;
   a.planes = c->d_accum;
-  if (c->chain_active) {  // device-driven solve: omega and the end-of-solve flag live in device memory
+  if (c->chain_active && !c->chain_first) {  // device-driven solve: omega and the end-of-solve flag live in device memory
     a.w_dev = c->d_chain->x_req;
     a.skip = &c->d_chain->done;
   }

@@ -401,8 +401,9 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
  * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
  * (-1: whole plane), [8] = bytes the last sharded evaluation exchanged (all collectives, this rank's buffers), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
- * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement */
-#define CMX_N_STATS 16
+ * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement, [16] = device-driven
+ * solves that started warm (no initial copy, nothing cleared: the solve before them on this context ended normally) */
+#define CMX_N_STATS 17
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes
  * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added) */

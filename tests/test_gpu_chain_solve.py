@@ -92,7 +92,9 @@ def test_chain_solve_back_to_back_packets_and_ineligible_configurations(hip):
         dev = fe.setupProblemAndOptimize(np.zeros(3))
         host = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
         _close(dev, host)
-    assert fe.stats()["chain_solves"] == 4 and fe.stats()["chain_takeovers"] == 0
+    st = fe.stats()
+    assert st["chain_solves"] == 4 and st["chain_takeovers"] == 0
+    assert st["chain_warm_starts"] == 3   # every solve after the first started without the initial copy / any clearing
     # deterministic mode and the reference-shaped path are solved host-driven (and bitwise reproducibly in the former)
     fe.set_deterministic(True)
     a = fe.setupProblemAndOptimize(np.zeros(3))
@@ -136,3 +138,57 @@ def test_chain_solve_resorts_the_events_mid_solve_and_runs_beside_another_contex
     for i in range(2):
         _close(out[i], alone[i])
         assert evs[i].stats()["chain_solves"] == 5 and evs[i].stats()["chain_takeovers"] == 0
+
+
+def test_warm_started_solves_between_other_uses_of_the_context(hip, oracle):
+    """A device-driven solve that ends normally leaves the device-side state (end-of-solve flag, moment rows, ping-pong planes,
+    accumulator rows) as the next solve's first slot expects it: that solve starts without the initial copy and without clearing
+    anything (stats: chain_warm_starts).  Whatever happens in between -- plain evaluations, an image read-back, a new packet, a
+    solve the host took over (cold start after it), a host-driven solve -- every solve must reach what the host-driven one does."""
+    p = synth.frontend_packet(120_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=95)
+    q = synth.frontend_packet(70_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=96)
+    host_p = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
+    host_q = _fe(hip, q, 0).setupProblemAndOptimize(np.zeros(3))
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    fe = _fe(hip, p, 1)
+    warm = 0
+    for k in range(6):
+        dev = fe.setupProblemAndOptimize(np.zeros(3))
+        _close(dev, host_p)
+        assert fe.stats()["chain_warm_starts"] == warm, (k, fe.stats())
+        warm += 1
+        if k == 1:      # plain evaluations between two solves (they use the ping-pong planes and the accumulator rows)
+            for x in (np.zeros(3), dev[0]):
+                c, g = fe.eval(x)
+                c_ref, g_ref = ref.eval(x)
+                assert abs(c - c_ref) < 1e-5 * abs(c_ref) and np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()
+        if k == 2:      # the image of the last evaluated point
+            iwe = fe.computeImageOfWarpedEvents(dev[0])
+            assert np.isfinite(iwe).all() and iwe.sum() > 0
+        if k == 3:      # odd and even numbers of cost-only evaluations in between (which ping-pong plane is the clean one)
+            fe.eval(0.5 * dev[0], False)
+        if k == 4:
+            fe.eval(0.5 * dev[0], False)
+            fe.eval(0.25 * dev[0], False)
+    # a new packet on the same context: still warm
+    fe.set_packet(q.x, q.y, q.t_ns, q.t_ref_ns, q.fx, q.fy, q.cx, q.cy, q.batch, q.sigma, _lib.VARIANCE)
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    assert fe.stats()["chain_warm_starts"] == warm
+    warm += 1
+    # a solve the host takes over leaves nothing to rely on: the next one starts cold, the one after it warm again
+    fe.set_option(_lib.OPT_CHAIN_SOLVE, 2)
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    assert fe.stats()["chain_takeovers"] == 1 and fe.stats()["chain_warm_starts"] == warm   # (the taken-over solve itself started warm)
+    fe.set_option(_lib.OPT_CHAIN_SOLVE, 1)
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    assert fe.stats()["chain_warm_starts"] == warm       # cold
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    warm += 1
+    assert fe.stats()["chain_warm_starts"] == warm       # warm again
+    # a host-driven solve in between does not disturb the state
+    fe.set_option(_lib.OPT_CHAIN_SOLVE, 0)
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    fe.set_option(_lib.OPT_CHAIN_SOLVE, 1)
+    _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
+    assert fe.stats()["chain_warm_starts"] == warm + 1 and fe.stats()["chain_takeovers"] == 1
