@@ -338,6 +338,8 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
         n_comm = cal["comm"][1] / ncal
         out["comm"] = {"ms_per_step": kernel_ms["comm"] * n_comm, "collectives_per_step": n_comm,
                        "share_of_step": kernel_ms["comm"] * n_comm / ms_step,
+                       "bytes_last_evaluation": stats.get("comm_bytes"), "exchange_set_tiles": stats.get("exchange_tiles"),
+                       "exchange_misses": stats.get("exchange_misses"),
                        "note": "RCCL collectives as seen on rank 0's stream in the calibration steps: the exchange plus the wait "
                                "for the slowest rank"}
     out["_last"] = (c, g)

@@ -179,7 +179,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   HIP_TRY(c, hipMemsetAsync(c->d_alpha, 0, sizeof(double), c->stream));  // on the context's (non-blocking) stream: ordered before its kernels
   c->h_result[kAlphaSlot] = 0.0;  // alpha mirror
   c->first_iter = true;     // setFirstIter(true), pose_graph_optimizer.cpp:293
-  comm_reset_band(c);       // sharded large panoramas: the first exchange of a window covers the whole plane
+  comm_reset_xset(c);       // sharded panoramas: the first exchange of a window covers the whole planes
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (nb && d_raw) {
     long long e[2] = {0, 0};

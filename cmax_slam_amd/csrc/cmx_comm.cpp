@@ -14,8 +14,6 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -33,8 +31,6 @@ RcclApi &rccl() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
-    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");  // optional: fuses the per-plane band collectives
-    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
     return a;
   }();
@@ -58,35 +54,49 @@ int comm_allreduce(cmx_ctx *c, void *buf, size_t count, int dt /* CMX_DT_* */, i
 
 // Exchange of the partial planes between splat and blur.
 // Which collectives are issued depends on RANK-INVARIANT state only -- context kind, plane size, what the accumulate call
-// produced (a function of the options and of the call itself), the row band every rank derived from the same all-reduced
-// flags -- never on a rank's own event count: mismatched collectives are undefined behaviour in RCCL.
+// produced (a function of the options and of the call itself), the size of the exchange set every rank derived from the same
+// all-reduced flags -- never on a rank's own event count: mismatched collectives are undefined behaviour in RCCL.
 //
-// Large panoramas (planes of 8 MB and more): the ranks' votes cover a few tile rows of a mostly empty map.  The
-// tile-occupancy flags (a few KB) are all-reduced with max; band_kernel reduces them to the first / last touched tile
-// row and writes that to mapped host memory; the planes are then summed over the band of rows the PREVIOUS evaluation
-// found, widened by kBandMargin tile rows (the whole plane while no band is known) -- 64 MB per evaluation become ~16 MB
-// at 4096x2048 (BASELINE config 5) with no host synchronisation between splat and blur.  band_kernel also reports whether
-// a touched row lay outside the band that was exchanged; finish_sharded() then completes the evaluation with a whole-plane exchange (rare: the
-// parameters moved the votes by more than two tile rows between two evaluations).
-constexpr size_t kSparseExchangeMinPlaneBytes = (size_t)8 << 20;
-constexpr int kBandMargin = 2;
-static int allreduce_rows(cmx_ctx *c, int tile_row0, int tile_row1 /* exclusive */) {
+// Panoramas (planes of 1 MB and more): a window's votes cover a few per cent of the map (BASELINE config 4: ~3 % of the tiles of
+// two 4 MB planes; config 5: ~1 % of two 32 MB planes), and every rank's slab of the window covers a part of that.  So the
+// tile-occupancy flags (a few KB) are all-reduced with max first, and what travels is the EXCHANGE SET: the tiles any rank
+// flagged in the PREVIOUS evaluation, dilated (xset_kernel) -- packed from both planes into one staging buffer, summed by ONE
+// collective, unpacked.  Its size is known on the host from the previous evaluation's result words, so nothing is waited for
+// between splat and blur.  xset_kernel also lists the flagged tiles the set did NOT cover (the parameters moved the votes
+// further than the dilation); finish_sharded() then completes the evaluation with a second exchange of exactly those tiles.
+// The first evaluation of a window, and sets of more than half of the map, exchange the whole planes.
+constexpr size_t kSparseExchangeMinPlaneBytes = (size_t)1 << 20;
+static int ensure_xset(cmx_ctx *c, size_t ntiles) {
+  if (ntiles <= c->xset_tiles_cap && c->d_xmiss) return CMX_OK;
+  void **ptrs[5] = {(void **)&c->d_xlist[0], (void **)&c->d_xlist[1], (void **)&c->d_xmember[0], (void **)&c->d_xmember[1],
+                    (void **)&c->d_xmiss};
+  const size_t bytes[5] = {ntiles * sizeof(int), ntiles * sizeof(int), ntiles, ntiles, ntiles * sizeof(int)};
+  for (int k = 0; k < 5; k++) {
+    if (*ptrs[k]) HIP_TRY(c, hipFree(*ptrs[k]));
+    *ptrs[k] = nullptr;
+    HIP_TRY(c, hipMalloc(ptrs[k], bytes[k]));
+  }
+  c->xset_tiles_cap = ntiles;
+  c->xset_n = -1;  // (whatever set was known lived in the old buffers)
+  return CMX_OK;
+}
+// both planes' tiles of `list` -> staging -> all-reduce -> back
+static int exchange_tiles(cmx_ctx *c, const int *list, int n) {
+  if (n <= 0) return CMX_OK;
   const size_t np = (size_t)c->Wp * c->Hp;
-  const size_t row0 = (size_t)tile_row0 * kTileY, row1 = std::min((size_t)tile_row1 * kTileY, (size_t)c->Hp);
-  if (row1 <= row0) return CMX_OK;
-  // the two planes' bands are two regions of memory: one RCCL group = one launch instead of two (native communicator only;
-  // a caller-supplied transport sees the two calls)
-  const bool group = c->comm && rccl().GroupStart && rccl().GroupEnd;
-  if (group) rccl().GroupStart();
-  int rc = CMX_OK;
-  for (int plane = 0; plane < 2 && !rc; plane++)
-    rc = comm_allreduce(c, c->d_accum + plane * np + row0 * c->Wp, (row1 - row0) * c->Wp, CMX_DT_F32);
-  if (group && rccl().GroupEnd() != ncclSuccess && !rc) rc = fail(c, CMX_ERR_HIP, "ncclGroupEnd failed");
-  return rc;
+  const size_t need = (size_t)2 * n * kTileX * kTileY;
+  int rc = ensure(c, c->d_xstage, c->xstage_cap, need);
+  if (rc) return rc;
+  launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n, c->d_xstage, c->stream);
+  rc = comm_allreduce(c, c->d_xstage, need, CMX_DT_F32);
+  if (rc) return rc;
+  launch_xset_copy(true, c->d_accum, np, c->Wp, c->Hp, list, n, c->d_xstage, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return CMX_OK;
 }
 static int exchange_planes(cmx_ctx *c) {
   const size_t np = (size_t)c->Wp * c->Hp;
-  c->band_pending = false;
+  c->xset_pending = false;
   const bool sparse = c->kind == KIND_BE && c->accum_flagged && c->d_tflags && np * sizeof(float) >= kSparseExchangeMinPlaneBytes &&
                       c->accum_count == 2 * np;
   if (!sparse) {
@@ -103,17 +113,20 @@ static int exchange_planes(cmx_ctx *c) {
     return rc;
   }
   const int tiles_x = (c->Wp + kTileX - 1) / kTileX, tiles_y = (c->Hp + kTileY - 1) / kTileY;
-  int rc = comm_allreduce(c, c->d_tflags, (size_t)tiles_x * tiles_y, CMX_DT_U8, CMX_OP_MAX);
+  const int ntiles = tiles_x * tiles_y;
+  int rc = ensure_xset(c, (size_t)ntiles);
   if (rc) return rc;
-  int lo = c->band_lo, hi = c->band_hi;
-  if (hi < lo) { lo = 0; hi = tiles_y - 1; }  // no band known yet (first evaluation of a window): the whole plane
-  launch_band(c->d_tflags, tiles_x, tiles_y, lo, hi, c->d_result + kBandSlot, ++c->band_seq, c->stream);
+  rc = comm_allreduce(c, c->d_tflags, (size_t)ntiles, CMX_DT_U8, CMX_OP_MAX);
+  if (rc) return rc;
+  const int cur = c->xset_cur, n = c->xset_n;
+  const bool use_set = n >= 0 && 2 * n <= ntiles;  // (rank-invariant: n derives from the all-reduced flags of the previous evaluation)
+  launch_xset(c->d_tflags, tiles_x, tiles_y, use_set ? c->d_xmember[cur] : nullptr, c->d_xlist[cur ^ 1], c->d_xmember[cur ^ 1], c->d_xmiss,
+              c->d_result + kXsetSlot, ++c->xset_seq, c->stream);
   HIP_TRY(c, hipGetLastError());
-  rc = allreduce_rows(c, lo, hi + 1);
+  rc = use_set ? exchange_tiles(c, c->d_xlist[cur], n) : comm_allreduce(c, c->d_accum, c->accum_count, CMX_DT_F32);
   if (rc) return rc;
-  c->band_pending = true;
-  c->band_used_lo = lo;
-  c->band_used_hi = hi;
+  c->xset_pending = true;
+  c->xset_used = use_set;
   return CMX_OK;
 }
 
@@ -124,10 +137,9 @@ void comm_release(cmx_ctx *c) {
   c->comm = nullptr;
   c->comm_fn = nullptr;
 }
-void comm_reset_band(cmx_ctx *c) {
-  c->band_lo = 0;
-  c->band_hi = -1;
-  c->band_pending = false;
+void comm_reset_xset(cmx_ctx *c) {
+  c->xset_n = -1;
+  c->xset_pending = false;
 }
 
 static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad) {
@@ -157,42 +169,34 @@ int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double
     if (rc) return rc;
   }
   rc = finish_exchanged(c, kind, contrast, grad);
-  if (rc || !exchange || !c->band_pending) return rc;
-  // the results are on the host, and with them what band_kernel found (written by an earlier kernel of the same stream)
-  c->band_pending = false;
-  const int tiles_y = (c->Hp + kTileY - 1) / kTileY;
+  if (rc || !exchange || !c->xset_pending) return rc;
+  // the results are on the host, and with them what xset_kernel found (written by an earlier kernel of the same stream)
+  c->xset_pending = false;
   // ... in an EARLIER kernel than the finalize whose ticket was waited for, outside its checksummed snapshot: the words carry
-  // their own stamp.  A rank that read a stale band would choose another exchange than its peers (a hang), so a snapshot
+  // their own stamp.  A rank that read stale words would choose another exchange than its peers (a hang), so a snapshot
   // that does not verify is re-read, then the stream is synchronised, and only then is it an error.
-  double bw[3] = {0, 0, 0};
-  bool band_ok = false;
-  for (int attempt = 0; attempt < 3 && !band_ok; attempt++) {
-    for (int spin = 0; spin < 20000 && !band_ok; spin++) {
-      const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result + kBandSlot);
+  double xw[3] = {0, 0, 0};
+  bool words_ok = false;
+  for (int attempt = 0; attempt < 3 && !words_ok; attempt++) {
+    for (int spin = 0; spin < 20000 && !words_ok; spin++) {
+      const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(c->h_result + kXsetSlot);
       const unsigned long long b0 = w[0], b1 = w[1], b2 = w[2], st = w[3];
-      if ((b0 ^ b1 ^ b2 ^ (c->band_seq * kTicketMix)) == st) {
-        memcpy(&bw[0], &b0, 8); memcpy(&bw[1], &b1, 8); memcpy(&bw[2], &b2, 8);
-        band_ok = true;
+      if ((b0 ^ b1 ^ b2 ^ (c->xset_seq * kTicketMix)) == st) {
+        memcpy(&xw[0], &b0, 8); memcpy(&xw[1], &b1, 8); memcpy(&xw[2], &b2, 8);
+        words_ok = true;
       }
     }
-    if (!band_ok) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!words_ok) HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  if (!band_ok) return fail(c, CMX_ERR_HIP, "the band kernel's result did not arrive (sequence %llu)", c->band_seq);
-  const int r0 = (int)bw[0], r1 = (int)bw[1];
-  const bool miss = bw[2] != 0.0;
-  if (r1 >= r0) {
-    c->band_lo = std::max(0, r0 - kBandMargin);
-    c->band_hi = std::min(tiles_y - 1, r1 + kBandMargin);
-  } else {
-    comm_reset_band(c);  // nobody voted anywhere
-  }
-  if (miss) {
-    // every rank read the same three numbers (they derive from the all-reduced flags), so every rank is here: the rows
-    // outside the exchanged band still hold partial sums -- exchange them and finish once more on the complete planes
-    c->band_misses++;
-    rc = allreduce_rows(c, 0, c->band_used_lo);
-    if (rc) return rc;
-    rc = allreduce_rows(c, c->band_used_hi + 1, tiles_y);
+  if (!words_ok) return fail(c, CMX_ERR_HIP, "the exchange-set kernel's result did not arrive (sequence %llu)", c->xset_seq);
+  const int n_next = (int)xw[0], n_miss = (int)xw[1];
+  c->xset_cur ^= 1;  // what xset_kernel wrote is the next evaluation's set
+  c->xset_n = n_next;
+  if (c->xset_used && n_miss > 0) {
+    // every rank read the same numbers (they derive from the all-reduced flags), so every rank is here: the listed tiles still
+    // hold partial sums -- exchange exactly those and finish once more on the complete planes
+    c->xset_misses++;
+    rc = exchange_tiles(c, c->d_xmiss, n_miss);
     if (rc) return rc;
     rc = finish_exchanged(c, kind, contrast, grad);
   }
@@ -217,7 +221,7 @@ int cmx_comm_attach(cmx_ctx *c, const char id[CMX_COMM_ID_BYTES], int rank, int 
   if (rc) return rc;
   if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
   c->comm_fn = nullptr;
-  comm_reset_band(c);
+  comm_reset_xset(c);
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
@@ -237,7 +241,7 @@ int cmx_comm_detach(cmx_ctx *c) {
   c->comm_user = nullptr;
   c->comm_size = 1;
   c->comm_rank = 0;
-  comm_reset_band(c);
+  comm_reset_xset(c);
   return CMX_OK;
 }
 int cmx_comm_attach_custom(cmx_ctx *c, cmx_allreduce_fn fn, void *user, int rank, int nranks) {

@@ -323,6 +323,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_My);
   hipFree(c->d_gpartials);
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
+  hipFree(c->d_xlist[0]); hipFree(c->d_xlist[1]); hipFree(c->d_xmember[0]); hipFree(c->d_xmember[1]); hipFree(c->d_xmiss); hipFree(c->d_xstage);
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
   hipFree(c->d_tail_counters);
@@ -429,8 +430,8 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[3] = (double)c->n_packed;
   stats[4] = (double)c->reuse_hits;
   stats[5] = (double)c->sharded_host_syncs;
-  stats[6] = (double)c->band_misses;
-  stats[7] = c->band_hi >= c->band_lo ? (double)(c->band_hi - c->band_lo + 1) : -1.0;
+  stats[6] = (double)c->xset_misses;
+  stats[7] = (double)c->xset_n;
   stats[8] = (double)c->comm_bytes_eval;
   stats[9] = (double)c->spec_images;
   stats[10] = (double)c->spec_hits;

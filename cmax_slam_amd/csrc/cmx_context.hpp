@@ -224,12 +224,19 @@ struct cmx_ctx {
   void *comm_user = nullptr;
   int comm_rank = 0, comm_size = 1;
   bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
-  // row band of the sparse plane exchange (tile rows, inclusive); band_hi < band_lo: unknown -> whole plane
-  int band_lo = 0, band_hi = -1;
-  bool band_pending = false;       // the last evaluation ran the band kernel: its result waits in h_result[kBandSlot..]
-  unsigned long long band_seq = 0; // sequence number of that launch (stamped into the result, see kBandSlot)
-  int band_used_lo = 0, band_used_hi = -1;  // what that evaluation actually exchanged (whole plane: 0 .. tiles_y-1)
-  int64_t sharded_host_syncs = 0, band_misses = 0;
+  // exchange set of the sparse plane exchange (cmx_comm.cpp): the tiles whose partial sums travel.  Two list / membership buffers
+  // alternate: [xset_cur] is what this evaluation exchanges, the other one is written by xset_kernel for the next evaluation.
+  int *d_xlist[2] = {nullptr, nullptr};
+  unsigned char *d_xmember[2] = {nullptr, nullptr};
+  int *d_xmiss = nullptr;
+  size_t xset_tiles_cap = 0;
+  float *d_xstage = nullptr;       // staging of the listed tiles of both planes (what the collective runs on)
+  size_t xstage_cap = 0;
+  int xset_cur = 0, xset_n = -1;   // tiles in [xset_cur]; -1: no set known (first evaluation of a window) -> whole planes
+  bool xset_pending = false;       // the last evaluation ran xset_kernel: its words wait in h_result[kXsetSlot..]
+  bool xset_used = false;          // ... and exchanged the set (not the whole planes)
+  unsigned long long xset_seq = 0; // sequence number of that launch (stamped into the words)
+  int64_t sharded_host_syncs = 0, xset_misses = 0;
   int64_t comm_bytes_eval = 0, comm_calls_eval = 0;  // bytes / collectives of the last sharded evaluation
 
   // timing
@@ -360,7 +367,7 @@ int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the f
 
 // ---- cmx_comm.cpp
 int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad);
-void comm_reset_band(cmx_ctx *c);  // a new window / packet / panorama: the next exchange covers the whole plane
+void comm_reset_xset(cmx_ctx *c);  // a new window / packet / panorama: the next exchange covers the whole planes
 void comm_release(cmx_ctx *c);  // destroys an attached communicator (cmx_destroy)
 
 // ---- cmx_frontend.cpp / cmx_backend.cpp: the bodies behind set_packet / set_window and their *_from forms

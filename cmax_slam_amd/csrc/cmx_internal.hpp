@@ -139,8 +139,8 @@ constexpr int kChecksumSlot = 4092;  // xor of the bit patterns of result[0..nou
 constexpr int kTicketSlot = 4093;    // ticket of the last finished evaluation
 constexpr int kFallbackSlot = 4094;  // votes that left their LDS window in that evaluation
 constexpr int kAlphaSlot = 4095;     // alpha mirror (back end)
-constexpr int kBandSlot = 4088;      // [0] first, [1] last flagged tile row of the all-reduced occupancy map, [2] = 1 if a flagged
-                                     // row lay outside the band this evaluation exchanged (sharded large panoramas), [3] = stamp:
+constexpr int kXsetSlot = 4088;      // sharded panoramas (xset_kernel): [0] tiles in the next evaluation's exchange set, [1] flagged tiles
+                                     // this evaluation's exchange did not cover, [2] flagged tiles, [3] = stamp:
                                      // bits[0] ^ bits[1] ^ bits[2] ^ (launch sequence number * kTicketMix)
 constexpr unsigned long long kTicketMix = 0x9E3779B97F4A7C15ull;
 
@@ -299,7 +299,9 @@ void launch_be_pose_table(const SplineArgs &spline, const long long *d_batch_t, 
 void launch_be_splat(const BeSplatArgs &a, bool deriv, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, unsigned long long seq, hipStream_t s);
+void launch_xset(const unsigned char *flags, int tiles_x, int tiles_y, const unsigned char *cur_member, int *next_list,
+                 unsigned char *next_member, int *miss_list, double *out, unsigned long long seq, hipStream_t s);
+void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const int *list, int n, float *stage, hipStream_t s);
 void launch_tile_flags_pair(const float *a, const float *b, int W, int H, unsigned char *flags, hipStream_t s);
 void launch_tile_flags(const float *plane, int W, int H, unsigned char *flags, hipStream_t s);  // flags[tile] = 1 where plane != 0
 void launch_alpha(const AlphaArgs &a, hipStream_t s);

@@ -769,56 +769,122 @@ __device__ __forceinline__ bool tail_arrive(const TailArgs &tl, int nblocks, int
   return sm.is_last != 0;
 }
 
-// Sharded large panoramas: first and last tile row that carries a flag in the (all-reduced) occupancy map, written to
-// mapped host memory for the NEXT evaluation's exchange, and whether any flagged row lies outside the band [lo, hi] the
-// host sized THIS evaluation's exchange for (cmx_comm.cpp).  One workgroup.
-__global__ __launch_bounds__(1024) void band_kernel(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out,
+// Sharded panoramas: the EXCHANGE SET.  The ranks' votes cover a few per cent of a panorama's tiles, so only those tiles
+// of the partial planes travel: flags = the occupancy map all-reduced with max (identical on every rank), cur_member = the set
+// the host sized THIS evaluation's exchange for (built by this kernel one evaluation earlier; null: the whole planes travel).
+// One workgroup writes
+//   next_list / next_member: the flagged tiles dilated by kXsetDx columns (wrapping: the panorama's seam) and kXsetDy rows, in
+//                            ascending tile order -- the next evaluation's exchange set (parameters move the votes by pixels);
+//   miss_list:               flagged tiles outside cur_member -- what this evaluation's exchange did not cover (a jump of the
+//                            parameters); the host completes the evaluation with a second exchange of exactly these;
+//   out[0..2] = |next|, |miss|, |flagged|, out[3] = stamp (the words lie outside the finalize's checksummed snapshot).
+constexpr int kXsetDx = 1, kXsetDy = 1;
+__global__ __launch_bounds__(1024) void xset_kernel(const unsigned char *flags, int tiles_x, int tiles_y, const unsigned char *cur_member,
+                                                    int *next_list, unsigned char *next_member, int *miss_list, double *out,
                                                     unsigned long long seq) {
-  __shared__ int sh_lo, sh_hi;
-  if (threadIdx.x == 0) { sh_lo = tiles_y; sh_hi = -1; }
-  __syncthreads();
-  int my_lo = tiles_y, my_hi = -1;
+  __shared__ int wave_tot[3][16];
+  constexpr int kLdsTiles = 16384;  // 8192 x 2048 pixels; larger maps read the flags through the caches
+  __shared__ __attribute__((aligned(16))) unsigned char sflags[kLdsTiles];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = tiles_x * tiles_y;
-  if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(flags) & 15) == 0) {  // 16 flags per load, every load of a thread in one round
-    for (int t = 16 * (int)threadIdx.x; t < n; t += 16 * 1024) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(flags + t);
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (w[q]) {
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            if ((w[q] >> (8 * b)) & 0xffu) {
-              const int row = (t + 4 * q + b) / tiles_x;
-              my_lo = min(my_lo, row);
-              my_hi = max(my_hi, row);
-            }
-        }
+  // the 3 x 3 neighbourhoods re-read every flag nine times: one coalesced pass brings the map into LDS first (a thread's
+  // dependent byte loads from L2 were 18 us of this kernel at 8192 tiles)
+  const unsigned char *fl = flags;
+  if (n <= kLdsTiles) {
+    if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(flags) & 15) == 0) {
+      for (int t = 16 * tid; t < n; t += 16 * 1024) *reinterpret_cast<uint4 *>(sflags + t) = *reinterpret_cast<const uint4 *>(flags + t);
+    } else {
+      for (int t = tid; t < n; t += 1024) sflags[t] = flags[t];
     }
-  } else {
-    for (int t = threadIdx.x; t < n; t += 1024)
-      if (flags[t]) {
-        const int row = t / tiles_x;
-        my_lo = min(my_lo, row);
-        my_hi = max(my_hi, row);
-      }
+    __syncthreads();
+    fl = sflags;
   }
-  if (my_hi >= 0) { atomicMin(&sh_lo, my_lo); atomicMax(&sh_hi, my_hi); }
+  // every thread owns a contiguous run of tiles: ONE workgroup-wide scan of the per-thread counts orders the lists
+  const int per = (n + 1023) / 1024;
+  const int t_beg = min(n, tid * per), t_end = min(n, t_beg + per);
+  unsigned nxt_bits = 0, miss_bits = 0;
+  int c_nxt = 0, c_miss = 0, c_flag = 0;
+  for (int t = t_beg; t < t_end; t++) {
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const bool f = fl[t] != 0;
+    int nxt = 0;
+    for (int dy = -kXsetDy; dy <= kXsetDy; dy++) {
+      const int yy = ty + dy;
+      if (yy < 0 || yy >= tiles_y) continue;
+      for (int dx = -kXsetDx; dx <= kXsetDx; dx++) nxt |= fl[yy * tiles_x + (tx + dx + tiles_x) % tiles_x] != 0;
+    }
+    const int miss = (f && cur_member && !cur_member[t]) ? 1 : 0;
+    next_member[t] = (unsigned char)nxt;
+    if (t - t_beg < 32) { nxt_bits |= (unsigned)nxt << (t - t_beg); miss_bits |= (unsigned)miss << (t - t_beg); }
+    c_nxt += nxt; c_miss += miss; c_flag += f ? 1 : 0;
+  }
+  int inc0 = c_nxt, inc1 = c_miss, inc2 = c_flag;  // inclusive scans inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v0 = __shfl_up(inc0, o, 64), v1 = __shfl_up(inc1, o, 64), v2 = __shfl_up(inc2, o, 64);
+    if (lane >= o) { inc0 += v0; inc1 += v1; inc2 += v2; }
+  }
+  if (lane == 63) { wave_tot[0][wave] = inc0; wave_tot[1][wave] = inc1; wave_tot[2][wave] = inc2; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] = (double)sh_lo;
-    out[1] = (double)sh_hi;
-    const double miss = (sh_hi >= 0 && (sh_lo < lo || sh_hi > hi)) ? 1.0 : 0.0;
-    out[2] = miss;
-    // the three words lie outside the finalize's checksummed snapshot: they carry their own stamp (sequence number of this
-    // launch mixed with their bit patterns), and the host accepts them only when the stamp matches what it read
-    reinterpret_cast<unsigned long long *>(out)[3] =
-        (unsigned long long)__double_as_longlong((double)sh_lo) ^ (unsigned long long)__double_as_longlong((double)sh_hi) ^
-        (unsigned long long)__double_as_longlong(miss) ^ (seq * kTicketMix);
+  int off0 = inc0 - c_nxt, off1 = inc1 - c_miss, tot0 = 0, tot1 = 0, tot2 = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wave) { off0 += wave_tot[0][w]; off1 += wave_tot[1][w]; }
+    tot0 += wave_tot[0][w];
+    tot1 += wave_tot[1][w];
+    tot2 += wave_tot[2][w];
+  }
+  for (int t = t_beg; t < t_end; t++) {
+    int nxt, miss;
+    if (t - t_beg < 32) {
+      nxt = (nxt_bits >> (t - t_beg)) & 1u;
+      miss = (miss_bits >> (t - t_beg)) & 1u;
+    } else {  // (maps beyond 32768 tiles: read back what the first pass stored / recompute)
+      nxt = next_member[t];
+      miss = (fl[t] != 0 && cur_member && !cur_member[t]) ? 1 : 0;
+    }
+    if (nxt) next_list[off0++] = t;
+    if (miss) miss_list[off1++] = t;
+  }
+  if (tid == 0) {
+    const double w0 = (double)tot0, w1 = (double)tot1, w2 = (double)tot2;
+    out[0] = w0;
+    out[1] = w1;
+    out[2] = w2;
+    reinterpret_cast<unsigned long long *>(out)[3] = (unsigned long long)__double_as_longlong(w0) ^ (unsigned long long)__double_as_longlong(w1) ^
+                                                      (unsigned long long)__double_as_longlong(w2) ^ (seq * kTicketMix);
   }
 }
-void launch_band(const unsigned char *flags, int tiles_x, int tiles_y, int lo, int hi, double *out, unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(band_kernel, dim3(1), dim3(1024), 0, s, flags, tiles_x, tiles_y, lo, hi, out, seq);
+void launch_xset(const unsigned char *flags, int tiles_x, int tiles_y, const unsigned char *cur_member, int *next_list,
+                 unsigned char *next_member, int *miss_list, double *out, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(xset_kernel, dim3(1), dim3(1024), 0, s, flags, tiles_x, tiles_y, cur_member, next_list, next_member, miss_list, out,
+                     seq);
+}
+
+// the listed tiles of both planes <-> one contiguous staging buffer [plane][entry][kTileY][kTileX] (pixels beyond the image: zero)
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void xset_copy_kernel(float *planes, size_t np, int W, int H, int tiles_x, const int *list, int n,
+                                                        float *stage) {
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int tile = list[i];
+  const int x0 = (tile % tiles_x) * kTileX, y0 = (tile / tiles_x) * kTileY;
+  float *img = planes + (size_t)plane * np;
+  float *st = stage + ((size_t)plane * n + i) * (kTileX * kTileY);
+  for (int p = threadIdx.x; p < kTileX * kTileY; p += 256) {
+    const int lx = p % kTileX, ly = p / kTileX;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool in = gx < W && gy < H;
+    if (UNPACK) {
+      if (in) img[(size_t)gy * W + gx] = st[p];
+    } else {
+      st[p] = in ? img[(size_t)gy * W + gx] : 0.f;
+    }
+  }
+}
+void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const int *list, int n, float *stage, hipStream_t s) {
+  if (n <= 0) return;
+  const int tiles_x = (W + kTileX - 1) / kTileX;
+  if (unpack) hipLaunchKernelGGL(xset_copy_kernel<true>, dim3(n, 2), dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage);
+  else hipLaunchKernelGGL(xset_copy_kernel<false>, dim3(n, 2), dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage);
 }
 
 size_t image_lds_bytes(int r) {

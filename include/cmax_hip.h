@@ -297,12 +297,12 @@ int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
  * and take identical optimiser decisions.  Every rank must use the same options (cmx_set_option) and issue the same
  * sequence of calls; which collectives an evaluation issues then depends on rank-invariant state only (plane size,
  * options, call sequence) -- never on how many events a rank happens to hold (an empty shard takes part like any other).
- * Back-end planes of 8 MB and more are exchanged as a band of image rows: the tile-occupancy flags are all-reduced
- * (max), a kernel reduces them to the first / last touched tile row, and the rows exchanged are the band the PREVIOUS
- * evaluation found (widened by two tile rows; the whole plane on a window's first evaluation) -- no host
- * synchronisation between splat and blur.  The same kernel reports whether a touched row lay outside that band; if so
- * (parameters jumped) the evaluation is completed by exchanging the remaining rows and finishing again.  Smaller planes
- * travel whole.  cmx_get_stats reports host synchronisations inside sharded evaluations (0) and band misses.
+ * Back-end planes of 1 MB and more are exchanged as a SET OF TILES (64 x 16 pixels): the tile-occupancy flags are all-reduced
+ * (max); the tiles exchanged -- packed from both planes into one staging buffer, one collective -- are those any rank flagged in
+ * the PREVIOUS evaluation, dilated by one tile in every direction (the whole planes on a window's first evaluation, or when
+ * the set exceeds half of the map) -- no host synchronisation between splat and blur.  A kernel lists the flagged tiles the set
+ * did not cover; if there are any (parameters jumped) the evaluation is completed by exchanging exactly those and finishing again.
+ * Smaller planes travel whole.  cmx_get_stats reports host synchronisations inside sharded evaluations (0), misses and set size.
  * Rank 0 creates the 128-byte id (cmx_comm_unique_id); the launcher distributes it by whatever means it has
  * (torch.distributed broadcast in bench.py, MPI, a file).  RCCL is dlopen()ed at this point only; hosts that never
  * attach a communicator do not need it installed. */
@@ -395,11 +395,11 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
 /* CMX_T_FINAL: the separate finalize launch (absent when CMX_OPT_TAIL_FINALIZE folds it into the last kernel);
  * CMX_T_BATCH: the back end's per-batch pass of the gradient gather.  Every class except CMX_T_ZERO / CMX_T_COMM is timed
  * through events carried by its (main) kernel: the dispatch's own begin / end timestamps, what rocprofv3 reports. */
-/* stats (16 doubles): [0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
+/* stats (CMX_N_STATS doubles): [0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
  * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
  * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
- * exchanged row band missed touched rows and were completed by a second exchange, [7] = tile rows in the current band
- * (-1: whole plane), [8] = bytes the last sharded evaluation exchanged (all collectives, this rank's buffers), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
+ * exchange set missed flagged tiles and were completed by a second exchange, [7] = tiles in the current exchange set
+ * (-1: none known, whole planes), [8] = bytes the last sharded evaluation exchanged (all collectives, this rank's buffers), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
  * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
  * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement, [16] = device-driven
  * solves that started warm (no initial copy, nothing cleared: the solve before them on this context ended normally) */

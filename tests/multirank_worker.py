@@ -65,7 +65,7 @@ def main():
         st = be.stats()
         assert st["sharded_host_syncs"] == 0
         if Wp == 4096:
-            assert st["band_rows"] > 0 and st["band_misses"] >= 1, st
+            assert st["exchange_tiles"] > 0 and st["exchange_misses"] >= 1, st
         x, rep = be.setupProblemAndOptimize()
         same_everywhere(rep["final_cost"], x)
         be.close()

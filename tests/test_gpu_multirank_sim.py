@@ -7,8 +7,8 @@ a host barrier (device -> host, reduce, host -> device).  What is checked is eve
   * both ranks issue the SAME sequence of collectives (count, dtype, op) -- also when one rank's shard is EMPTY
     (ADVICE r1: a rank without events used to take the whole-plane exchange while the others took the band exchange);
   * contrast and gradient equal the one-context evaluation of the whole window, and are bit-identical across ranks;
-  * the row-band exchange of large panoramas: band known after the first evaluation, no host synchronisation inside an
-    evaluation, and a jump of the parameters that moves the votes out of the band is detected and repaired."""
+  * the tile-set exchange of panoramas: set known after the first evaluation, no host synchronisation inside an
+    evaluation, and a jump of the parameters that moves the votes out of the set is detected and repaired."""
 import threading
 
 import numpy as np
@@ -105,7 +105,7 @@ def _check_sequence(ar, evs, one, seq):
         assert ar.calls[0] == ar.calls[1], (i, ar.calls[0][-6:], ar.calls[1][-6:])   # matched collectives
 
 
-def test_two_ranks_large_panorama_band_exchange_and_recovery(hip):
+def test_two_ranks_large_panorama_tile_set_exchange_and_recovery(hip):
     w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 4096, 2048, 2, 5, 0, 0.2, seed=47)
     IG = np.zeros((w.Hp, w.Wp), np.float32)
     IG[700:740, 1800:2300] = 1.3
@@ -117,25 +117,44 @@ def test_two_ranks_large_panorama_band_exchange_and_recovery(hip):
            (big, True), (big + rng.normal(0, 0.005, w.P), False), (np.zeros(w.P), True)]
     _check_sequence(ar, evs, one, seq[:3])
     s = evs[0].stats()
-    tiles_y = (w.Hp + 15) // 16
-    assert 0 < s["band_rows"] < tiles_y // 2 and s["band_misses"] == 0 and s["sharded_host_syncs"] == 0
-    # bytes the last (banded, cost-only) evaluation exchanged: the tile flags + a band of both planes -- a fraction of the
+    ntiles = ((w.Wp + 63) // 64) * ((w.Hp + 15) // 16)
+    assert 0 < s["exchange_tiles"] < ntiles // 8 and s["exchange_misses"] == 0 and s["sharded_host_syncs"] == 0
+    # bytes the last (cost-only) evaluation exchanged: the tile flags + the set's tiles of both planes -- a few per cent of the
     # 2 x 32 MB the whole planes would have been; both ranks count the same
     plane_bytes = w.Wp * w.Hp * 4
-    assert 0 < s["comm_bytes"] < 0.6 * 2 * plane_bytes and s["comm_bytes"] == evs[1].stats()["comm_bytes"]
-    assert s["comm_bytes"] >= 2 * s["band_rows"] * 16 * w.Wp * 4 * 0.5
+    assert ntiles < s["comm_bytes"] < 0.1 * 2 * plane_bytes and s["comm_bytes"] == evs[1].stats()["comm_bytes"]
     n_before = len(ar.calls[0])
     _check_sequence(ar, evs, one, seq[3:4])            # the jump: detected, repaired, results still right
     s = evs[0].stats()
-    assert s["band_misses"] == 1 and evs[1].stats()["band_misses"] == 1
-    # flags + 2 band planes, gradient sums, then the two complements x 2 planes and the gradient sums again
-    assert len(ar.calls[0]) - n_before >= 1 + 2 + 1 + 2 + 1
+    assert s["exchange_misses"] == 1 and evs[1].stats()["exchange_misses"] == 1
+    # flags, the set (one staging buffer), gradient sums, then the uncovered tiles and the gradient sums again
+    assert len(ar.calls[0]) - n_before == 1 + 1 + 1 + 1 + 1
     _check_sequence(ar, evs, one, seq[4:])
-    assert evs[0].stats()["band_misses"] <= 3 and evs[0].stats()["sharded_host_syncs"] == 0
-    # the first evaluation exchanged whole planes (no band yet); later ones a band
+    assert evs[0].stats()["exchange_misses"] <= 3 and evs[0].stats()["sharded_host_syncs"] == 0
+    # the first evaluation exchanged whole planes (no set yet); later ones a set of tiles
     floats = [c for c in ar.calls[0] if c[1] == _lib.DT_F32]
-    assert floats[0][0] == w.Wp * w.Hp and min(c[0] for c in floats) < w.Wp * w.Hp // 2
+    assert floats[0][0] == 2 * w.Wp * w.Hp and max(c[0] for c in floats[1:]) < w.Wp * w.Hp // 4
+    assert all(c[0] % (2 * 64 * 16) == 0 for c in floats[1:])
     assert rel_scalar(evs[0].alpha, one.alpha) < 1e-7 and one.alpha > 0
+
+
+def test_two_ranks_config4_sized_window_exchanges_a_set_of_tiles(hip):
+    """planes below 8 MB used to travel whole (BASELINE config 4: 2 x 4 MB per evaluation for ~3 % occupied
+    tiles).  The exchange set applies from 1 MB planes on: a 1024 x 1024 panorama's evaluations exchange the flags and a few
+    dozen tiles.  Results equal the single-GPU ones; a jump of the parameters is repaired like on the large panoramas."""
+    w = synth.backend_window(200_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 1024, 1024, 4, 10, 1, 0.3, seed=53)
+    ranges = [dist.batch_range(len(w.x), w.batch, r, 2) for r in range(2)]
+    ar, evs, one = _backend_pair(hip, w, None, ranges)
+    rng = np.random.default_rng(5)
+    seq = [(np.zeros(w.P), True)] + [(rng.normal(0, 0.004, w.P), k % 2 == 0) for k in range(6)]
+    _check_sequence(ar, evs, one, seq)
+    s = evs[0].stats()
+    assert s["exchange_misses"] == 0 and 0 < s["exchange_tiles"] < 1024 // 4, s
+    assert s["comm_bytes"] < 2 * (1 << 20), s        # flags + staged tiles (+ gradient rows when asked for): a quarter of 2 x 4 MB
+    assert s["comm_bytes"] == evs[1].stats()["comm_bytes"]
+    jump = np.tile([0.6, 0.0, 0.0], w.P // 3)        # 34 degrees about the camera's x axis: other tiles
+    _check_sequence(ar, evs, one, [(jump, True), (jump, False), (np.zeros(w.P), True)])
+    assert 1 <= evs[0].stats()["exchange_misses"] <= 2 and evs[0].stats()["sharded_host_syncs"] == 0, evs[0].stats()
 
 
 def test_two_ranks_with_an_empty_shard_issue_the_same_collectives(hip):
@@ -145,7 +164,7 @@ def test_two_ranks_with_an_empty_shard_issue_the_same_collectives(hip):
     rng = np.random.default_rng(4)
     seq = [(np.zeros(w.P), True), (rng.normal(0, 0.01, w.P), False), (rng.normal(0, 0.01, w.P), True)]
     _check_sequence(ar, evs, one, seq)
-    assert any(c[1] == _lib.DT_U8 for c in ar.calls[1])   # the empty rank took the band exchange like the other one
+    assert any(c[1] == _lib.DT_U8 for c in ar.calls[1])   # the empty rank took the tile-set exchange like the other one
 
 
 def test_two_ranks_small_panorama_whole_plane_and_solver(hip):
