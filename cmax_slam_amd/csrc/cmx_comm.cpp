@@ -60,8 +60,8 @@ int comm_allreduce(cmx_ctx *c, void *buf, size_t count, int dt /* CMX_DT_* */, i
 // Panoramas (planes of 1 MB and more): a window's votes cover a few per cent of the map (BASELINE config 4: ~3 % of the tiles of
 // two 4 MB planes; config 5: ~1 % of two 32 MB planes), and every rank's slab of the window covers a part of that.  So the
 // tile-occupancy flags (a few KB) are all-reduced with max first, and what travels is the EXCHANGE SET: the tiles any rank
-// flagged in the PREVIOUS evaluation, dilated (xset_kernel) -- packed from both planes into one staging buffer, summed by ONE
-// collective, unpacked.  Its size is known on the host from the previous evaluation's result words, so nothing is waited for
+// flagged in the PREVIOUS evaluation, dilated (xset_kernel) -- packed from both planes into one staging buffer with the map behind
+// them (as floats: summed, > 0 = occupied), summed by ONE collective, unpacked.  Its size is known on the host from the previous evaluation's result words, so nothing is waited for
 // between splat and blur.  xset_kernel also lists the flagged tiles the set did NOT cover (the parameters moved the votes
 // further than the dilation); finish_sharded() then completes the evaluation with a second exchange of exactly those tiles.
 // The first evaluation of a window, and sets of more than half of the map, exchange the whole planes.
@@ -80,17 +80,17 @@ static int ensure_xset(cmx_ctx *c, size_t ntiles) {
   c->xset_n = -1;  // (whatever set was known lived in the old buffers)
   return CMX_OK;
 }
-// both planes' tiles of `list` -> staging -> all-reduce -> back
-static int exchange_tiles(cmx_ctx *c, const int *list, int n) {
-  if (n <= 0) return CMX_OK;
+// both planes' tiles of `list` (and, with `flags`, the occupancy map as floats behind them) -> staging -> ONE all-reduce -> back
+static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *flags, int ntiles) {
+  if (n <= 0 && !flags) return CMX_OK;
   const size_t np = (size_t)c->Wp * c->Hp;
-  const size_t need = (size_t)2 * n * kTileX * kTileY;
+  const size_t need = (size_t)2 * (n > 0 ? n : 0) * kTileX * kTileY + (flags ? (size_t)ntiles : 0);
   int rc = ensure(c, c->d_xstage, c->xstage_cap, need);
   if (rc) return rc;
-  launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n, c->d_xstage, c->stream);
+  launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, c->d_xstage, flags, ntiles, c->stream);
   rc = comm_allreduce(c, c->d_xstage, need, CMX_DT_F32);
   if (rc) return rc;
-  launch_xset_copy(true, c->d_accum, np, c->Wp, c->Hp, list, n, c->d_xstage, c->stream);
+  launch_xset_copy(true, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, c->d_xstage, flags, ntiles, c->stream);
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }
@@ -116,15 +116,18 @@ static int exchange_planes(cmx_ctx *c) {
   const int ntiles = tiles_x * tiles_y;
   int rc = ensure_xset(c, (size_t)ntiles);
   if (rc) return rc;
-  rc = comm_allreduce(c, c->d_tflags, (size_t)ntiles, CMX_DT_U8, CMX_OP_MAX);
-  if (rc) return rc;
   const int cur = c->xset_cur, n = c->xset_n;
   const bool use_set = n >= 0 && 2 * n <= ntiles;  // (rank-invariant: n derives from the all-reduced flags of the previous evaluation)
+  if (use_set) {  // the set does not depend on THIS evaluation's flags: map and tiles travel as one collective
+    rc = exchange_tiles(c, c->d_xlist[cur], n, c->d_tflags, ntiles);
+  } else {
+    rc = comm_allreduce(c, c->d_tflags, (size_t)ntiles, CMX_DT_U8, CMX_OP_MAX);
+    if (!rc) rc = comm_allreduce(c, c->d_accum, c->accum_count, CMX_DT_F32);
+  }
+  if (rc) return rc;
   launch_xset(c->d_tflags, tiles_x, tiles_y, use_set ? c->d_xmember[cur] : nullptr, c->d_xlist[cur ^ 1], c->d_xmember[cur ^ 1], c->d_xmiss,
               c->d_result + kXsetSlot, ++c->xset_seq, c->stream);
   HIP_TRY(c, hipGetLastError());
-  rc = use_set ? exchange_tiles(c, c->d_xlist[cur], n) : comm_allreduce(c, c->d_accum, c->accum_count, CMX_DT_F32);
-  if (rc) return rc;
   c->xset_pending = true;
   c->xset_used = use_set;
   return CMX_OK;
@@ -196,7 +199,7 @@ int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double
     // every rank read the same numbers (they derive from the all-reduced flags), so every rank is here: the listed tiles still
     // hold partial sums -- exchange exactly those and finish once more on the complete planes
     c->xset_misses++;
-    rc = exchange_tiles(c, c->d_xmiss, n_miss);
+    rc = exchange_tiles(c, c->d_xmiss, n_miss, nullptr, 0);
     if (rc) return rc;
     rc = finish_exchanged(c, kind, contrast, grad);
   }

@@ -860,10 +860,21 @@ void launch_xset(const unsigned char *flags, int tiles_x, int tiles_y, const uns
                      seq);
 }
 
-// the listed tiles of both planes <-> one contiguous staging buffer [plane][entry][kTileY][kTileX] (pixels beyond the image: zero)
+// the listed tiles of both planes <-> one contiguous staging buffer [plane][entry][kTileY][kTileX] (pixels beyond the image: zero);
+// with `flags`, the occupancy map rides behind them as floats (summed: > 0 = some rank voted there), so that the map and the
+// tiles are ONE collective -- blockIdx.y == 2 are the map's workgroups
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void xset_copy_kernel(float *planes, size_t np, int W, int H, int tiles_x, const int *list, int n,
-                                                        float *stage) {
+                                                        float *stage, unsigned char *flags, int ntiles) {
+  if (blockIdx.y == 2) {
+    float *sf = stage + (size_t)2 * n * (kTileX * kTileY);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+      if (UNPACK) flags[t] = sf[t] > 0.f ? 1 : 0;
+      else sf[t] = flags[t] ? 1.f : 0.f;
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= n) return;
   const int i = blockIdx.x, plane = blockIdx.y;
   const int tile = list[i];
   const int x0 = (tile % tiles_x) * kTileX, y0 = (tile / tiles_x) * kTileY;
@@ -880,11 +891,13 @@ __global__ __launch_bounds__(256) void xset_copy_kernel(float *planes, size_t np
     }
   }
 }
-void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const int *list, int n, float *stage, hipStream_t s) {
-  if (n <= 0) return;
+void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const int *list, int n, float *stage, unsigned char *flags,
+                      int ntiles, hipStream_t s) {
+  if (n <= 0 && !flags) return;
   const int tiles_x = (W + kTileX - 1) / kTileX;
-  if (unpack) hipLaunchKernelGGL(xset_copy_kernel<true>, dim3(n, 2), dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage);
-  else hipLaunchKernelGGL(xset_copy_kernel<false>, dim3(n, 2), dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage);
+  const dim3 grid(n > 0 ? n : 1, flags ? 3 : 2);
+  if (unpack) hipLaunchKernelGGL(xset_copy_kernel<true>, grid, dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage, flags, ntiles);
+  else hipLaunchKernelGGL(xset_copy_kernel<false>, grid, dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage, flags, ntiles);
 }
 
 size_t image_lds_bytes(int r) {

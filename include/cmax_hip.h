@@ -297,8 +297,8 @@ int cmx_set_grad_buffer(cmx_ctx *ctx, void *device_ptr, size_t n_doubles);
  * and take identical optimiser decisions.  Every rank must use the same options (cmx_set_option) and issue the same
  * sequence of calls; which collectives an evaluation issues then depends on rank-invariant state only (plane size,
  * options, call sequence) -- never on how many events a rank happens to hold (an empty shard takes part like any other).
- * Back-end planes of 1 MB and more are exchanged as a SET OF TILES (64 x 16 pixels): the tile-occupancy flags are all-reduced
- * (max); the tiles exchanged -- packed from both planes into one staging buffer, one collective -- are those any rank flagged in
+ * Back-end planes of 1 MB and more are exchanged as a SET OF TILES (64 x 16 pixels): the tiles exchanged -- packed from both
+ * planes into one staging buffer with the tile-occupancy map behind them, one collective -- are those any rank flagged in
  * the PREVIOUS evaluation, dilated by one tile in every direction (the whole planes on a window's first evaluation, or when
  * the set exceeds half of the map) -- no host synchronisation between splat and blur.  A kernel lists the flagged tiles the set
  * did not cover; if there are any (parameters jumped) the evaluation is completed by exchanging exactly those and finishing again.
