@@ -25,4 +25,4 @@ while time.time() - t0 < 45.0:
     if nbe % 20 == 0:
         fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
 cf, cb = np.array(costs_fe), np.array(costs_be)
-print("soak ok: %d front-end solves, %d back-end solves in %.0f s; fe final cost %.6f .. %.6f, be %.6f .. %.6f; stats fe %s" % (nfe, nbe, time.time() - t0, cf.min(), cf.max(), cb.min(), cb.max(), {k: v for k, v in fe.stats().items() if "gated" in k or "spec" in k}))
+print("soak ok: %d front-end solves, %d back-end solves in %.0f s; fe final cost %.6f .. %.6f, be %.6f .. %.6f; stats fe %s" % (nfe, nbe, time.time() - t0, cf.min(), cf.max(), cb.min(), cb.max(), {k: v for k, v in fe.stats().items() if "gated" in k or "spec" in k or "chain" in k}))
