@@ -468,6 +468,54 @@ def parity_vs_one_gpu(ctx, kind, obj, x_first, x, c_sharded, g_sharded, args):
             "tolerance": 1e-5, "events_total": int(len(xs))}
 
 
+def concurrent_contexts(device_index, p, pts, hbm_bytes_per_eval, counts=(4, 8), seconds=0.4):
+    """Several evaluator contexts on ONE GPU, each with its own host thread and stream, each evaluating its own copy of the
+    workload (fdf, every evaluation waited for): one context is bound by the latency of its three dependent launches, the GPU
+    by its throughput -- what a process serving several event streams (or the reference's front-end and back-end threads,
+    src/node.cpp:22) gets.  Not the headline: `value` stays the single-context rate."""
+    import threading
+    from cmax_slam_amd import _lib, evaluator
+    res = []
+    for T in counts:
+        evs = []
+        for _ in range(T):
+            ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=device_index)
+            ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+            ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+            for k in range(5):
+                ev.eval(pts[k % len(pts)], True)
+            evs.append(ev)
+        n_done = [0] * T
+        go = threading.Barrier(T + 1)
+        stop = [0.0]
+
+        def work(k):
+            ev, n = evs[k], 0
+            go.wait()
+            while time.perf_counter() < stop[0]:
+                ev.eval(pts[n % len(pts)], True)
+                n += 1
+            n_done[k] = n
+        th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+        for t in th:
+            t.start()
+        stop[0] = time.perf_counter() + seconds + 0.05
+        t0 = time.perf_counter()
+        go.wait()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        for ev in evs:
+            ev.close()
+        evals = sum(n_done)
+        res.append({"contexts": T, "evaluations": evals, "seconds": el, "value": evals * len(p.x) / el, "unit": "events/s",
+                    "ms_per_evaluation_per_context": el / max(min(n_done), 1) * 1e3,
+                    "whole_evaluation_frac": evals * hbm_bytes_per_eval / el / 1e9 / HBM_PEAK_GBS})
+    return {"runs": res,
+            "note": "aggregate of independent fdf evaluations on one GPU (own thread + stream per context, every evaluation waited "
+                    "for); whole_evaluation_frac = evaluations/s x HBM-mandatory bytes of one evaluation / 8 TB/s"}
+
+
 def cmax_solves(n_solves, ev, kind, _lib):
     """CMax iterations per second: full FR-CG solves (the reference's driver loop, host C++) from the reference's own
     start (front end: omega = 0; back end: zero increments on the perturbed knots), image reuse on as in production."""
@@ -775,6 +823,11 @@ def main():
                                          "store60k": per_packet_pipeline(local_rank, "store60k", 16)}
                 except Exception as e:  # must not cost the headline line
                     out["per_packet"] = {"error": repr(e)}
+            if world == 1 and not args.no_per_packet:
+                try:
+                    out["concurrent_contexts"] = concurrent_contexts(local_rank, p, pts, out["whole_evaluation"]["hbm_mandatory_bytes"])
+                except Exception as e:
+                    out["concurrent_contexts"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline("frontend", p, pts[len(pts) // 2], args.cpu_seconds)
         ev.close()
