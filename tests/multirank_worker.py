@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_multirank.py: one process per GPU (torch.distributed.run), native RCCL communicator inside the
-evaluator.  Every rank evaluates its batch-range shard of one back-end window (a large panorama, so the row-band exchange
+evaluator.  Every rank evaluates its batch-range shard of one back-end window (a large panorama, so the tile-set exchange
 runs, and a small one) and of one front-end packet; rank 0 also evaluates the whole problem on its own GPU and compares.
 Prints MULTIRANK_OK on success; any failure raises (non-zero exit)."""
 import os

@@ -179,8 +179,8 @@ def test_native_rccl_communicator_world1(hip, oracle):
 
 
 def test_touched_rows_exchange_on_a_large_panorama_world1(hip):
-    """Planes of 8 MB and more are exchanged as the band of tile rows any rank voted into (flags all-reduced with max
-    first).  With one rank the collectives are identities, so every result must equal the run without a communicator --
+    """Planes of 1 MB and more are exchanged as the set of tiles any rank voted into in the previous evaluation (with the
+    occupancy map behind them).  With one rank the collectives are identities, so every result must equal the run without a communicator --
     across a sequence of evaluations that moves the votes, alternates cost-only and gradient calls (ping-pong buffers,
     image reuse) and includes a non-zero global map."""
     w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 2048, 1024, 2, 5, 1, 0.2, seed=45)
