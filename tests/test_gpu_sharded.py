@@ -178,15 +178,17 @@ def test_native_rccl_communicator_world1(hip, oracle):
     assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
 
 
-def test_touched_rows_exchange_on_a_large_panorama_world1(hip):
+@pytest.mark.parametrize("Wp,Hp", [(2048, 1024), (1100, 565)])
+def test_tile_set_exchange_on_a_panorama_world1(hip, Wp, Hp):
     """Planes of 1 MB and more are exchanged as the set of tiles any rank voted into in the previous evaluation (with the
-    occupancy map behind them).  With one rank the collectives are identities, so every result must equal the run without a communicator --
-    across a sequence of evaluations that moves the votes, alternates cost-only and gradient calls (ping-pong buffers,
-    image reuse) and includes a non-zero global map."""
-    w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 2048, 1024, 2, 5, 1, 0.2, seed=45)
+    occupancy map behind them).  With one rank the collectives are identities, so every result must equal the run without a
+    communicator -- across a sequence of evaluations that moves the votes (also out of the set: repaired), alternates cost-only
+    and gradient calls (ping-pong buffers, image reuse) and includes a non-zero global map.  1100 x 565: partial tiles at the
+    right and bottom edges, a tile count that is no multiple of 16."""
+    w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, Wp, Hp, 2, 5, 1, 0.2, seed=45)
     IG = np.zeros((w.Hp, w.Wp), np.float32)
-    IG[300:340, 900:1100] = 1.5      # map content in rows the events of this window do not reach
-    IG[500:520, 1000:1040] = 0.7
+    IG[300 * Hp // 1024:340 * Hp // 1024, 900 * Wp // 2048:1100 * Wp // 2048] = 1.5   # map content where this window's events do not reach
+    IG[500 * Hp // 1024:520 * Hp // 1024, 1000 * Wp // 2048:1040 * Wp // 2048] = 0.7
     plain = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     shard = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     for ev in (plain, shard):
@@ -205,6 +207,8 @@ def test_touched_rows_exchange_on_a_large_panorama_world1(hip):
             assert rel_vec(g1, g0) < 1e-6, i
         assert rel_img(shard.get_plane(_lib_plane("IL_OLD")), plain.get_plane(_lib_plane("IL_OLD"))) < 1e-6
     assert rel_scalar(shard.alpha, plain.alpha) < 1e-7 and plain.alpha > 0
+    st = shard.stats()
+    assert st["exchange_tiles"] > 0 and st["exchange_misses"] >= 1 and st["sharded_host_syncs"] == 0, st
     x0, r0 = plain.setupProblemAndOptimize()
     x1, r1 = shard.setupProblemAndOptimize()
     assert abs(r1["final_cost"] - r0["final_cost"]) < 1e-3 * abs(r0["final_cost"])
