@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcmaxhip.so")
+SO_PATH = os.environ.get("CMAX_HIP_SO") or os.path.join(_HERE, "libcmaxhip.so")  # (the override: A/B runs of two builds on one GPU box, tools/ab_builds.sh)
 
 OK, ERR_INVALID_ARG, ERR_EVENT_RANGE, ERR_HIP, ERR_SPLINE_RANGE, ERR_STATE, ERR_TIME_ORDER = range(7)
 VARIANCE, MEAN_SQUARE, GRADIENT_MAGNITUDE = 0, 1, 2

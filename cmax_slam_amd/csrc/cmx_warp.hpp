@@ -5,6 +5,7 @@
 // fp64 geometry exactly as the reference (compile with -ffp-contract=off), fp32 bilinear offsets.
 #pragma once
 #include "cmx_internal.hpp"
+#include "cmx_trig.hpp"
 
 namespace cmx {
 
@@ -110,9 +111,15 @@ __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e,
   const double y = R[3] * b0 + R[4] * b1 + R[5] * b2;
   const double z = R[6] * b0 + R[7] * b1 + R[8] * b2;
   // equirectangular projection
-  const double phi = atan2(x, z);
-  const double rho = sqrt(x * x + y * y + z * z);
-  const double theta = asin(y / rho);
+  const double phi = lean_atan2(x, z);  // (cmx_trig.hpp: the two transcendental calls were three quarters of this function)
+  // rho = |R b|: the reference's sqrt and division (y / rho) as ONE reciprocal square root -- v_rsq_f64 and two Newton steps
+  // (~14 instructions against ~45; y * (1/rho) is within 2 ulp of y / rho, i.e. 1e-16 of the pixel coordinate)
+  const double rho2 = x * x + y * y + z * z;
+  double inv_rho = __builtin_amdgcn_rsq(rho2);
+  inv_rho = inv_rho * (1.5 - 0.5 * rho2 * inv_rho * inv_rho);
+  inv_rho = inv_rho * (1.5 - 0.5 * rho2 * inv_rho * inv_rho);
+  const double rho = rho2 * inv_rho;
+  const double theta = lean_asin(y * inv_rho);
   const double pxm = a.cxp + phi * a.fx;
   const double pym = a.cyp + theta * a.fy;
   w.xx = (int)pxm;
