@@ -1,7 +1,7 @@
 // cmx_trig.hpp -- fp64 atan2 / asin for the back end's equirectangular projection (device only).
 //
-// The back end's per-event kernels are bound by fp64 VALU issue, and ocml's atan2 + asin were 138 of the splat's ~180 VALU
-// instructions per event (62 + 76: asin carries a double-double correction for < 1 ulp).  The pixel coordinate needs nothing like
+// ocml's atan2 + asin were 138 of the back-end splat's ~180 VALU instructions per event, and as many of the gather's ~320
+// (62 + 76: asin carries a double-double correction for < 1 ulp).  The pixel coordinate needs nothing like
 // that: these are plain polynomial forms, 1-3 ulp (4e-13 of a pixel at 4096 x 2048), ~85 instructions for the pair:
 //   atan(a) = a + a r Qa(r),  r = a^2 in [0, 1],  a = min(|y|,|x|) / max(|y|,|x|) (reciprocal + Newton + one residual step)
 //   asin(s) = s + s r Qs(r),  r = s^2 in [0, 1/4]; |t| > 1/2: asin(t) = pi/2 - 2 asin(sqrt((1 - |t|) / 2)), the square root by
