@@ -41,7 +41,7 @@ __device__ __forceinline__ double lean_atan2(double y, double x) {
   const double inv = trig_rcp(hi);
   double a = lo * inv;
   a = __builtin_fma(__builtin_fma(-hi, a, lo), inv, a);  // residual step: a = lo / hi to the last place
-  a = hi > 0.0 ? a : 0.0;
+  if (hi < 1e-290) a = hi > 0.0 ? lo / hi : 0.0;  // (a ray along the pole: the reciprocal of a subnormal overflows; never in practice)
   const double r = a * a;
   double p = kAtanQ[20];
 #pragma unroll

@@ -69,6 +69,8 @@ def test_atan2_all_octants_within_a_few_ulp():
     u = _ulps(got, ref)
     assert u.max() < 4.0, (u.max(), y[np.argmax(u)], x[np.argmax(u)])
     assert lean_atan2(np.array([0.0]), np.array([0.0]))[0] == 0.0
+    tiny = lean_atan2(np.array([3e-310, 0.0, 1e-320]), np.array([4e-310, 5e-315, 0.0]))      # subnormal rays (the pole)
+    assert np.allclose(tiny, np.arctan2([3e-310, 0.0, 1e-320], [4e-310, 5e-315, 0.0]), rtol=0, atol=1e-15)
     assert np.abs(got - np.arctan2(y, x)).max() < 1e-15
 
 
