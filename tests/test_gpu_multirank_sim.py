@@ -157,6 +157,28 @@ def test_two_ranks_config4_sized_window_exchanges_a_set_of_tiles(hip):
     assert 1 <= evs[0].stats()["exchange_misses"] <= 2 and evs[0].stats()["sharded_host_syncs"] == 0, evs[0].stats()
 
 
+def test_two_ranks_votes_across_the_panorama_seam(hip):
+    """The camera looks backwards: the votes sit at both ends of the panorama's rows (longitude +-180 degrees).  The exchange
+    set dilates across the seam (tile column 0 is the neighbour of the last one), and a yaw that carries the votes over it is
+    followed without a miss; results equal the one-context evaluation throughout."""
+    w = synth.backend_window(150_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 2048, 1024, 4, 10, 0, 0.3, seed=61)
+    ranges = [dist.batch_range(len(w.x), w.batch, r, 2) for r in range(2)]
+    ar, evs, one = _backend_pair(hip, w, None, ranges)
+    rng = np.random.default_rng(6)
+
+    def yaw(deg):
+        return np.tile([0.0, np.deg2rad(deg), 0.0], w.P // 3)
+    seq = [(yaw(176.0), True)]
+    for k, deg in enumerate([176.5, 177.5, 178.5, 179.5, 180.5, 181.5, 182.5, 183.5]):   # 1 degree = 5.7 pixels per step
+        seq.append((yaw(deg) + rng.normal(0, 0.002, w.P), k % 2 == 0))
+    _check_sequence(ar, evs, one, seq)
+    s = evs[0].stats()
+    assert s["exchange_misses"] == 0 and s["exchange_tiles"] > 0 and s["sharded_host_syncs"] == 0, s
+    # both ends of the rows are occupied: the planes of one rank carry votes in the first and in the last tile column
+    il = evs[0].get_plane(_lib.PLANE_IL_NEW) + evs[0].get_plane(_lib.PLANE_IL_OLD)
+    assert il[:, :64].sum() > 0 and il[:, -64:].sum() > 0
+
+
 def test_two_ranks_with_an_empty_shard_issue_the_same_collectives(hip):
     w = synth.backend_window(20_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 4096, 2048, 4, 6, 1, 0.15, seed=48)
     ranges = [(0, len(w.x)), (len(w.x), len(w.x))]     # rank 1 holds nothing (dist.batch_range does this when nb < world*per)
