@@ -20,11 +20,18 @@ def _fe(hip, p, chain, sigma=None, measure=_lib.VARIANCE):
 
 
 def _close(a, b):
+    """Two solves of the same problem by two drivers.  Their evaluations differ in the last bits (order of the fp32 atomics), and
+    FR-CG's line search and stopping rules amplify that: over 2000 random starts two HOST-driven runs of one packet end more than
+    0.2 % apart in 4-5 % of the cases, up to a third in the worst (profiles/r03_chain_vs_host_random.txt), and one of the packets
+    below has two end points 1.4 % apart that either driver reaches (40 repetitions of this file: 5 landed on different ones).  So
+    "the same result" is: the same start, both descended, end points within 5 % in cost and 0.2 rad/s in omega.  What pins the
+    device's machine to the host's is elsewhere: every solve here must finish WITHOUT a hand-over, i.e. the host's replay of the
+    machine on the reported costs / gradients agreed bit for bit with every point the device chose."""
     (xa, ra), (xb, rb) = a, b
-    assert abs(ra["final_cost"] - rb["final_cost"]) < 2e-3 * abs(rb["final_cost"]), (ra, rb)
-    assert np.abs(xa - xb).max() < 0.05, (xa, xb)
+    assert abs(ra["final_cost"] - rb["final_cost"]) < 5e-2 * abs(rb["final_cost"]), (ra, rb)
+    assert np.abs(xa - xb).max() < 0.2, (xa, xb)
     assert ra["initial_cost"] == pytest.approx(rb["initial_cost"], rel=1e-6)
-    assert ra["final_cost"] <= ra["initial_cost"]
+    assert ra["final_cost"] <= ra["initial_cost"] and rb["final_cost"] <= rb["initial_cost"]
 
 
 @pytest.mark.parametrize("n_events,W,H,mode", [(100_000, 240, 180, 1), (400_000, 640, 480, 1), (100_000, 240, 180, 4)])
@@ -38,7 +45,7 @@ def test_chain_solve_reaches_what_the_host_driven_solve_reaches(hip, oracle, n_e
     st = fe.stats()
     assert st["chain_solves"] == 1 and st["chain_takeovers"] == 0 and st["chain_slots"] >= dev[1]["n_f"] + 1
     _close(dev, host)
-    assert abs(dev[1]["n_f"] - host[1]["n_f"]) <= 12 and dev[1]["iterations"] >= 2
+    assert dev[1]["iterations"] >= 2 and host[1]["iterations"] >= 2
     # ... and what the same driver reaches over the CPU oracle
     ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
     ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
@@ -53,7 +60,7 @@ def test_chain_solve_reaches_what_the_host_driven_solve_reaches(hip, oracle, n_e
     c_ref, g_ref = ref.eval(dev[0])
     assert abs(c - c_ref) < 1e-5 * abs(c_ref) and np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()
     again = fe.setupProblemAndOptimize(dev[0])
-    assert again[1]["final_cost"] <= dev[1]["final_cost"] * (1 - 1e-3) or again[1]["iterations"] <= 3
+    assert again[1]["final_cost"] <= dev[1]["final_cost"] + 1e-6 * abs(dev[1]["final_cost"])   # (costs are -contrast: a warm restart does not climb)
     assert fe.stats()["chain_solves"] == 2
 
 
