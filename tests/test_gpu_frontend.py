@@ -169,3 +169,16 @@ def test_unknown_measure_means_variance(hip, oracle, small):
     c_ref, g_ref = ref.eval((0.3, -0.5, 0.2))
     c, g = fe7.eval((0.3, -0.5, 0.2))
     assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
+
+
+@pytest.mark.parametrize("n", [257, 65_537, 131_000, 300_001, 524_287, 524_289])
+def test_gather_slice_sizes_of_the_production_path(hip, oracle, n):
+    """The gradient gather cuts the packet into slices of n / 512 events (a multiple of 256, between 256 and 1024) below 512k events
+    and of 1024 above: packets on both sides of every change of that rule, with odd event counts."""
+    p = synth.frontend_packet(n, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=100 + n % 97)
+    fe, ref = _pair(hip, oracle, p)
+    fe.set_fast_path()
+    for omega in [(0.0, 0.0, 0.0), (0.5, -0.8, 0.3)]:
+        c, g = fe.eval(omega)
+        c_ref, g_ref = ref.eval(omega)
+        assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL, (n, omega)
