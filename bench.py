@@ -486,7 +486,7 @@ def concurrent_contexts(device_index, p, pts, hbm_bytes_per_eval, counts=(4, 8),
                 ev.eval(pts[k % len(pts)], True)
             evs.append(ev)
         n_done = [0] * T
-        go = threading.Barrier(T + 1)
+        go = threading.Barrier(T + 1, timeout=60)  # (a worker that died before the start must not hang the bench)
         stop = [0.0]
 
         def work(k):
