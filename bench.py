@@ -887,14 +887,23 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         out.pop("_last", None)
-        try:  # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the LAST line
+        try:  # whatever native libraries still hold in their C stdio buffers goes where stdout currently points: stderr
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         sys.stdout.flush()
+        if _STDOUT_FD is not None:
+            os.dup2(_STDOUT_FD, 1)  # the real stdout back: it carries the ONE JSON line and nothing else
         print(json.dumps(out), flush=True)
 
 
+_STDOUT_FD = None
+
 if __name__ == "__main__":
+    # RCCL prints its version banner (six lines) to stdout through C stdio when the first communicator comes up: everything any
+    # library prints while the bench runs is sent to stderr, and stdout is handed back for the one JSON line
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
     main()
