@@ -202,6 +202,9 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
                            int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
                            int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
                            double blur_sigma, int contrast_measure, const float *IG) {
+  if (is_group(c))
+    return group_set_window(c, n, x, y, t_ns, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
+                            event_sample_rate, blur_sigma, contrast_measure, IG);
   return be_set_window_impl(c, n, x, y, t_ns, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed,
                             t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
 }
@@ -231,7 +234,12 @@ int be_ensure_time_bearings(cmx_ctx *c) {
 // The back end's counterpart of cmx_frontend_prepare: pose table at `drotv_hint` (NULL = zero increments), destination-tile
 // sort, chunk table and the bearing streams of a window, queued behind its upload.  A host that owns two contexts prepares
 // window k+1 while window k is being solved (pose_graph_optimizer.cpp:244-376 is the loop this sits in).
+static int be_prepare_one(cmx_ctx *c, const double *drotv_hint);
 int cmx_backend_prepare(cmx_ctx *c, const double *drotv_hint) {
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return be_prepare_one(m, drotv_hint); });
+  return be_prepare_one(c, drotv_hint);
+}
+static int be_prepare_one(cmx_ctx *c, const double *drotv_hint) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
   int rc = bind_device(c);
@@ -326,7 +334,12 @@ static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
   return CMX_OK;
 }
 
+static int be_accumulate_checked(cmx_ctx *c, const double *drotv, int want_grad);
 int cmx_backend_accumulate(cmx_ctx *c, const double *drotv, int want_grad) {
+  CMX_NOT_FOR_GROUPS(c, "the split-phase interface");
+  return be_accumulate_checked(c, drotv, want_grad);
+}
+static int be_accumulate_checked(cmx_ctx *c, const double *drotv, int want_grad) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
   if (!drotv && c->K > c->num_fixed) return fail(c, CMX_ERR_INVALID_ARG, "null drotv");
@@ -368,7 +381,12 @@ int be_first_iter(cmx_ctx *c) {
   return CMX_OK;
 }
 
+static int be_finish_one(cmx_ctx *c, double *contrast, double *grad);
 int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
+  CMX_NOT_FOR_GROUPS(c, "the split-phase interface");
+  return be_finish_one(c, contrast, grad);
+}
+static int be_finish_one(cmx_ctx *c, double *contrast, double *grad) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   if (!c->accumulated) return fail(c, CMX_ERR_STATE, "finish without accumulate");
   if (!contrast) return fail(c, CMX_ERR_INVALID_ARG, "null contrast");
@@ -404,21 +422,30 @@ int cmx_backend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
+  if (is_group(c)) return group_eval(c, drotv, contrast, grad);  // one call, N devices, one contrast / gradient
+  return be_eval_one(c, drotv, contrast, grad);
+}
+int be_eval_one(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
   const bool sharded = c && c->sharded();
   if (c && c->kind == KIND_BE && drotv && can_reuse(c, drotv, 3 * (c->K - c->num_fixed), grad != nullptr)) {
     c->last_adjoint = true;
     c->reuse_hits++;
     if (sharded) return finish_sharded(c, KIND_BE, false, contrast, grad);
-    return cmx_backend_finish(c, contrast, grad);
+    return be_finish_one(c, contrast, grad);
   }
-  int rc = cmx_backend_accumulate(c, drotv, grad != nullptr);
+  int rc = be_accumulate_checked(c, drotv, grad != nullptr);
   if (rc) return rc;
   if (sharded) return finish_sharded(c, KIND_BE, true, contrast, grad);
-  return cmx_backend_finish(c, contrast, grad);
+  return be_finish_one(c, contrast, grad);
 }
 
 // ---- global-map upkeep on the device: IG and the visit counts stay resident
+static int be_update_map_one(cmx_ctx *c, int max_update_times);
 int cmx_backend_update_map(cmx_ctx *c, int max_update_times) {
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return be_update_map_one(m, max_update_times); });  // every member keeps its own replica of the map
+  return be_update_map_one(c, max_update_times);
+}
+static int be_update_map_one(cmx_ctx *c, int max_update_times) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   if (!c->accumulated) return fail(c, CMX_ERR_STATE, "no evaluation has run in this window (IL_old undefined)");
   int rc = bind_device(c);
@@ -428,7 +455,12 @@ int cmx_backend_update_map(cmx_ctx *c, int max_update_times) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMX_OK;
 }
+static int be_mark_visited_one(cmx_ctx *c, const double q[4], int radius);
 int cmx_backend_mark_visited(cmx_ctx *c, const double q[4], int radius) {
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return be_mark_visited_one(m, q, radius); });  // every member keeps its own replica of the map
+  return be_mark_visited_one(c, q, radius);
+}
+static int be_mark_visited_one(cmx_ctx *c, const double q[4], int radius) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   if (!q || radius < 0 || radius > 64) return fail(c, CMX_ERR_INVALID_ARG, "bad pose / radius");
   int rc = bind_device(c);
@@ -439,7 +471,12 @@ int cmx_backend_mark_visited(cmx_ctx *c, const double q[4], int radius) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return CMX_OK;
 }
+static int be_reset_map_one(cmx_ctx *c);
 int cmx_backend_reset_map(cmx_ctx *c) {
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return be_reset_map_one(m); });  // every member keeps its own replica of the map
+  return be_reset_map_one(c);
+}
+static int be_reset_map_one(cmx_ctx *c) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   int rc = bind_device(c);
   if (rc) return rc;
@@ -460,7 +497,12 @@ int cmx_backend_get_map(cmx_ctx *c, float *IG, unsigned char *visits) {
   if (visits) HIP_TRY(c, hipMemcpy(visits, c->d_visits, np, hipMemcpyDeviceToHost));
   return CMX_OK;
 }
+static int be_set_map_one(cmx_ctx *c, const float *IG, const unsigned char *visits);
 int cmx_backend_set_map(cmx_ctx *c, const float *IG, const unsigned char *visits) {
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return be_set_map_one(m, IG, visits); });  // every member keeps its own replica of the map
+  return be_set_map_one(c, IG, visits);
+}
+static int be_set_map_one(cmx_ctx *c, const float *IG, const unsigned char *visits) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   int rc = bind_device(c);
   if (rc) return rc;
@@ -495,6 +537,38 @@ int cmx_backend_get_plane(cmx_ctx *c, int which, float *host) {
   }
   HIP_TRY(c, hipMemcpyAsync(host, src, np * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return sync_and_collect(c);
+}
+
+int cmx_backend_get_pose_table(cmx_ctx *c, int max_batches, double *R, float *Jcp, int *idx, int64_t *t_batch_ns, int *n_batches) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
+  if (max_batches < 0) return fail(c, CMX_ERR_INVALID_ARG, "bad row count");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (n_batches) *n_batches = c->nb;
+  const int n = c->nb < max_batches ? c->nb : max_batches;
+  if (n <= 0) return CMX_OK;
+  if (!c->accumulated) {  // no evaluation yet in this window: the table at zero increments
+    std::vector<double> zero((size_t)3 * (c->K - c->num_fixed > 0 ? c->K - c->num_fixed : 1), 0.0);
+    be_update_knots(c, zero.data());
+  }
+  // the same launch an evaluation issues (h_spline holds the knots of the last one), Jacobians included
+  launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, true, c->d_poseR, c->d_poses, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<PoseR> hr((size_t)n);
+  std::vector<PoseEntry> he((size_t)n);
+  std::vector<long long> ht((size_t)n);
+  HIP_TRY(c, hipMemcpyAsync(hr.data(), c->d_poseR, (size_t)n * sizeof(PoseR), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(he.data(), c->d_poses, (size_t)n * sizeof(PoseEntry), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(ht.data(), c->d_batch_t, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int b = 0; b < n; b++) {
+    if (R) memcpy(R + (size_t)9 * b, hr[(size_t)b].R, 9 * sizeof(double));
+    if (Jcp) memcpy(Jcp + (size_t)36 * b, he[(size_t)b].Jcp, 36 * sizeof(float));
+    if (idx) idx[b] = he[(size_t)b].idx_cp_beg;
+    if (t_batch_ns) t_batch_ns[b] = (int64_t)ht[(size_t)b];
+  }
+  return CMX_OK;
 }
 
 int cmx_backend_get_alpha(cmx_ctx *c, double *alpha) {

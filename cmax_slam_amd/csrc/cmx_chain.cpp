@@ -139,6 +139,8 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   f.chain.done = &c->d_chain->done;
   f.chain.abort_flag = &c->d_chain->abort_flag;
   f.chain.stage = 2;
+  f.chain.gate_cur = &c->d_chain->gate[par];
+  f.chain.gate_next = &c->d_chain->gate[par ^ 1u];
   f.chain.sm_src = first ? &c->d_chain_init[c->chain_init_sel].sm : nullptr;
   f.ticket = ++c->ticket_issued;
   g.tail.counters = c->d_tail_counters;
@@ -191,6 +193,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     sm_to_fixed<kChainMaxN>(hs, st->sm);
     for (int k = 0; k < 3; k++) st->x_req[k] = c->chain_x0[k] = hs.x[k];
     st->done = 0;
+    for (int q = 0; q < 2; q++) { st->gate[q].thr = hs.gate_thr; st->gate[q].mode = hs.gate_mode; }  // (a cold start's first slot has parity 0)
     if (!warm) {
       HIP_TRY(c, hipMemcpyAsync(c->d_chain, st, sizeof(ChainDev), hipMemcpyHostToDevice, c->stream));
       c->chain_seq = 0;

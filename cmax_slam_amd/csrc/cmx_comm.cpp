@@ -191,7 +191,13 @@ int finish_sharded(cmx_ctx *c, int kind, bool exchange, double *contrast, double
     }
     if (!words_ok) HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  if (!words_ok) return fail(c, CMX_ERR_HIP, "the exchange-set kernel's result did not arrive (sequence %llu)", c->xset_seq);
+  if (!words_ok) {
+    // This rank cannot know which exchange its peers chose next: the communicator is UNUSABLE after this error (the peers
+    // would hang in their next collective) -- the caller must tear the job down.  The set is dropped so that a retry on a fresh
+    // communicator starts from whole planes like every other rank.
+    comm_reset_xset(c);
+    return fail(c, CMX_ERR_HIP, "the exchange-set kernel's result did not arrive (sequence %llu): communicator unusable", c->xset_seq);
+  }
   const int n_next = (int)xw[0], n_miss = (int)xw[1];
   c->xset_cur ^= 1;  // what xset_kernel wrote is the next evaluation's set
   c->xset_n = n_next;
@@ -218,6 +224,7 @@ int cmx_comm_unique_id(char id[CMX_COMM_ID_BYTES]) {
   return CMX_OK;
 }
 int cmx_comm_attach(cmx_ctx *c, const char id[CMX_COMM_ID_BYTES], int rank, int nranks) {
+  CMX_NOT_FOR_GROUPS(c, "attaching a communicator");
   if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, CMX_ERR_INVALID_ARG, "bad communicator arguments");
   if (!rccl().ok) return fail(c, CMX_ERR_HIP, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
   int rc = bind_device(c);
@@ -235,6 +242,7 @@ int cmx_comm_attach(cmx_ctx *c, const char id[CMX_COMM_ID_BYTES], int rank, int 
 }
 int cmx_comm_detach(cmx_ctx *c) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  CMX_NOT_FOR_GROUPS(c, "detaching the communicator");
   int rc = bind_device(c);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -280,6 +280,10 @@ const char *cmx_status_string(int s) {
 
 void cmx_destroy(cmx_ctx *c) {
   if (!c) return;
+  if (c->group) {  // a group's handle: workers, transport and every member (which come back here with group == nullptr)
+    if (c->group_rank == 0) group_destroy(c);
+    return;
+  }
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -342,8 +346,13 @@ void cmx_destroy(cmx_ctx *c) {
   delete c;
 }
 
+static int set_option_one(cmx_ctx *c, int key, int value);
 int cmx_set_option(cmx_ctx *c, int key, int value) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return set_option_one(m, key, value); });  // members must agree
+  return set_option_one(c, key, value);
+}
+static int set_option_one(cmx_ctx *c, int key, int value) {
   switch (key) {
     case CMX_OPT_GRAD_MODE:
       if (value != CMX_GRAD_PLANES && value != CMX_GRAD_ADJOINT) return fail(c, CMX_ERR_INVALID_ARG, "bad grad mode %d", value);
@@ -399,6 +408,7 @@ int cmx_hint_next_df(cmx_ctx *c, double threshold, int mode) {
 
 int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  CMX_NOT_FOR_GROUPS(c, "a caller-owned stream");
   int rc = bind_device(c);
   if (rc) return rc;
   if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -411,6 +421,38 @@ int cmx_set_stream(cmx_ctx *c, void *hip_stream) {
     c->own_stream = true;
   }
   return CMX_OK;
+}
+
+// ---- the context's own stream with a scheduling priority or a compute-unit mask: a front-end context beside a back-end
+// window solve on one GPU (the reference's two threads, src/node.cpp:22 + src/cmax_slam.cpp:92)
+static int replace_own_stream(cmx_ctx *c, int priority_level, const uint32_t *mask, int n_words) {
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (c->stream && !c->own_stream) return fail(c, CMX_ERR_STATE, "the context runs on a caller-owned stream (cmx_set_stream)");
+  if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipStream_t s = nullptr;
+  if (mask && n_words > 0) {
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+  } else {
+    int least = 0, greatest = 0;  // numerically: greatest priority <= least priority (HIP: lower number = served first)
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = priority_level > 0 ? greatest : (priority_level < 0 ? least : (least + greatest) / 2);
+    HIP_TRY(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  }
+  if (c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
+  c->stream = s;
+  c->own_stream = true;
+  return CMX_OK;
+}
+int cmx_set_stream_priority(cmx_ctx *c, int level) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return replace_own_stream(m, level, nullptr, 0); });
+  return replace_own_stream(c, level, nullptr, 0);
+}
+int cmx_set_cu_mask(cmx_ctx *c, const uint32_t *mask, int n_words) {
+  if (!c || n_words < 0 || (n_words > 0 && !mask)) return CMX_ERR_INVALID_ARG;
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { return replace_own_stream(m, 0, mask, n_words); });
+  return replace_own_stream(c, 0, mask, n_words);
 }
 
 int cmx_abi_version(void) { return CMX_ABI_VERSION; }
@@ -478,6 +520,7 @@ size_t cmx_accum_capacity(const cmx_ctx *c) {
 }
 int cmx_set_accum_buffer(cmx_ctx *c, void *device_ptr, size_t n_floats) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  CMX_NOT_FOR_GROUPS(c, "a caller-owned accumulation buffer");
   int rc = bind_device(c);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -35,8 +36,12 @@ constexpr double kRebinFallbackFrac = 0.03;
 struct TimedSpan { int cls; hipEvent_t a, b; };
 typedef struct ncclComm *ncclComm_t;  // as <rccl/rccl.h> declares it; only cmx_comm.cpp includes that header
 
+struct cmx_group;  // cmx_group.cpp: one-process multi-GPU group (members, worker threads, transport)
+
 struct cmx_ctx {
   int kind = 0, device = 0;
+  cmx_group *group = nullptr;  // set on every member of a group; the member with group_rank 0 is the handle the caller holds
+  int group_rank = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -364,6 +369,19 @@ int finish_begin(cmx_ctx *c, int kind, int want_grad);
 int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
 int be_ensure_time_bearings(cmx_ctx *c);  // cmx_backend.cpp: the gather's time-ordered bearing stream (once per window)
 int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the first evaluation of a window
+
+// ---- cmx_group.cpp: the entry points of the C ABI hand a group's handle to these
+bool is_group(const cmx_ctx *c);
+int group_size(const cmx_ctx *c);
+int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn);  // fn(member, rank) on every member; first failure
+void group_destroy(cmx_ctx *leader);
+int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
+                     const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                     int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
+int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *grad);
+int be_eval_one(cmx_ctx *c, const double *drotv, double *contrast, double *grad);  // cmx_backend.cpp: one context's evaluation
+#define CMX_NOT_FOR_GROUPS(c, what) \
+  do { if ((c) && (c)->group) return fail((c), CMX_ERR_STATE, what " is not available on a group (the group runs its own exchange)"); } while (0)
 
 // ---- cmx_comm.cpp
 int finish_sharded(cmx_ctx *c, int kind, bool exchange_planes, double *contrast, double *grad);

@@ -105,6 +105,7 @@ int cmx_backend_set_window_from(cmx_ctx *c, const cmx_events *e, int64_t first, 
                                 const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed,
                                 int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate, double blur_sigma,
                                 int contrast_measure, const float *IG) {
+  CMX_NOT_FOR_GROUPS(c, "a window cut from a device event store (the store lives on one device)");
   size_t off = 0;
   int rc = store_range(c, e, first, count, &off);
   if (rc) return rc;

@@ -18,7 +18,7 @@
 #include <math.h>
 #include <stddef.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CMX_SM_HD __host__ __device__
 #else
 #define CMX_SM_HD
@@ -192,6 +192,11 @@ CMX_SM_HD inline void sm_min_begin(SM &s) {
   s.old1 = fabs(s.v - s.u);
   s.m_iter = 0;
   sm_copy(s.x2, s.x1, s.n);
+  // DELIBERATE DEVIATION in a value nothing reads: in GSL the callee's `dx2` parameter IS the state's `dx` (iterate() passes it
+  // for both), so GSL's memcpy(dx2, dx1) leaves dx = dx1 when no step of minimize() is accepted; here dx2 is its own field and
+  // dx keeps the trial step's value.  m_fa / m_fc are likewise not refreshed on rejected steps.  The reference's stopping rules
+  // (local_optim_contrast_gsl.cpp:134-215) read the gradient and f only, never dx: a host that wants GSL's dx after an
+  // unsuccessful line search must not take it from this machine.
   sm_copy(s.dx2, s.dx, s.n);
   s.f = s.m_fb;
   s.step = s.m_stepb;

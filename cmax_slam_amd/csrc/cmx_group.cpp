@@ -1,0 +1,420 @@
+// cmx_group.cpp -- one-process multi-GPU: a GROUP of back-end contexts behind ONE handle, ONE host thread, ONE optimiser.
+//
+// The reference's host is one process with one back-end thread and one GSL instance
+// (src/cmax_slam.cpp:92, src/backend/global_optim_contrast_gsl.cpp:23-33): it cannot be launched once per GPU.  A group is the
+// form that drops into it: cmx_backend_create_group() returns an ordinary cmx_ctx handle; the unchanged global_contrast_fdf
+// body calls cmx_backend_eval(handle, ...) and the evaluation fans out to the N member contexts -- member r holds the
+// contiguous range of whole event batches dist.batch_range gives rank r (event_pano_warper.cpp:188-196 is the loop being
+// sharded), the members exchange their partial planes after the splat and their gradient rows after the gather exactly as
+// the one-process-per-GPU form does (cmx_comm.cpp: same collectives, same exchange set), and ONE contrast / gradient comes
+// back.  No replicated optimisers, no launcher.
+//
+// How the fan-out runs.  Queueing one member's evaluation is ~10 launches + 2 collectives of host work (~40-60 us with RCCL's
+// enqueue path); eight members queued by one thread would take longer than the ~150 us the evaluation runs for.  So every
+// member but the first has a WORKER thread owned by the group, parked on the group's command word; the calling thread
+// publishes the command, runs member 0 itself, and collects.  Between the calls of a solve the workers spin (hand-over
+// ~0.2 us); after kSpinIdleUs without a command they sleep on a condition variable.  The caller sees a synchronous,
+// single-threaded API.
+//
+// Transports (what an all-reduce between the members is):
+//   CMX_GROUP_RCCL    ncclCommInitAll over the members' devices, one communicator per member, used from its worker
+//                     (RCCL's "one thread per device" mode) -- the default whenever the members sit on different devices;
+//   CMX_GROUP_DIRECT  peer-to-peer kernels, no library: reduce-scatter + all-gather in place over the members' own buffers
+//                     (every slice is summed by exactly one member, in member order: all members hold the same bits),
+//                     ordered by HIP events between the members' streams.  Members on ONE device (what a single-GPU box can
+//                     run: the tests, bench.py's group leg) always use it; across devices it needs peer access (xGMI) and
+//                     has never run on hardware -- opt-in.
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only (see cmx_comm.cpp)
+
+#include "cmx_context.hpp"
+
+namespace {
+
+constexpr int kMaxMembers = 16;
+constexpr double kSpinIdleUs = 300.0;     // a worker spins this long for the next command before it sleeps
+constexpr double kBarrierTimeoutMs = 20000.0;
+
+// ---- the direct transport's kernels.  ptrs[m] = member m's buffer (same length everywhere); member `me` owns slice `me`.
+struct PeerPtrs { void *p[kMaxMembers]; };
+
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void peer_reduce_scatter_kernel(PeerPtrs pp, int n, int me, size_t beg, size_t end) {
+  T *mine = static_cast<T *>(pp.p[me]);
+  for (size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) {
+    T acc = static_cast<const T *>(pp.p[0])[i];
+    for (int m = 1; m < n; m++) {  // member order: whoever computes a slice, the bits are the same
+      const T v = static_cast<const T *>(pp.p[m])[i];
+      acc = MAX ? (v > acc ? v : acc) : (T)(acc + v);
+    }
+    mine[i] = acc;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void peer_all_gather_kernel(PeerPtrs pp, int n, int me, size_t per, size_t count) {
+  T *mine = static_cast<T *>(pp.p[me]);
+  for (int m = 0; m < n; m++) {
+    if (m == me) continue;
+    const size_t beg = (size_t)m * per, end = beg + per < count ? beg + per : count;
+    const T *src = static_cast<const T *>(pp.p[m]);
+    for (size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) mine[i] = src[i];
+  }
+}
+
+// ---- RCCL entry points a group needs beyond cmx_comm.cpp's (same lazy loading)
+struct RcclGroupApi {
+  void *handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclGroupApi &rccl_group() {
+  static RcclGroupApi api = [] {
+    RcclGroupApi a;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (!a.handle) return a;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.handle, "ncclCommInitAll");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.ok = a.CommInitAll && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct cmx_group {
+  int n = 0;
+  int transport = CMX_GROUP_DIRECT;
+  cmx_ctx *m[kMaxMembers] = {nullptr};
+  std::vector<std::thread> workers;
+  // ---- command word: the leader publishes, the workers run it on their member
+  std::atomic<unsigned long long> seq{0};
+  const std::function<int(cmx_ctx *, int)> *cmd = nullptr;
+  std::atomic<int> remaining{0};
+  int rc[kMaxMembers] = {0};
+  std::atomic<int> abort_flag{0};  // a member failed: peers waiting for it in the direct transport give up
+  bool quit = false;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> sleepers{0};
+  // ---- direct transport
+  struct DirectUser { cmx_group *g; int rank; } duser[kMaxMembers];
+  void *slot_ptr[kMaxMembers] = {nullptr};
+  hipEvent_t ev_ready[kMaxMembers] = {nullptr}, ev_rs[kMaxMembers] = {nullptr}, ev_ag[kMaxMembers] = {nullptr};
+  std::atomic<int> bar_count{0};
+  std::atomic<unsigned> bar_gen{0};
+  // ---- results of the members of the call in flight
+  double out_c[kMaxMembers] = {0};
+  std::vector<double> out_g[kMaxMembers];
+  int64_t evals = 0;
+  double last_fanout_us = 0;  // host time of the last fan-out: command published -> every member returned
+};
+
+namespace {
+
+// sense-reversing spin barrier over the n member threads of a call; false: a peer failed (abort) or timed out
+bool group_barrier(cmx_group *g) {
+  const unsigned gen = g->bar_gen.load(std::memory_order_acquire);
+  if (g->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == g->n) {
+    g->bar_count.store(0, std::memory_order_relaxed);
+    g->bar_gen.store(gen + 1, std::memory_order_release);
+    return true;
+  }
+  const double t0 = now_us();
+  for (unsigned spins = 0;; spins++) {
+    if (g->bar_gen.load(std::memory_order_acquire) != gen) return true;
+    if (g->abort_flag.load(std::memory_order_relaxed)) return false;
+    __builtin_ia32_pause();
+    if ((spins & 4095u) == 4095u && now_us() - t0 > kBarrierTimeoutMs * 1e3) return false;
+  }
+}
+
+template <typename T>
+void direct_launch(cmx_group *g, int me, size_t count, int op, hipStream_t s, bool gather_phase) {
+  PeerPtrs pp{};
+  for (int k = 0; k < g->n; k++) pp.p[k] = g->slot_ptr[k];
+  // slices of whole 16-byte groups; member r owns [r*per, (r+1)*per)
+  const size_t grp = 16 / sizeof(T);
+  const size_t per = ((count + g->n - 1) / g->n + grp - 1) / grp * grp;
+  const size_t beg = (size_t)me * per < count ? (size_t)me * per : count, end = beg + per < count ? beg + per : count;
+  if (!gather_phase) {
+    if (end <= beg) return;
+    int blocks = (int)((end - beg + 255) / 256);
+    blocks = blocks > 1024 ? 1024 : blocks;
+    if (op == CMX_OP_MAX) hipLaunchKernelGGL((peer_reduce_scatter_kernel<T, true>), dim3(blocks), dim3(256), 0, s, pp, g->n, me, beg, end);
+    else hipLaunchKernelGGL((peer_reduce_scatter_kernel<T, false>), dim3(blocks), dim3(256), 0, s, pp, g->n, me, beg, end);
+  } else {
+    int blocks = (int)((per + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL((peer_all_gather_kernel<T>), dim3(blocks), dim3(256), 0, s, pp, g->n, me, per, count);
+  }
+}
+
+// cmx_allreduce_fn of the direct transport: called by member `rank`'s thread with the member's device current
+int direct_allreduce(void *user, void *buf, size_t count, int dt, int op, void *hip_stream) {
+  auto *u = static_cast<cmx_group::DirectUser *>(user);
+  cmx_group *g = u->g;
+  const int me = u->rank, n = g->n;
+  hipStream_t s = (hipStream_t)hip_stream;
+  g->slot_ptr[me] = buf;
+  if (hipEventRecord(g->ev_ready[me], s) != hipSuccess) return 1;  // my partial sums are complete behind this point
+  if (!group_barrier(g)) return 2;                                  // every pointer published, every ready event recorded
+  for (int k = 0; k < n; k++)
+    if (k != me && hipStreamWaitEvent(s, g->ev_ready[k], 0) != hipSuccess) return 1;
+  if (dt == CMX_DT_U8) direct_launch<unsigned char>(g, me, count, op, s, false);
+  else if (dt == CMX_DT_F32) direct_launch<float>(g, me, count, op, s, false);
+  else direct_launch<double>(g, me, count, op, s, false);
+  if (hipEventRecord(g->ev_rs[me], s) != hipSuccess) return 1;
+  if (!group_barrier(g)) return 2;
+  for (int k = 0; k < n; k++)
+    if (k != me && hipStreamWaitEvent(s, g->ev_rs[k], 0) != hipSuccess) return 1;  // every slice holds its final sum
+  if (dt == CMX_DT_U8) direct_launch<unsigned char>(g, me, count, op, s, true);
+  else if (dt == CMX_DT_F32) direct_launch<float>(g, me, count, op, s, true);
+  else direct_launch<double>(g, me, count, op, s, true);
+  if (hipEventRecord(g->ev_ag[me], s) != hipSuccess) return 1;
+  if (!group_barrier(g)) return 2;
+  // nothing queued after the collective may overwrite my buffer while a peer is still copying my slice out of it
+  for (int k = 0; k < n; k++)
+    if (k != me && hipStreamWaitEvent(s, g->ev_ag[k], 0) != hipSuccess) return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+void worker_loop(cmx_group *g, int rank) {
+  unsigned long long seen = 0;
+  for (;;) {
+    // wait for the next command: spin first (the calls of a solve follow one another within microseconds), then sleep
+    const double t0 = now_us();
+    bool have = false;
+    for (unsigned spins = 0;; spins++) {
+      if (g->seq.load(std::memory_order_acquire) != seen) { have = true; break; }
+      __builtin_ia32_pause();
+      if ((spins & 255u) == 255u && now_us() - t0 > kSpinIdleUs) break;
+    }
+    if (!have) {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->sleepers.fetch_add(1, std::memory_order_seq_cst);
+      g->cv.wait(lk, [&] { return g->seq.load(std::memory_order_seq_cst) != seen; });
+      g->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+    }
+    seen = g->seq.load(std::memory_order_acquire);
+    if (g->quit) return;
+    int rc = CMX_ERR_STATE;
+    if (g->cmd) rc = (*g->cmd)(g->m[rank], rank);
+    g->rc[rank] = rc;
+    if (rc) g->abort_flag.store(1, std::memory_order_relaxed);
+    g->remaining.fetch_sub(1, std::memory_order_acq_rel);
+  }
+}
+
+void publish(cmx_group *g) {
+  g->seq.fetch_add(1, std::memory_order_seq_cst);
+  if (g->sleepers.load(std::memory_order_seq_cst) > 0) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->cv.notify_all();
+  }
+}
+
+void batch_range(int64_t n, int B, int rank, int world, int64_t *beg, int64_t *end) {  // cmax_slam_amd/dist.py: batch_range
+  const int64_t nb = (n + B - 1) / B, per = (nb + world - 1) / world;
+  const int64_t b0 = std::min<int64_t>((int64_t)rank * per, nb), b1 = std::min<int64_t>(b0 + per, nb);
+  *beg = std::min<int64_t>(b0 * B, n);
+  *end = std::min<int64_t>(b1 * B, n);
+}
+
+}  // namespace
+
+bool is_group(const cmx_ctx *c) { return c && c->group && c->group_rank == 0; }
+int group_size(const cmx_ctx *c) { return (c && c->group) ? c->group->n : 1; }
+
+// run fn(member, rank) on every member -- member 0 on the calling thread, the others on their workers -- and return the first
+// failure (its text copied to the handle)
+int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn) {
+  cmx_group *g = leader->group;
+  const double t0 = now_us();
+  g->abort_flag.store(0, std::memory_order_relaxed);
+  g->bar_count.store(0, std::memory_order_relaxed);  // (a call that failed half-way may have left arrivals behind)
+  g->cmd = &fn;
+  g->remaining.store(g->n - 1, std::memory_order_release);
+  if (g->n > 1) publish(g);
+  int rc0 = fn(g->m[0], 0);
+  g->rc[0] = rc0;
+  if (rc0) g->abort_flag.store(1, std::memory_order_relaxed);
+  while (g->remaining.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  g->cmd = nullptr;
+  g->last_fanout_us = now_us() - t0;
+  for (int r = 0; r < g->n; r++)
+    if (g->rc[r]) {
+      if (r != 0) leader->err = "member " + std::to_string(r) + " (device " + std::to_string(g->m[r]->device) + "): " + g->m[r]->err;
+      return g->rc[r];
+    }
+  return CMX_OK;
+}
+
+static void group_teardown(cmx_group *g) {
+  if (!g) return;
+  if (!g->workers.empty()) {
+    g->quit = true;
+    publish(g);
+    for (auto &t : g->workers) t.join();
+    g->workers.clear();
+  }
+  for (int r = 0; r < g->n; r++) {
+    if (g->m[r]) (void)hipSetDevice(g->m[r]->device);
+    if (g->ev_ready[r]) hipEventDestroy(g->ev_ready[r]);
+    if (g->ev_rs[r]) hipEventDestroy(g->ev_rs[r]);
+    if (g->ev_ag[r]) hipEventDestroy(g->ev_ag[r]);
+  }
+  for (int r = g->n - 1; r >= 0; r--) {  // members: the ordinary single-context destroy (communicators included)
+    cmx_ctx *m = g->m[r];
+    if (!m) continue;
+    m->group = nullptr;
+    if (m->comm_fn) { m->comm_fn = nullptr; m->comm_user = nullptr; }
+    cmx_destroy(m);
+  }
+  delete g;
+}
+void group_destroy(cmx_ctx *leader) { group_teardown(leader->group); }
+
+int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, int W, int H, const double *lut, int Wp, int Hp,
+                             int transport) {
+  if (!out) return CMX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > kMaxMembers || transport < CMX_GROUP_AUTO || transport > CMX_GROUP_DIRECT)
+    return CMX_ERR_INVALID_ARG;
+  if (n_devices == 1) return cmx_backend_create(out, devices[0], W, H, lut, Wp, Hp);  // a group of one IS a plain context
+  bool same_device = false;
+  for (int a = 0; a < n_devices; a++)
+    for (int b = a + 1; b < n_devices; b++) same_device = same_device || devices[a] == devices[b];
+  if (transport == CMX_GROUP_AUTO) transport = same_device ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL;
+  cmx_group *g = new cmx_group();
+  g->n = n_devices;
+  g->transport = transport;
+  int rc = CMX_OK;
+  for (int r = 0; r < n_devices && !rc; r++) {
+    rc = cmx_backend_create(&g->m[r], devices[r], W, H, lut, Wp, Hp);
+    if (g->m[r]) { g->m[r]->group = g; g->m[r]->group_rank = r; }
+  }
+  cmx_ctx *leader = g->m[0];
+  *out = leader;  // returned on failure too when it exists: the caller reads cmx_last_error and destroys it
+  if (rc) {
+    if (!leader) { group_teardown(g); return rc; }
+    for (int r = 1; r < n_devices; r++)
+      if (g->m[r] && !g->m[r]->err.empty()) { leader->err = g->m[r]->err; break; }
+    return rc;
+  }
+  if (transport == CMX_GROUP_RCCL) {
+    if (same_device) return fail(leader, CMX_ERR_INVALID_ARG, "RCCL cannot place two ranks on one device: use CMX_GROUP_DIRECT");
+    if (!rccl_group().ok) return fail(leader, CMX_ERR_HIP, "librccl.so.1 could not be loaded (ncclCommInitAll)");
+    ncclComm_t comms[kMaxMembers] = {nullptr};
+    const ncclResult_t r = rccl_group().CommInitAll(comms, n_devices, devices);
+    if (r != ncclSuccess) return fail(leader, CMX_ERR_HIP, "ncclCommInitAll failed: %s", rccl_group().GetErrorString(r));
+    for (int k = 0; k < n_devices; k++) { g->m[k]->comm = comms[k]; g->m[k]->comm_rank = k; g->m[k]->comm_size = n_devices; }
+  } else {
+    for (int a = 0; a < n_devices; a++) {  // peer access between the members' devices (a no-op on one device)
+      HIP_TRY(leader, hipSetDevice(devices[a]));
+      for (int b = 0; b < n_devices; b++) {
+        if (devices[a] == devices[b]) continue;
+        int can = 0;
+        HIP_TRY(leader, hipDeviceCanAccessPeer(&can, devices[a], devices[b]));
+        if (!can) return fail(leader, CMX_ERR_HIP, "device %d cannot access device %d: the direct transport needs peer access", devices[a], devices[b]);
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(leader, CMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed", devices[a], devices[b]);
+        (void)hipGetLastError();
+      }
+    }
+    for (int r = 0; r < n_devices; r++) {
+      HIP_TRY(leader, hipSetDevice(devices[r]));
+      // system-scope release at the record: what a peer DEVICE reads behind the wait must be in memory, not in this device's L2
+      const unsigned flags = hipEventDisableTiming | hipEventReleaseToSystem;
+      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ready[r], flags));
+      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_rs[r], flags));
+      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ag[r], flags));
+      g->duser[r].g = g;
+      g->duser[r].rank = r;
+      g->m[r]->comm_fn = direct_allreduce;
+      g->m[r]->comm_user = &g->duser[r];
+      g->m[r]->comm_rank = r;
+      g->m[r]->comm_size = n_devices;
+    }
+  }
+  for (int r = 1; r < n_devices; r++) g->workers.emplace_back(worker_loop, g, r);
+  HIP_TRY(leader, hipSetDevice(devices[0]));
+  return CMX_OK;
+}
+
+// ---- the group forms of the entry points (called from the C ABI functions when the handle is a group's)
+int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
+                     const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                     int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG) {
+  cmx_group *g = leader->group;
+  const int N = g->n;
+  const bool shardable = n > 0 && event_batch_size > 0 && x && y && t_ns;
+  const int rc = group_all(leader, [&](cmx_ctx *m, int r) {
+    int64_t beg = 0, end = (r == 0) ? n : 0;  // bad arguments: member 0 gets them as they are and reports the error
+    if (shardable) {
+      batch_range(n, event_batch_size, r, N, &beg, &end);
+      // One event more than the member's batches hold.  The reference's loop `for (beg = 0; beg < n - 1; beg += B)` with
+      // `end = (n - beg > B) ? beg + B : n` (event_pano_warper.cpp:188-196) never opens a batch for a single trailing event;
+      // with the extra event a member's last batch is a whole one (n - beg = B + 1 > B) and the event itself is in no batch of
+      // this member -- the next member owns it.  The last member holding events sees the true tail, quirk included.
+      if (end > beg && end < n) end += 1;
+    }
+    const bool none = !shardable && r != 0;
+    return be_set_window_impl(m, none ? 0 : end - beg, none ? nullptr : x + beg, none ? nullptr : y + beg, none ? nullptr : t_ns + beg,
+                              nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
+                              event_sample_rate, blur_sigma, contrast_measure, IG);
+  });
+  if (rc)  // a window one member rejected is no window: no member may walk into a collective its peers will not join
+    for (int r = 0; r < N; r++) g->m[r]->have_data = false;
+  return rc;
+}
+
+int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *grad) {
+  cmx_group *g = leader->group;
+  const int P = 3 * (leader->K - leader->num_fixed);
+  for (int r = 0; r < g->n; r++)
+    if ((int)g->out_g[r].size() < P + 1) g->out_g[r].assign((size_t)P + 1, 0.0);
+  const int rc = group_all(leader, [&](cmx_ctx *m, int r) { return be_eval_one(m, drotv, &g->out_c[r], grad ? g->out_g[r].data() : nullptr); });
+  if (rc) return rc;
+  g->evals++;
+  // every member finished on the same all-reduced planes and rows: the numbers are the same bits (cmx_comm.cpp) -- a difference
+  // means the members' states diverged and nothing they report can be trusted
+  for (int r = 1; r < g->n; r++) {
+    if (memcmp(&g->out_c[r], &g->out_c[0], sizeof(double)) != 0 ||
+        (grad && P > 0 && memcmp(g->out_g[r].data(), g->out_g[0].data(), sizeof(double) * (size_t)P) != 0))
+      return fail(leader, CMX_ERR_STATE, "group members disagree (member %d: contrast %.17g vs %.17g)", r, g->out_c[r], g->out_c[0]);
+  }
+  if (contrast) *contrast = g->out_c[0];
+  if (grad) for (int k = 0; k < P; k++) grad[k] = g->out_g[0][k];
+  return CMX_OK;
+}
+
+int cmx_group_info(cmx_ctx *c, int *n_members, int *devices, int max_devices, int *transport, int64_t *events_per_member,
+                   double *last_fanout_us) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  const cmx_group *g = c->group;
+  const int n = g ? g->n : 1;
+  if (n_members) *n_members = n;
+  if (transport) *transport = g ? g->transport : CMX_GROUP_AUTO;
+  if (last_fanout_us) *last_fanout_us = g ? g->last_fanout_us : 0.0;
+  for (int r = 0; r < n && r < max_devices; r++) {
+    const cmx_ctx *m = g ? g->m[r] : c;
+    if (devices) devices[r] = m->device;
+    if (events_per_member) events_per_member[r] = m->n_packed;
+  }
+  return CMX_OK;
+}

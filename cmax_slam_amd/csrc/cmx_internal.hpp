@@ -73,6 +73,11 @@ struct ChainDev {  // one device allocation, initialised by one copy
   // self-gating slots: the image pass adds its tiles' two moments (sum B, sum B^2) to 8 shard rows of buffer (slot & 1) with
   // fp64 atomics instead of handing a table to a finalize of its own; rows 128 B apart
   double macc[2][kTailShards][16];
+  // self-gating slots: the acceptance test of the slot with parity p, published by the finalize of the slot BEFORE it.  The
+  // workgroups of a self-gating launch read gate[p]; the finalize of that very launch (which may run in workgroup 0 while
+  // others have not started: cost-only outcome) writes gate[p ^ 1] -- never the words the launch itself is still reading
+  // (the gate used to be read from `sm`, which that finalize rewrites).
+  struct Gate { double thr; int mode; int pad; } gate[2];
 };
 struct ChainArgs {
   ChainMachine *sm;  // the machine in device memory (copied to LDS and back by the finalize that advances it); null = off
@@ -81,6 +86,8 @@ struct ChainArgs {
   int stage;         // 0: this finalize ends a cost evaluation, 1: a gradient pass, 2: a self-gating slot (cost, then the gradient
                      //    if the launch computed one: FinalizeArgs::gP > 0)
   int *abort_flag;
+  const ChainDev::Gate *gate_cur;  // self-gating slots: the test this launch's workgroups evaluate (ChainDev::gate[parity]) ...
+  ChainDev::Gate *gate_next;       // ... and where its finalize publishes the next slot's
   const ChainMachine *sm_src;  // first slot of a warm-started solve: the machine's INITIAL state, read from pinned host memory by the
                                // one finalizing workgroup (no copy in front of the solve); the slot's kernels get omega as arguments,
                                // no end-of-solve flag, and take the machine's first request for what it always is (cost + gradient)

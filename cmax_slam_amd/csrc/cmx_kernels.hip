@@ -492,7 +492,11 @@ __device__ __forceinline__ void chain_step(const FinalizeArgs &a, ChainMachine &
     sm_grad(s, g);
   } else {  // self-gating slot: the launch's workgroups decided from the same contrast whether to compute the gradient
     const bool have_grad = a.gP > 0;
-    if ((gate_condition(outv[0], s.gate_thr, s.gate_mode) != 0) != have_grad) {
+    // (the test the workgroups evaluated: the published copy; first slot of a warm start: "always")
+    const double cur_thr = a.chain.sm_src ? 0.0 : a.chain.gate_cur->thr;
+    const int cur_mode = a.chain.sm_src ? 4 : a.chain.gate_cur->mode;
+    if ((gate_condition(outv[0], cur_thr, cur_mode) != 0) != have_grad || cur_mode != s.gate_mode ||
+        __double_as_longlong(cur_thr) != __double_as_longlong(s.gate_thr)) {
       disagree = 1;  // (cannot happen: same number, same expression) -- the machine is left where it was, the host takes over
     } else {
       need = sm_cost(s, -outv[0]) ? 1 : 0;
@@ -509,6 +513,10 @@ __device__ __forceinline__ void chain_step(const FinalizeArgs &a, ChainMachine &
   const int done = (sm_done(s) || disagree) ? 1 : 0;
   const bool moved = a.chain.stage != 0 || !need;  // the machine has gone on to its next request
   if (a.gate_out) *a.gate_out = need;              // read by the gradient pass queued behind this launch
+  if (a.chain.gate_next) {                         // self-gating slots: the NEXT slot's test, in the words this launch does not read
+    a.chain.gate_next->thr = s.gate_thr;
+    a.chain.gate_next->mode = s.gate_mode;
+  }
   if (done) *a.chain.done = 1;                     // read by every later launch of the chain
   else if (a.chain.sm_src) *a.chain.done = 0;      // (first slot of a warm start: the flag still says the previous solve ended)
   outv[nout] = (double)need;
@@ -1617,7 +1625,9 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     chain_moment_sums(fa.macc, s0, s1);
     const double c = contrast_from_sums(s0, s1, fa.npix, fa.measure, &mu);
     // (first slot of a warm start: the machine's first request is cost + gradient, gate mode 4 -- its state is still on the host)
-    if (!fa.chain.sm_src && !gate_condition(c, fa.chain.sm->gate_thr, fa.chain.sm->gate_mode)) {
+    // the gate is read from the slot-parity copy the PREVIOUS slot's finalize published: this launch's own finalize may already
+    // be rewriting the machine (workgroup 0, cost-only outcome) while late workgroups arrive here
+    if (!fa.chain.sm_src && !gate_condition(c, fa.chain.gate_cur->thr, fa.chain.gate_cur->mode)) {
       if (blockIdx.x != 0) return;
       FinalizeArgs f = fa;  // cost only: no gradient sums to read
       f.gP = 0;

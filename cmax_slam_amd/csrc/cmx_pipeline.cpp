@@ -819,12 +819,13 @@ int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad) {
 }
 int cmx_frontend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_FE, want_grad); }
 int cmx_frontend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_FE, contrast, grad); }
-int cmx_backend_finish_begin(cmx_ctx *c, int want_grad) { return finish_begin(c, KIND_BE, want_grad); }
-int cmx_backend_finish_end(cmx_ctx *c, double *contrast, double *grad) { return finish_end(c, KIND_BE, contrast, grad); }
+int cmx_backend_finish_begin(cmx_ctx *c, int want_grad) { CMX_NOT_FOR_GROUPS(c, "the split-phase interface"); return finish_begin(c, KIND_BE, want_grad); }
+int cmx_backend_finish_end(cmx_ctx *c, double *contrast, double *grad) { CMX_NOT_FOR_GROUPS(c, "the split-phase interface"); return finish_end(c, KIND_BE, contrast, grad); }
 void *cmx_grad_ptr(const cmx_ctx *c) { return c ? c->d_gsum : nullptr; }
 size_t cmx_grad_count(const cmx_ctx *c) { return (c && c->finish_pending && c->pending_P > 0) ? (size_t)(2 * c->pending_P) : 0; }
 int cmx_set_grad_buffer(cmx_ctx *c, void *device_ptr, size_t n_doubles) {
   if (!c) return CMX_ERR_INVALID_ARG;
+  CMX_NOT_FOR_GROUPS(c, "a caller-owned gradient buffer");
   int rc = bind_device(c);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

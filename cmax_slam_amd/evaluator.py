@@ -106,6 +106,23 @@ class _Evaluator:
         memory, fixed summation orders everywhere; ~10-20 % slower.  Applies to the production path."""
         self.set_option(_lib.OPT_DETERMINISTIC, 1 if on else 0)
 
+    def set_stream_priority(self, level):
+        """cmx_set_stream_priority: > 0 highest (the front end beside a back-end solve), 0 normal, < 0 lowest."""
+        self._ck(self._L.cmx_set_stream_priority(self._ctx, int(level)))
+
+    def set_cu_mask(self, n_cus=None, first=0, mask_words=None):
+        """cmx_set_cu_mask: run on `n_cus` compute units starting at bit `first` (on MI355X consecutive bits walk the eight
+        XCDs, so any run of bits is spread over all of them), or on an explicit list of 32-bit words; None / 0 = all."""
+        if mask_words is None:
+            if not n_cus:
+                self._ck(self._L.cmx_set_cu_mask(self._ctx, None, 0))
+                return
+            bits = ((1 << int(n_cus)) - 1) << int(first)
+            nw = max(8, (bits.bit_length() + 31) // 32)
+            mask_words = [(bits >> (32 * i)) & 0xffffffff for i in range(nw)]
+        arr = (C.c_uint32 * len(mask_words))(*mask_words)
+        self._ck(self._L.cmx_set_cu_mask(self._ctx, arr, len(mask_words)))
+
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned stream (an int / void* hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
         self._ck(self._L.cmx_set_stream(self._ctx, C.c_void_p(hip_stream_handle or None)))
@@ -339,14 +356,46 @@ class FrontendEvaluator(_Evaluator):
 
 
 class BackendEvaluator(_Evaluator):
-    def __init__(self, W, H, lut, pano_width, pano_height, device=0):
+    def __init__(self, W, H, lut, pano_width, pano_height, device=0, devices=None, transport=0):
+        """devices = [d0, d1, ...]: a one-process multi-GPU GROUP (cmx_backend_create_group) behind the same interface --
+        set_window shards the window, eval / setupProblemAndOptimize fan out and return one contrast / gradient.  The same
+        device may be listed more than once (members sharing a GPU: how a one-GPU box exercises the group)."""
         super().__init__()
         self.W, self.H, self.Wp, self.Hp = int(W), int(H), int(pano_width), int(pano_height)
         lut = _c(lut, np.float64).reshape(-1)
         if lut.size != self.W * self.H * 3:
             raise ValueError("lut must hold W*H*3 doubles")
-        self._ck(self._L.cmx_backend_create(C.byref(self._ctx), int(device), self.W, self.H, _dp(lut), self.Wp, self.Hp))
+        if devices is None:
+            self._ck(self._L.cmx_backend_create(C.byref(self._ctx), int(device), self.W, self.H, _dp(lut), self.Wp, self.Hp))
+        else:
+            dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self._ck(self._L.cmx_backend_create_group(C.byref(self._ctx), dv, len(devices), self.W, self.H, _dp(lut), self.Wp,
+                                                      self.Hp, int(transport)))
         self.K = self.num_fixed = 0
+
+    def group_info(self):
+        """{'members', 'devices', 'transport', 'events_per_member', 'last_fanout_us'} of this handle (a plain context: 1 member)."""
+        n, tr, us = C.c_int(), C.c_int(), C.c_double()
+        dev = (C.c_int * 16)()
+        ev = np.zeros(16, np.int64)
+        self._ck(self._L.cmx_group_info(self._ctx, C.byref(n), dev, 16, C.byref(tr), ev.ctypes.data_as(c_i64p), C.byref(us)))
+        return {"members": n.value, "devices": list(dev[:n.value]), "transport": tr.value,
+                "events_per_member": [int(v) for v in ev[:n.value]], "last_fanout_us": us.value}
+
+    def get_pose_table(self):
+        """cmx_backend_get_pose_table: (R[nb,3,3] fp64, Jcp[nb,3,3*order] fp32, idx[nb], t_batch_ns[nb]) at the last evaluation's
+        parameters -- what Trajectory::evaluate returns per batch (value, ddrot_ddrot_cp, idx_cp_beg)."""
+        nb = C.c_int()
+        self._ck(self._L.cmx_backend_get_pose_table(self._ctx, 0, None, None, None, None, C.byref(nb)))
+        n = nb.value
+        R = np.zeros((max(n, 1), 9))
+        J = np.zeros((max(n, 1), 36), np.float32)
+        idx = np.zeros(max(n, 1), np.int32)
+        t = np.zeros(max(n, 1), np.int64)
+        self._ck(self._L.cmx_backend_get_pose_table(self._ctx, n, _dp(R), J.ctypes.data_as(c_fp), idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                                    t.ctypes.data_as(c_i64p), C.byref(nb)))
+        order = self._order
+        return (R[:n].reshape(n, 3, 3), J[:n, :9 * order].reshape(n, 3, 3 * order), idx[:n].copy(), t[:n].copy())
 
     @property
     def num_params(self):
@@ -369,7 +418,7 @@ class BackendEvaluator(_Evaluator):
             int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns),
             int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
             C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
-        self.K, self.num_fixed = k.shape[0], int(num_fixed)
+        self.K, self.num_fixed, self._order = k.shape[0], int(num_fixed), int(order)
 
     def set_window_from(self, store, first, count, order, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns,
                         event_batch_size=100, event_sample_rate=1, blur_sigma=1.0, contrast_measure=VARIANCE, IG=None):
@@ -382,7 +431,7 @@ class BackendEvaluator(_Evaluator):
             int(num_fixed), int(t_next_win_beg_ns), int(event_batch_size), int(event_sample_rate), float(blur_sigma),
             int(contrast_measure),
             C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
-        self.K, self.num_fixed = k.shape[0], int(num_fixed)
+        self.K, self.num_fixed, self._order = k.shape[0], int(num_fixed), int(order)
 
     def prepare(self, drotv_hint=None):
         """cmx_backend_prepare: pose table at the hint, tile sort, chunk table and bearing streams of the window, queued now."""

@@ -121,6 +121,17 @@ void cmx_destroy(cmx_ctx *ctx);
 int cmx_set_option(cmx_ctx *ctx, int key, int value);
 /* run the context's work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
 int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
+/* Two paths on one GPU.  The reference runs the front end (a packet every 10 ms, src/node.cpp:22) beside the back-end thread's
+ * window solves (src/cmax_slam.cpp:92); on one GPU the two contexts' kernels share the compute units.  Both calls replace the
+ * context's OWN stream (they wait for its queued work first; not with cmx_set_stream's caller-owned stream):
+ *   cmx_set_stream_priority  level > 0: the device's highest stream priority (the front end: its short kernels are dispatched
+ *                            ahead of the back end's queued workgroups), 0: normal, < 0: lowest;
+ *   cmx_set_cu_mask          the stream's kernels run on the compute units whose bit is set (hipExtStreamCreateWithCUMask;
+ *                            n_words x 32 bits; on MI355X bit i = compute unit i / 8 of XCD i % 8, so the first k bits spread
+ *                            over all eight XCDs); n_words == 0: all compute units, normal priority.
+ * Results never depend on either. */
+int cmx_set_stream_priority(cmx_ctx *ctx, int level);
+int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
 
 /* ------------------------------------------------------------------ front end -------------------------
  * replaces AngVelEstimator::computeImageOfWarpedEvents + computeContrast
@@ -217,6 +228,13 @@ enum { CMX_PLANE_IL_OLD = 0, CMX_PLANE_IL_NEW = 1, CMX_PLANE_IWE = 2, CMX_PLANE_
  * plane j (only after an evaluation with CMX_GRAD_PLANES and grad != NULL). host: Hp*Wp fp32. */
 int cmx_backend_get_plane(cmx_ctx *ctx, int which, float *host);
 int cmx_backend_get_alpha(cmx_ctx *ctx, double *alpha);
+/* Parity read-back of the per-batch pose table the splat and gather kernels read (be_pose_table kernels = So3Spline::evaluate
+ * with Jacobians, thirdparty/basalt-headers/include/basalt/spline/so3_spline.h:218-274, as Trajectory::evaluate stores them,
+ * src/backend/trajectory.cpp:86-110 / :329-355): recomputed on the device at the LAST evaluation's parameters (zero increments
+ * before the first one).  R = n x 9 fp64 row-major; Jcp = n x 36 fp32, the 3 x 3*order row-major block in front; idx = first
+ * control pose of the batch's segment; t_batch_ns = the batch's pose time.  Any output may be NULL; *n_batches = batches of
+ * the window; at most max_batches rows are written. */
+int cmx_backend_get_pose_table(cmx_ctx *ctx, int max_batches, double *R, float *Jcp, int *idx, int64_t *t_batch_ns, int *n_batches);
 
 /* Global-map upkeep on the device (once per window, after the solve).  Keeps IG_ and
  * IG_update_times_map_ resident across windows: pass IG = CMX_KEEP_MAP to cmx_backend_set_window instead of
@@ -319,6 +337,33 @@ enum { CMX_OP_SUM = 0, CMX_OP_MAX = 1 };
 typedef int (*cmx_allreduce_fn)(void *user, void *device_buf, size_t count, int dtype, int op, void *hip_stream);
 int cmx_comm_attach_custom(cmx_ctx *ctx, cmx_allreduce_fn fn, void *user, int rank, int nranks);
 
+/* ------------------------------------------------------------------ one-process multi-GPU: a GROUP ---------
+ * The reference's host is ONE process with ONE back-end thread and ONE GSL instance (src/cmax_slam.cpp:92,
+ * src/backend/global_optim_contrast_gsl.cpp:23-33): it cannot be started once per GPU.  cmx_backend_create_group returns an
+ * ordinary back-end handle whose evaluations fan out to n_devices member contexts: cmx_backend_set_window shards the window
+ * by whole event batches (member r = rank r of the one-process-per-GPU form; event_pano_warper.cpp:188-196 is the loop being
+ * split), cmx_backend_eval / cmx_backend_solve run the members' splat, the plane / tile-set exchange, blur, gather and the
+ * gradient-row exchange on all devices and return ONE contrast / gradient -- the bodies of global_contrast_{f,df,fdf} do not
+ * change, there is one optimiser and no launcher.  The map upkeep calls, cmx_set_option and cmx_destroy act on every member
+ * (each keeps its own replica of IG); cmx_backend_get_plane / get_alpha / get_map / cmx_get_stats read member 0.  The caller
+ * stays single-threaded; the group owns one worker thread per further member (queueing eight devices' launches from one
+ * thread would take longer than the evaluation runs).  Not available on a group: the split-phase interface, caller-owned
+ * buffers / streams, cmx_comm_attach*, cmx_backend_set_window_from, cmx_backend_eval_many.
+ *   transport: CMX_GROUP_RCCL  -- ncclCommInitAll, one communicator per member (devices must be distinct);
+ *              CMX_GROUP_DIRECT -- peer-to-peer reduce-scatter + all-gather kernels over the members' own buffers, ordered by
+ *                                  HIP events (needs peer access between the devices; the only form for members that share
+ *                                  ONE device, which is how a single-GPU box exercises all of this);
+ *              CMX_GROUP_AUTO   -- DIRECT if two members share a device, RCCL otherwise.
+ * n_devices == 1 returns a plain context (no group, no overhead).  Results equal the single-context evaluation of the whole
+ * window to summation order (the planes are sums of the members' partial planes). */
+enum { CMX_GROUP_AUTO = 0, CMX_GROUP_RCCL = 1, CMX_GROUP_DIRECT = 2 };
+int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, int W, int H, const double *lut, int Wp, int Hp,
+                             int transport);
+/* what a handle is made of: members, their devices, the transport in use, packed events per member of the current window,
+ * host microseconds of the last fan-out (command published -> all members returned).  Any pointer may be NULL. */
+int cmx_group_info(cmx_ctx *ctx, int *n_members, int *devices, int max_devices, int *transport, int64_t *events_per_member,
+                   double *last_fanout_us);
+
 /* ------------------------------------------------------------------ optimiser driver (host C++) ----------
  * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors
  * (src/frontend/local_optim_contrast_gsl.cpp:74-233, src/backend/global_optim_contrast_gsl.cpp:15-145).  These
@@ -406,8 +451,9 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
 #define CMX_N_STATS 17
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes
- * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added) */
-#define CMX_ABI_VERSION 3
+ * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added;
+ *  4: groups, cmx_backend_get_pose_table, stream priority / CU mask) */
+#define CMX_ABI_VERSION 4
 int cmx_abi_version(void);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);

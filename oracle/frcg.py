@@ -1,7 +1,7 @@
 """oracle/frcg.py -- Python restatement of the optimiser the reference drives its cost functors with.
 
 TEST INFRASTRUCTURE ONLY (same rule as the rest of oracle/): the product's driver is host C++
-(cmax_slam_amd/csrc/cmx_frcg.hpp + cmx_solver.cpp); this file is the second, independently written implementation
+(cmax_slam_amd/csrc/cmx_frcg_sm.hpp + cmx_solver.cpp); this file is the second, independently written implementation
 the tests compare it with, call for call.
 
 What is restated, and from where

@@ -1,4 +1,4 @@
-"""CPU: the product's FR-CG driver (cmx_frcg_minimize: host C++, cmx_frcg.hpp + cmx_solver.cpp) against a second,
+"""CPU: the product's FR-CG driver (cmx_frcg_minimize: host C++, cmx_frcg_sm.hpp + cmx_solver.cpp) against a second,
 independently written restatement of GSL's conjugate_fr + the reference's stopping rules (oracle/frcg.py, Python),
 CALL FOR CALL: both are run over the same deterministic functor and must ask for the same evaluations (cost-only or
 with gradient) at bitwise the same points, and return the same iterate, counts and costs.

@@ -199,3 +199,48 @@ def test_warm_started_solves_between_other_uses_of_the_context(hip, oracle):
     fe.set_option(_lib.OPT_CHAIN_SOLVE, 1)
     _close(fe.setupProblemAndOptimize(np.zeros(3)), host_q)
     assert fe.stats()["chain_warm_starts"] == warm + 1 and fe.stats()["chain_takeovers"] == 1
+
+
+def test_flat_start_beside_a_busy_context_keeps_the_accumulators_clean(hip, oracle):
+    """in a self-gating slot whose outcome is 'cost only', workgroup 0 runs the finalize and the machine's step
+    while other workgroups of the SAME launch may not have started; they used to read the gate from the machine that step had just
+    rewritten -- a late workgroup could then take the gradient path, add to the accumulator rows and bump the arrival tickets
+    with no finalize to consume them (the next slot's gradient polluted, its last-arriver detection early).  The gate now lives
+    in a slot-parity copy (ChainDev::gate) the launch's own finalize never writes.  Stress: the halving loop of a flat start
+    (hundreds of chained cost-only slots whose next request often passes for the same contrast) while a second context keeps
+    the compute units busy with large launches, so that workgroups of the one-block-wide decisions arrive late; after every solve
+    a plain gradient evaluation on the same context must equal the oracle's (it reads the accumulator rows and tickets the solve
+    left behind), and the warm-started solve after it must reach what the host-driven one reaches."""
+    import threading
+    p = synth.frontend_packet(150_000, 320, 240, 300.0, 300.0, 159.5, 119.5, T=0.12, omega_true=(2.5, -3.5, 1.5), seed=81)
+    big = synth.frontend_packet(1_000_000, 640, 480, 570.0, 570.0, 319.5, 239.5, seed=84)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, oracle.VARIANCE)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    x_chk = 0.3 * np.array(p.omega_true)
+    c_ref, g_ref = ref.eval(x_chk)
+    host_flat = _fe(hip, p, 0).setupProblemAndOptimize(np.zeros(3))
+    host_good = _fe(hip, p, 0).setupProblemAndOptimize(x_chk)
+    noisy = _fe(hip, big, 0)
+    stop = threading.Event()
+
+    def hammer():
+        xs = np.random.default_rng(1).normal(0, 1.0, (64, 3))
+        while not stop.is_set():
+            noisy.eval_many(xs, True)        # 64 evaluations of 1M events queued back to back: the GPU never idles
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        fe = _fe(hip, p, 1)
+        for k in range(6):
+            flat = fe.setupProblemAndOptimize(np.zeros(3))
+            assert flat[1]["n_f"] >= 10 and np.abs(flat[0]).max() < 1e-2
+            assert abs(flat[1]["final_cost"] - host_flat[1]["final_cost"]) < 1e-5 * abs(host_flat[1]["final_cost"])
+            c, g = fe.eval(x_chk)
+            assert abs(c - c_ref) < 1e-5 * abs(c_ref) and np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max(), (k, g, g_ref)
+            good = fe.setupProblemAndOptimize(x_chk)
+            _close(good, host_good)
+        st = fe.stats()
+        assert st["chain_solves"] == 12 and st["chain_takeovers"] == 0, st
+    finally:
+        stop.set()
+        th.join()

@@ -1,0 +1,223 @@
+"""-m gpu: one-process multi-GPU -- a GROUP of back-end contexts behind one handle (cmx_backend_create_group).
+
+The reference's host is one process / one back-end thread / one GSL instance (src/cmax_slam.cpp:92,
+src/backend/global_optim_contrast_gsl.cpp:23-33).  A group is driven exactly like a single context: ONE thread calls
+set_window / eval / setupProblemAndOptimize on ONE handle; the library shards the window by whole batches, fans the
+evaluation out, exchanges the partial planes and gradient rows between the members and returns one contrast / gradient.
+
+A one-GPU box runs the members on the SAME device (the direct transport: peer reduce-scatter + all-gather kernels ordered
+by HIP events); the variants over 2 / 4 / 8 devices (RCCL through ncclCommInitAll, and the direct transport across
+devices) skip by device count.  Everything is compared with the single-context evaluation of the whole window -- itself
+compared with the oracle at these very sizes by test_gpu_baseline_configs.py / test_gpu_config5_full.py -- and, at a size
+the oracle finishes in seconds, with the oracle directly."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import _lib, dist, synth
+from util import RTOL, rel_img, rel_scalar, rel_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(be, w, IG=None, n=None):
+    n = len(w.x) if n is None else n
+    be.set_window(w.x[:n], w.y[:n], w.t_ns[:n], w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
+                  w.batch, w.sample_rate, w.sigma, _lib.VARIANCE, IG)
+
+
+def _pair(hip, w, devices, IG=None, n=None, transport=0, fast=True):
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=devices, transport=transport)
+    one = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    if fast:
+        grp.set_fast_path()
+        one.set_fast_path()
+    _set(grp, w, IG, n)
+    _set(one, w, IG, n)
+    return grp, one
+
+
+def _same(grp, one, seq, tol=1e-6):
+    for i, (d, want) in enumerate(seq):
+        c0, g0 = one.eval(d, want)
+        c, g = grp.eval(d, want)
+        assert rel_scalar(c, c0) < tol, (i, c, c0)
+        if want:
+            assert rel_vec(g, g0) < tol, (i, g, g0)
+
+
+def test_group_of_two_on_one_gpu_config4_slab(hip):
+    """BASELINE config 4's per-GPU slab (5M events, cubic K = 10, 1024^2) split over two members of one device: the shards are
+    dist.batch_range's, the evaluations -- a sequence with a cost-only point, a repeated point (image reuse) and a parameter jump
+    that leaves the exchange set -- equal the single context's; one handle, one thread."""
+    w = synth.config4_slab(2, 8, 5_000_000)
+    grp, one = _pair(hip, w, [0, 0])
+    info = grp.group_info()
+    assert info["members"] == 2 and info["devices"] == [0, 0] and info["transport"] == _lib.GROUP_DIRECT
+    want = [dist.batch_range(len(w.x), w.batch, r, 2) for r in range(2)]
+    assert info["events_per_member"] == [e - b for b, e in want]      # (sample rate 1: packed events = events of the shard)
+    rng = np.random.default_rng(7)
+    small = rng.normal(0, 0.004, w.P)
+    jump = np.tile([0.5, 0.0, 0.0], w.P // 3)
+    seq = [(np.zeros(w.P), True), (small, False), (small, True), (rng.normal(0, 0.004, w.P), True), (jump, True), (jump, False),
+           (np.zeros(w.P), True)]
+    _same(grp, one, seq)
+    s = grp.stats()
+    assert s["exchange_misses"] >= 1 and s["sharded_host_syncs"] == 0 and 0 < s["exchange_tiles"] < 1024 // 4, s
+    assert s["comm_bytes"] < 2 * (1 << 20), s            # a set of tiles + the gradient rows, not 2 x 4 MB of planes
+    # the planes a member holds after the exchange are the window's (what updateIG / publishEventImage read)
+    assert rel_img(grp.get_plane(_lib.PLANE_IL_OLD), one.get_plane(_lib.PLANE_IL_OLD)) < 1e-6
+    assert rel_img(grp.get_plane(_lib.PLANE_IWE), one.get_plane(_lib.PLANE_IWE)) < 1e-6
+    assert 0 < grp.group_info()["last_fanout_us"] < 5e5
+    grp.close()
+    one.close()
+
+
+def test_group_of_two_on_one_gpu_config5_slab_with_a_map(hip):
+    """BASELINE config 5's per-GPU slab (2.5M events, 1280x720, 4096x2048, linear K = 5) with a non-zero global map: alpha is
+    formed by every member from the exchanged planes and equals the single context's; tile-set exchange on 32 MB planes."""
+    w = synth.config5_slab(3, 8, 2_500_000)
+    IG = np.zeros((w.Hp, w.Wp), np.float32)
+    IG[900:1100, 1500:2600] = 0.7
+    grp, one = _pair(hip, w, [0, 0], IG)
+    rng = np.random.default_rng(8)
+    seq = [(np.zeros(w.P), True), (rng.normal(0, 0.003, w.P), True), (rng.normal(0, 0.003, w.P), False),
+           (np.tile([0.25, 0.0, 0.0], w.P // 3), True), (np.zeros(w.P), True)]
+    _same(grp, one, seq)
+    assert one.alpha > 0 and rel_scalar(grp.alpha, one.alpha) < 1e-7
+    s = grp.stats()
+    assert s["sharded_host_syncs"] == 0 and s["comm_bytes"] < 0.1 * 2 * w.Wp * w.Hp * 4, s
+    # map upkeep acts on every member's replica; the next window (resident map) still agrees
+    for ev in (grp, one):
+        ev.eval(np.zeros(w.P), False)
+        ev.setUpdateTimesIG(w.knots_init[0], 3)
+        ev.updateIG(5)
+    assert rel_img(grp.getIG(), one.getIG()) < 1e-6
+    for ev in (grp, one):
+        _set(ev, w, "resident", n=1_000_000)
+    _same(grp, one, [(np.zeros(w.P), True), (rng.normal(0, 0.003, w.P), True)])
+    assert rel_scalar(grp.alpha, one.alpha) < 1e-7
+    grp.close()
+    one.close()
+
+
+@pytest.mark.parametrize("members,n_events,batch", [(2, 30_001, 100), (3, 20_000, 128), (4, 150, 100), (4, 2_001, 1), (2, 1, 100)])
+def test_group_vs_oracle_ragged_shards_and_empty_members(hip, oracle, members, n_events, batch):
+    """Against the oracle directly, at sizes it finishes in seconds: a window whose last batch is the single trailing event the
+    reference's loop never opens a batch for (event_pano_warper.cpp:188-196), members that hold NO events (150 events = 2
+    batches for 4 members), batch size 1 (every member's last event would be dropped by a naive split), a one-event window."""
+    w = synth.backend_window(n_events, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.3, seed=71 + members)
+    w.batch = batch
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0] * members)
+    grp.set_fast_path()
+    _set(grp, w)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, w.batch, w.sample_rate, w.sigma, oracle.VARIANCE)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    per = grp.group_info()["events_per_member"]
+    n_in_batches = n_events if (n_events - 1) % batch else n_events - 1      # a trailing single event is in no batch
+    assert sum(per) == (n_in_batches if n_events > 1 else 0), (per, n_events)
+    if members == 4 and n_events == 150:
+        assert per[2] == 0 and per[3] == 0
+    rng = np.random.default_rng(9)
+    for k, want in enumerate([True, False, True]):
+        d = rng.normal(0, 0.01, w.P) if k else np.zeros(w.P)
+        c_ref, g_ref = ref.eval(d)
+        c, g = grp.eval(d, want)
+        assert rel_scalar(c, c_ref) < RTOL or (c_ref == 0 and c == 0), (k, c, c_ref)
+        if want and np.abs(g_ref).max() > 0:
+            assert rel_vec(g, g_ref) < RTOL, (k, g, g_ref)
+    if n_events > 1:
+        assert rel_img(grp.get_plane(_lib.PLANE_IL_OLD) + grp.get_plane(_lib.PLANE_IL_NEW), ref.IL_old + ref.IL_new) < RTOL
+    grp.close()
+
+
+def test_group_reference_shaped_path_and_small_planes(hip):
+    """Derivative planes (CMX_GRAD_PLANES) through a group: 2 + P whole planes travel; 0.5 MB planes travel whole on the
+    production path too."""
+    w = synth.backend_window(30_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 10, 3, 0.35, seed=49)
+    for fast in (False, True):
+        grp, one = _pair(hip, w, [0, 0], fast=fast)
+        _same(grp, one, [(np.zeros(w.P), True), (np.full(w.P, 0.003), False), (np.full(w.P, 0.003), True)])
+        grp.close()
+        one.close()
+
+
+def test_group_solve_is_one_optimiser(hip):
+    """cmx_backend_solve on the handle: ONE FR-CG driver whose every evaluation fans out -- the unchanged
+    global_contrast_{f,df,fdf} bodies.  Same decisions as over the single context up to the summation order of the planes:
+    compared by outcome (FR-CG's loose stopping rules amplify 1e-8 differences, see test_gpu_solver.py)."""
+    w = synth.backend_window(200_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 1024, 512, 2, 5, 0, 0.2, seed=83, knot_sigma=0.02)
+    grp, one = _pair(hip, w, [0, 0, 0])
+    xg, rg = grp.setupProblemAndOptimize()
+    x1, r1 = one.setupProblemAndOptimize()
+    assert rg["initial_cost"] == pytest.approx(r1["initial_cost"], rel=1e-6)
+    assert abs(rg["final_cost"] - r1["final_cost"]) < 2e-3 * abs(r1["final_cost"]), (rg, r1)
+    assert rg["final_cost"] < rg["initial_cost"] and rg["n_f"] + rg["n_df"] >= 3
+    assert np.abs(xg - x1).max() < 0.02, (xg, x1)
+    # a second window on the same handle (workers woken again after idling)
+    import time
+    time.sleep(0.05)
+    _set(grp, w, None, n=120_000)
+    _set(one, w, None, n=120_000)
+    _same(grp, one, [(xg, True), (np.zeros(w.P), True)])
+    grp.close()
+    one.close()
+
+
+def test_group_errors_do_not_hang(hip):
+    """A window one member rejects (an event outside the sensor in the SECOND member's shard) fails the call with that member's
+    message and leaves the group without a window; bad arguments fail like on a plain context; the handle stays usable."""
+    w = synth.backend_window(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.3, seed=91)
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0])
+    grp.set_fast_path()
+    x_bad = w.x.copy()
+    x_bad[30_000] = 1000
+    with pytest.raises(hip.CmaxHipError) as e:
+        grp.set_window(x_bad, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                       w.sample_rate, w.sigma, _lib.VARIANCE, None)
+    assert e.value.status == _lib.ERR_EVENT_RANGE and "member 1" in str(e.value)
+    with pytest.raises(hip.CmaxHipError) as e:
+        grp.eval(np.zeros(w.P))
+    assert e.value.status == _lib.ERR_STATE
+    with pytest.raises(hip.CmaxHipError):
+        grp.accumulate(np.zeros(w.P))          # split-phase interface: not on a group
+    with pytest.raises(hip.CmaxHipError):
+        grp.set_window(w.x, w.y, w.t_ns, 3, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                       w.sample_rate, w.sigma, _lib.VARIANCE, None)     # spline order 3
+    _set(grp, w)
+    one = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    one.set_fast_path()
+    _set(one, w)
+    _same(grp, one, [(np.zeros(w.P), True)])
+    grp.close()
+    one.close()
+
+
+def test_group_of_one_is_a_plain_context(hip):
+    w = synth.backend_window(10_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 0, 0.2, seed=92)
+    g1 = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0])
+    assert g1.group_info()["members"] == 1
+    g1.set_fast_path()
+    _set(g1, w)
+    c, g = g1.eval(np.zeros(w.P))
+    assert g1.stats()["comm_bytes"] == 0 and np.isfinite(c)
+    g1.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 4, 8])
+@pytest.mark.parametrize("transport", [_lib.GROUP_RCCL, _lib.GROUP_DIRECT])
+def test_group_over_several_devices(hip, n_dev, transport):
+    """The same over n_dev GPUs of one node (RCCL via ncclCommInitAll; the direct peer-to-peer transport) -- skips on boxes
+    with fewer devices (every box the builder has seen)."""
+    if _lib.lib().cmx_device_count() < n_dev:
+        pytest.skip("needs %d GPUs" % n_dev)
+    w = synth.config4_slab(1, 8, 2_000_000)
+    grp, one = _pair(hip, w, list(range(n_dev)), transport=transport)
+    rng = np.random.default_rng(17)
+    seq = [(np.zeros(w.P), True), (rng.normal(0, 0.004, w.P), False), (rng.normal(0, 0.004, w.P), True),
+           (np.tile([0.5, 0.0, 0.0], w.P // 3), True)]
+    _same(grp, one, seq)
+    xg, rg = grp.setupProblemAndOptimize()
+    x1, r1 = one.setupProblemAndOptimize()
+    assert abs(rg["final_cost"] - r1["final_cost"]) < 2e-3 * abs(r1["final_cost"])
+    grp.close()
+    one.close()

@@ -1,5 +1,5 @@
 """CPU: the restated FR-CG driver (cmx_frcg_minimize, host C++ in libcmaxhip.so) on known functions and on the
-CPU oracle's cost functor.  (GSL itself is absent: the restatement is unpinned against GSL, see cmx_frcg.hpp.)"""
+CPU oracle's cost functor.  (GSL itself is absent: the restatement is unpinned against GSL, see cmx_frcg_sm.hpp.)"""
 import numpy as np
 import pytest
 
