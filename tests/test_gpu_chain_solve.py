@@ -56,8 +56,10 @@ def test_chain_solve_reaches_what_the_host_driven_solve_reaches(hip, oracle, n_e
     x_ref, rep_ref = solver.frcg_minimize(fdf, np.zeros(3), **solver.FRONTEND)
     _close(dev, (x_ref, rep_ref))
     # the context is usable as before: a plain evaluation, a second solve (warm start), a new packet
-    c, g = fe.eval(dev[0])
-    c_ref, g_ref = ref.eval(dev[0])
+    # (half-way to the solution: AT the solution the gradient is a 100x smaller difference of the same fp32 sums, and 1e-5 of it
+    # is the reference arithmetic's own noise -- DESIGN.md section 2; that regime is tests/test_gpu_sweep300.py's, with its arbiter)
+    c, g = fe.eval(0.5 * dev[0])
+    c_ref, g_ref = ref.eval(0.5 * dev[0])
     assert abs(c - c_ref) < 1e-5 * abs(c_ref) and np.abs(g - g_ref).max() < 1e-5 * np.abs(g_ref).max()
     again = fe.setupProblemAndOptimize(dev[0])
     assert again[1]["final_cost"] <= dev[1]["final_cost"] + 1e-6 * abs(dev[1]["final_cost"])   # (costs are -contrast: a warm restart does not climb)

@@ -65,8 +65,9 @@ def test_group_of_two_on_one_gpu_config4_slab(hip):
     assert s["exchange_misses"] >= 1 and s["sharded_host_syncs"] == 0 and 0 < s["exchange_tiles"] < 1024 // 4, s
     assert s["comm_bytes"] < 2 * (1 << 20), s            # a set of tiles + the gradient rows, not 2 x 4 MB of planes
     # the planes a member holds after the exchange are the window's (what updateIG / publishEventImage read)
-    assert rel_img(grp.get_plane(_lib.PLANE_IL_OLD), one.get_plane(_lib.PLANE_IL_OLD)) < 1e-6
-    assert rel_img(grp.get_plane(_lib.PLANE_IWE), one.get_plane(_lib.PLANE_IWE)) < 1e-6
+    # (fp32 sums in another order: two members' partial sums added, against one context's chunks)
+    assert rel_img(grp.get_plane(_lib.PLANE_IL_OLD), one.get_plane(_lib.PLANE_IL_OLD)) < RTOL
+    assert rel_img(grp.get_plane(_lib.PLANE_IWE), one.get_plane(_lib.PLANE_IWE)) < RTOL
     assert 0 < grp.group_info()["last_fanout_us"] < 5e5
     grp.close()
     one.close()
@@ -91,7 +92,7 @@ def test_group_of_two_on_one_gpu_config5_slab_with_a_map(hip):
         ev.eval(np.zeros(w.P), False)
         ev.setUpdateTimesIG(w.knots_init[0], 3)
         ev.updateIG(5)
-    assert rel_img(grp.getIG(), one.getIG()) < 1e-6
+    assert rel_img(grp.getIG(), one.getIG()) < RTOL
     for ev in (grp, one):
         _set(ev, w, "resident", n=1_000_000)
     _same(grp, one, [(np.zeros(w.P), True), (rng.normal(0, 0.003, w.P), True)])
@@ -105,7 +106,7 @@ def test_group_vs_oracle_ragged_shards_and_empty_members(hip, oracle, members, n
     """Against the oracle directly, at sizes it finishes in seconds: a window whose last batch is the single trailing event the
     reference's loop never opens a batch for (event_pano_warper.cpp:188-196), members that hold NO events (150 events = 2
     batches for 4 members), batch size 1 (every member's last event would be dropped by a naive split), a one-event window."""
-    w = synth.backend_window(n_events, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.3, seed=71 + members)
+    w = synth.backend_window(n_events, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.25, seed=71 + members)
     w.batch = batch
     grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0] * members)
     grp.set_fast_path()
@@ -166,7 +167,7 @@ def test_group_solve_is_one_optimiser(hip):
 def test_group_errors_do_not_hang(hip):
     """A window one member rejects (an event outside the sensor in the SECOND member's shard) fails the call with that member's
     message and leaves the group without a window; bad arguments fail like on a plain context; the handle stays usable."""
-    w = synth.backend_window(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.3, seed=91)
+    w = synth.backend_window(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.25, seed=91)
     grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0])
     grp.set_fast_path()
     x_bad = w.x.copy()
@@ -175,6 +176,7 @@ def test_group_errors_do_not_hang(hip):
         grp.set_window(x_bad, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
                        w.sample_rate, w.sigma, _lib.VARIANCE, None)
     assert e.value.status == _lib.ERR_EVENT_RANGE and "member 1" in str(e.value)
+    grp.K, grp.num_fixed = w.K, w.num_fixed      # (the python mirror records them after a successful hand-over only)
     with pytest.raises(hip.CmaxHipError) as e:
         grp.eval(np.zeros(w.P))
     assert e.value.status == _lib.ERR_STATE
