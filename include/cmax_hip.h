@@ -124,12 +124,15 @@ int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
 /* Two paths on one GPU.  The reference runs the front end (a packet every 10 ms, src/node.cpp:22) beside the back-end thread's
  * window solves (src/cmax_slam.cpp:92); on one GPU the two contexts' kernels share the compute units.  Both calls replace the
  * context's OWN stream (they wait for its queued work first; not with cmx_set_stream's caller-owned stream):
- *   cmx_set_stream_priority  level > 0: the device's highest stream priority (the front end: its short kernels are dispatched
- *                            ahead of the back end's queued workgroups), 0: normal, < 0: lowest;
+ *   cmx_set_stream_priority  level > 0: the device's highest stream priority, 0: normal, < 0: lowest;
  *   cmx_set_cu_mask          the stream's kernels run on the compute units whose bit is set (hipExtStreamCreateWithCUMask;
- *                            n_words x 32 bits; on MI355X bit i = compute unit i / 8 of XCD i % 8, so the first k bits spread
- *                            over all eight XCDs); n_words == 0: all compute units, normal priority.
- * Results never depend on either. */
+ *                            n_words x 32 bits; which physical unit a bit selects is the driver's mapping); n_words == 0: all
+ *                            compute units, normal priority.
+ * Measured on MI355X (profiles/r04_fe_beside_be.txt): with both contexts evaluating back to back the default -- dynamic sharing --
+ * costs the front end x1.9 and the back end x1.23; priorities change nothing (the back end's launches are one resident round of
+ * workgroups that fill the register files; a queue's priority does not pre-empt them); disjoint masks isolate the two (beside =
+ * solo x1.04-1.09) at the price of a static split -- e.g. front end 51.8 us (x1.34) / back end x1.82 with half of every XCD each.
+ * Results never depend on either call. */
 int cmx_set_stream_priority(cmx_ctx *ctx, int level);
 int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
 
