@@ -391,32 +391,43 @@ def prior_map_config5(ctx):
     return t.cpu().numpy().reshape(Hp, Wp)
 
 
-def backend_workload(args, ctx, which, per_gpu, steps):
-    """which = 'config3' (single window, N=1), 'config4' (time slab per rank), 'config5' (time slab per rank)."""
+def backend_workload(args, ctx, which, per_gpu, steps, group_devices=None):
+    """which = 'config3' (single window, N=1), 'config4' (time slab per rank), 'config5' (time slab per rank).
+    group_devices = [d0, d1, ...]: ONE process, the whole window (all slabs) handed to a group handle (--single-process)."""
     from cmax_slam_amd import _lib, evaluator, solver, synth
     rank, world, dev = ctx["rank"], ctx["world"], ctx["local_rank"]
     IG = None
+    n_members = len(group_devices) if group_devices else 1
     if which == "config3":
         w = synth.config3(per_gpu)
     elif which == "config4":
-        w = synth.config4_slab(rank, world, per_gpu)
+        w = (synth.concat_slabs([synth.config4_slab(r, n_members, per_gpu) for r in range(n_members)]) if group_devices
+             else synth.config4_slab(rank, world, per_gpu))
     else:
-        w = synth.config5_slab(rank, world, per_gpu)
+        w = (synth.concat_slabs([synth.config5_slab(r, n_members, per_gpu) for r in range(n_members)]) if group_devices
+             else synth.config5_slab(rank, world, per_gpu))
         IG = prior_map_config5(ctx)
     w.IG = IG
-    ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=dev)
+    ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=dev, devices=group_devices)
     ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
                   w.sample_rate, w.sigma, _lib.VARIANCE, IG)
     adjoint = args.mode == "fast"
     (ev.set_fast_path if adjoint else ev.set_reference_path)()
-    run = Runner(ev, world, args.comm, ctx["device"], ctx["torch"], ctx["dist"], force=ctx["sharded"])
+    run = Runner(ev, world, args.comm, ctx["device"], ctx["torch"], ctx["dist"], force=ctx["sharded"] and not group_devices)
+    if group_devices:
+        run.ev_sharded = True            # (no eval_many on a group; its exchange lives inside the handle)
+        run.comm_used = "one process, %d member contexts behind one handle (cmx_backend_create_group), %s" % (
+            n_members, {1: "RCCL via ncclCommInitAll", 2: "direct peer-to-peer kernels"}.get(ev.group_info()["transport"], "plain context"))
     if not ctx["sharded"]:
         points = record_trajectory(ev, np.zeros(w.P), "backend", solver.BACKEND)
     else:  # every rank must evaluate the same points: a seeded walk of the size of a solve's steps
         rng = np.random.default_rng(77)
         points = [np.zeros(w.P)] + [rng.normal(0, 0.004, w.P) * s for s in (0.3, 0.6, 0.9, 1.0)]
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
-    ev.accumulate(points[-1], False)
+    if group_devices and n_members > 1:
+        ev.eval(points[-1], False)   # (a group has no split-phase interface; member 0 holds the exchanged planes)
+    else:
+        ev.accumulate(points[-1], False)
     il_old, il_new = ev.get_plane(_lib.PLANE_IL_OLD), ev.get_plane(_lib.PLANE_IL_NEW)
     run.nnz_pixels = int(np.count_nonzero(il_old) + np.count_nonzero(il_new))
     # the image passes skip 64x16 tiles with nothing (votes or global map) within the filter's reach: count what is left
@@ -430,9 +441,9 @@ def backend_workload(args, ctx, which, per_gpu, steps):
         for dx in (-1, 0, 1):
             grown |= np.roll(np.roll(tiles, dy, 0), dx, 1)
     run.image_pixels = int(min(grown.sum() * 1024, Wp * Hp))
-    n_local = len(w.x)
+    n_local = len(w.x) // n_members
     nb = (n_local - 1 + w.batch - 1) // w.batch
-    m = measure(run, points, steps, args.warmup, "backend", w.order, n_local, n_local * world, w.Wp * w.Hp, nb, w.P, adjoint,
+    m = measure(run, points, steps, args.warmup, "backend", w.order, n_local, n_local * world * n_members, w.Wp * w.Hp, nb, w.P, adjoint,
                 ("backend_%s" % args.mode) if (which == "config3" and per_gpu == 5_000_000) else "none")
     desc = {"config3": "BASELINE config 3: back-end BA fdf, %d synthetic events, cubic 10-knot SO(3) spline (P=21), 1024x1024 pano",
             "config4": "BASELINE config 4: back-end BA sliding window fdf, %d synthetic events/GPU (time slab per rank), cubic 10-knot "
@@ -660,6 +671,251 @@ def per_packet_pipeline(device, which, n_packets=8):
             "note": "solves start at omega = 0 like `cmax`; solve_ms = the solve on a resident, already-sorted packet"}
 
 
+def per_window_pipeline(device, w, n_windows=4):
+    """The per-window pipeline of the back end (reference: PoseGraphOptimizer's loop, src/backend/pose_graph_optimizer.cpp:131-165,
+    244-323: a NEW window every stride): hand-over, first evaluation (upload + pose table + destination-tile sort + streams),
+    FR-CG solve -- BASELINE config 3's window, from host arrays (cmx_backend_set_window) and cut from the device event store
+    (cmx_backend_set_window_from).  sequential = one context; pipelined = two contexts, a helper host thread hands window k+1
+    over and calls cmx_backend_prepare while window k is solved."""
+    import queue
+    import threading
+    from cmax_slam_amd import _lib, evaluator
+    out = {}
+    args_w = (w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch, w.sample_rate, w.sigma, _lib.VARIANCE)
+    store = evaluator.EventStore(w.W, w.H, len(w.x) + 1024, device=device)
+    store.push(w.x, w.y, w.t_ns)
+    for source in ("host_arrays", "device_store"):
+        def hand_over(ev):
+            if source == "host_arrays":
+                ev.set_window(w.x, w.y, w.t_ns, *args_w)
+            else:
+                ev.set_window_from(store, 0, len(w.x), *args_w)
+        evs = [evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device) for _ in range(2)]
+        x0 = np.zeros(w.P)
+        for rep in range(2):  # (first pass untimed: allocations)
+            t_set = t_first = t_fresh = t_res = 0.0
+            iters = 0
+            for _ in range(n_windows):
+                t0 = time.perf_counter()
+                hand_over(evs[0])
+                t1 = time.perf_counter()
+                evs[0].eval(x0, True)
+                t2 = time.perf_counter()
+                hand_over(evs[0])
+                t3 = time.perf_counter()
+                _, r = evs[0].setupProblemAndOptimize()
+                t4 = time.perf_counter()
+                evs[0].setupProblemAndOptimize()
+                t5 = time.perf_counter()
+                t_set += t1 - t0
+                t_first += t2 - t1
+                t_fresh += t4 - t3
+                t_res += t5 - t4
+                iters += r["iterations"]
+        n = n_windows
+        set_ms, first_ms, fresh_ms, solve_ms = (t * 1e3 / n for t in (t_set, t_first, t_fresh, t_res))
+        seq_ms = set_ms + fresh_ms
+        jobs = queue.Queue()
+
+        def helper():
+            while True:
+                job = jobs.get()
+                if job is None:
+                    return
+                ev, done = job
+                hand_over(ev)
+                ev.prepare(None)
+                done.set()
+        th = threading.Thread(target=helper, daemon=True)
+        th.start()
+        best = None
+        for rep in range(3):
+            d0 = threading.Event()
+            jobs.put((evs[0], d0))
+            d0.wait()
+            t0 = time.perf_counter()
+            for k in range(n):
+                pend = None
+                if k + 1 < n:
+                    pend = threading.Event()
+                    jobs.put((evs[(k + 1) % 2], pend))
+                evs[k % 2].setupProblemAndOptimize()
+                if pend is not None:
+                    pend.wait()
+            el = (time.perf_counter() - t0) * 1e3 / n
+            best = el if best is None else min(best, el)
+        jobs.put(None)
+        th.join()
+        for e in evs:
+            e.close()
+        out[source] = {"set_window_ms": set_ms, "first_eval_ms": first_ms, "solve_ms": solve_ms, "solve_incl_first_sort_ms": fresh_ms,
+                       "iters_per_solve": iters / n,
+                       "sequential": {"ms_per_window": seq_ms, "ratio_to_solve": seq_ms / solve_ms},
+                       "pipelined": {"ms_per_window": best, "ratio_to_solve": best / solve_ms}}
+    store.close()
+    out["window"] = "%d events, %dx%d pano, order %d, K %d" % (len(w.x), w.Wp, w.Hp, w.order, w.K)
+    out["windows"] = n_windows
+    out["note"] = ("solve_ms = the solve on a resident, already-sorted window; pipelined = two contexts, a helper host thread runs "
+                   "set_window[_from] + cmx_backend_prepare of window k+1 beside the solve of window k")
+    return out
+
+
+def launch_default_shapes(device, solves=5, steps=200):
+    """The reference's own back-end operating points (launch/ijrr.launch:27-33, launch/ecrot_handheld.launch:28-34): LINEAR
+    spline, dt_knots 0.05 s, window 0.2 s -> K = 5 control poses, P = 15 (first window: no fixed pose) or 12 (one fixed), batches
+    of 100, sigma 1; 1024x512 (DAVIS 240x180) or 4096x2048 (1280x720) panorama; 200k and 1M events per window.  Every shape has
+    a full-size parity test (tests/test_gpu_launch_defaults.py)."""
+    from cmax_slam_amd import _lib, evaluator, synth
+    rows = []
+    for name, (W, H, f, Wp, Hp, stride) in (("ijrr", (240, 180, 200.0, 1024, 512, 0.1)),
+                                            ("ecrot_handheld", (1280, 720, 1000.0, 4096, 2048, 0.2))):
+        for n_ev in (200_000, 1_000_000):
+            for nf in (1, 0):
+                w = synth.backend_window(n_ev, W, H, f, f, (W - 1) / 2.0, (H - 1) / 2.0, Wp, Hp, 2, 5, nf, 0.2, dt_knots=0.05,
+                                         seed=synth.SEED0 + 40 + nf, win_stride=stride)
+                ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device)
+                ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
+                              w.batch, w.sample_rate, w.sigma, _lib.VARIANCE)
+                rng = np.random.default_rng(5)
+                pts = np.vstack([rng.normal(0, 0.003, w.P) * s for s in (0.0, 0.3, 0.6, 1.0)] * (steps // 4))
+                ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+                ev.eval_each(pts[:40], True)
+                t0 = time.perf_counter()
+                ev.eval_each(pts, True)
+                fdf_ms = (time.perf_counter() - t0) * 1e3 / len(pts)
+                t0 = time.perf_counter()
+                ev.eval_each(pts, False)
+                f_ms = (time.perf_counter() - t0) * 1e3 / len(pts)
+                ev.set_option(_lib.OPT_REUSE_IMAGE, 1)
+                ev.setupProblemAndOptimize()
+                it = evs = 0
+                t0 = time.perf_counter()
+                for _ in range(solves):
+                    _, r = ev.setupProblemAndOptimize()
+                    it += r["iterations"]
+                    evs += r["n_f"] + r["n_df"]
+                el = time.perf_counter() - t0
+                ev.close()
+                rows.append({"launch": name, "events": n_ev, "pano": "%dx%d" % (Wp, Hp), "P": w.P, "fdf_ms": fdf_ms,
+                             "cost_only_ms": f_ms, "events_per_s": n_ev / fdf_ms * 1e3, "solve_ms": el / solves * 1e3,
+                             "iters_per_s": it / el, "iters_per_solve": it / solves, "evals_per_solve": evs / solves})
+    return {"shapes": rows, "spline": "linear (So3Spline<2>), K = 5, dt_knots 0.05 s, window 0.2 s, batch 100, sigma 1, variance",
+            "note": "solves start at zero increments on the perturbed knots like `cmax`; fdf = cmx_backend_eval_each over 4 points"}
+
+
+def frontend_beside_backend(device, p, w, seconds=0.35):
+    """The reference's two threads on one GPU (src/node.cpp:22 + src/cmax_slam.cpp:92): a front-end context and a back-end
+    context, own host thread + stream each.  `back_to_back`: both evaluate fdf in a loop (front end at 100 % duty, the worst
+    case).  `at_100hz`: the front end solves one packet every 10 ms -- the reference's rate -- beside a back-end solve loop.
+    Stream priorities and CU masks were swept (profiles/r04_fe_beside_be.txt): isolation is available through
+    cmx_set_cu_mask at the price of a static split; the default measured here is dynamic sharing."""
+    import threading
+    from cmax_slam_amd import _lib, evaluator
+    fe = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=device)
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    be = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device)
+    be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE)
+    xf, xb = np.array([0.3, -0.5, 0.2]), np.zeros(w.P)
+
+    def loops(run_fe, run_be, fe_fn, be_fn, secs):
+        cnt, lat = [0, 0], [[], []]
+        stop = [0.0]
+        go = threading.Barrier(int(run_fe) + int(run_be) + 1, timeout=60)
+
+        def work(k, fn):
+            go.wait()
+            n = 0
+            while time.perf_counter() < stop[0]:
+                t0 = time.perf_counter()
+                fn()
+                lat[k].append(time.perf_counter() - t0)
+                n += 1
+            cnt[k] = n
+        th = ([threading.Thread(target=work, args=(0, fe_fn))] if run_fe else []) + \
+             ([threading.Thread(target=work, args=(1, be_fn))] if run_be else [])
+        for t in th:
+            t.start()
+        stop[0] = time.perf_counter() + secs + 0.02
+        go.wait()
+        for t in th:
+            t.join()
+        return [float(np.mean(v)) * 1e3 if v else None for v in lat]
+    res = {}
+    # ---- back to back
+    for ev, x in ((fe, xf), (be, xb)):
+        ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+        for _ in range(10):
+            ev.eval(x, True)
+    f_solo = loops(True, False, lambda: fe.eval(xf, True), None, seconds / 2)[0]
+    b_solo = loops(False, True, None, lambda: be.eval(xb, True), seconds / 2)[1]
+    f_bes, b_bes = loops(True, True, lambda: fe.eval(xf, True), lambda: be.eval(xb, True), seconds)
+    res["back_to_back"] = {"frontend_fdf_ms": {"solo": f_solo, "beside": f_bes, "ratio": f_bes / f_solo},
+                           "backend_fdf_ms": {"solo": b_solo, "beside": b_bes, "ratio": b_bes / b_solo}}
+    # ---- the reference's rate: one front-end solve per 10 ms
+    for ev in (fe, be):
+        ev.set_option(_lib.OPT_REUSE_IMAGE, 1)
+    fe.setupProblemAndOptimize(np.zeros(3))
+    be.setupProblemAndOptimize()
+
+    def fe_tick():
+        t0 = time.perf_counter()
+        fe.setupProblemAndOptimize(np.zeros(3))
+        fe_tick.lat.append(time.perf_counter() - t0)
+        dt = 0.010 - (time.perf_counter() - t0)
+        if dt > 0:
+            time.sleep(dt)
+    fe_tick.lat = []
+    loops(True, False, fe_tick, None, 0.25)
+    s_solo = float(np.mean(fe_tick.lat)) * 1e3
+    bs_solo = loops(False, True, None, lambda: be.setupProblemAndOptimize(), 0.25)[1]
+    fe_tick.lat = []
+    _, bs_bes = loops(True, True, fe_tick, lambda: be.setupProblemAndOptimize(), 0.5)
+    s_bes = float(np.mean(fe_tick.lat)) * 1e3
+    res["at_100hz"] = {"frontend_solve_ms": {"solo": s_solo, "beside": s_bes, "ratio": s_bes / s_solo, "solves": len(fe_tick.lat)},
+                       "backend_solve_ms": {"solo": bs_solo, "beside": bs_bes, "ratio": bs_bes / bs_solo},
+                       "note": "front end: one 1M-event FR-CG solve started every 10 ms (a packet per dt_ang_vel); back end: config-3 "
+                               "solves in a loop"}
+    res["settings"] = "default streams (no priority, no CU mask): see profiles/r04_fe_beside_be.txt for the sweep"
+    fe.close()
+    be.close()
+    return res
+
+
+def group_on_one_device(device, w, steps=200):
+    """One-process multi-GPU group (cmx_backend_create_group) exercised on the ONE device this box has: two members sharing the
+    GPU, direct transport, against the single context on the same window -- what the group machinery (fan-out to the worker
+    thread, pack / unpack of the exchange set, two in-process all-reduces) costs when the collective moves nothing over a link."""
+    from cmax_slam_amd import _lib, evaluator
+    rng = np.random.default_rng(77)
+    pts = np.vstack([rng.normal(0, 0.004, w.P) * s for s in (0.0, 0.3, 0.6, 0.9)] * (steps // 4))
+    res = {}
+    for name, devs in (("single_context", None), ("group_of_2_on_one_device", [device, device])):
+        ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device, devices=devs)
+        ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                      w.sample_rate, w.sigma, _lib.VARIANCE)
+        ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+        cs, gs = ev.eval_each(pts[:40], True)
+        t0 = time.perf_counter()
+        cs, gs = ev.eval_each(pts, True)
+        ms = (time.perf_counter() - t0) * 1e3 / len(pts)
+        res[name] = {"fdf_ms": ms, "events_per_s": len(w.x) / ms * 1e3, "contrast": float(cs[-1])}
+        if devs:
+            st, info = ev.stats(), ev.group_info()
+            res[name].update({"comm_bytes_last_evaluation": st["comm_bytes"], "exchange_set_tiles": st["exchange_tiles"],
+                              "events_per_member": info["events_per_member"], "transport": "direct (peer kernels + HIP events)",
+                              "grad_rel_vs_single": float(np.abs(gs[-1] - res["_g"]).max() / np.abs(res["_g"]).max()),
+                              "contrast_rel_vs_single": abs(float(cs[-1]) - res["single_context"]["contrast"]) / abs(res["single_context"]["contrast"])})
+        else:
+            res["_g"] = gs[-1].copy()
+        ev.close()
+    res.pop("_g")
+    res["overhead_ms"] = res["group_of_2_on_one_device"]["fdf_ms"] - res["single_context"]["fdf_ms"]
+    res["note"] = ("two members on ONE GPU serialise on its compute units: the difference to the single context is the group's machinery "
+                   "(collective kernels, event waits, fan-out), not a speed-up; a group of one is a plain context (no overhead)")
+    return res
+
+
 def host_cpu():
     try:
         for line in open("/proc/cpuinfo"):
@@ -740,6 +996,43 @@ def cpu_baseline(kind, obj, x0, seconds):
     return out
 
 
+def synth_config4_slab():
+    from cmax_slam_amd import synth
+    return synth.config4_slab(2, 8, 5_000_000)
+
+
+def summary_of(out):
+    """Compact headline figures, emitted as the LAST key of the line (the driver's stdout tail cut the front)."""
+    def g(d, *ks):
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    s = {"fdf_ms": out.get("ms_per_step"), "events_per_s": out.get("value"), "n_gpus": out.get("n_gpus"),
+         "roofline_frac": g(out, "roofline", "frac"), "roofline_kernel": g(out, "roofline", "kernel"),
+         "whole_evaluation_frac": g(out, "whole_evaluation", "frac"), "cmax_iters_per_s": g(out, "cmax", "iters_per_s"),
+         "cpu_baseline_events_per_s": g(out, "cpu_baseline", "value")}
+    if "backend" in out:
+        b = out["backend"]
+        s["backend"] = {"fdf_ms": b.get("ms_per_step"), "events_per_s": b.get("value"), "roofline_frac": g(b, "roofline", "frac"),
+                        "roofline_kernel": g(b, "roofline", "kernel"), "roofline_bound": g(b, "roofline", "bound"),
+                        "whole_evaluation_frac": g(b, "whole_evaluation", "frac"),
+                        "cmax_iters_per_s": g(b, "cmax", "iters_per_s"),
+                        "per_window_ratio_to_solve_store_pipelined": g(b, "per_window", "device_store", "pipelined", "ratio_to_solve"),
+                        "per_window_ratio_to_solve_host_pipelined": g(b, "per_window", "host_arrays", "pipelined", "ratio_to_solve")}
+    if "frontend_beside_backend" in out:
+        s["frontend_beside_backend"] = {"fe_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "frontend_fdf_ms", "ratio"),
+                                        "be_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "backend_fdf_ms", "ratio"),
+                                        "fe_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "frontend_solve_ms", "ratio"),
+                                        "be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "backend_solve_ms", "ratio")}
+    if "group" in out and isinstance(out["group"], dict):
+        s["group_overhead_ms_2_members_one_device"] = out["group"].get("overhead_ms")
+    if "parity_vs_1gpu" in out:
+        s["parity_vs_1gpu"] = out["parity_vs_1gpu"]
+    return s
+
+
 def line(m, world, args, name, n_total, img, comm_used, mode_desc):
     out = {
         "metric": METRIC, "value": m["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -779,6 +1072,13 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="N>1: skip the nested config-5 leg")
     ap.add_argument("--no-parity", action="store_true", help="N>1: skip the parity check against one GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N in ONE process: a group handle (cmx_backend_create_group) over devices 0..N-1, one host thread, one "
+                         "optimiser -- the form the reference's single-process host can use; launch WITHOUT torch.distributed.run")
+    ap.add_argument("--group-devices", default=None,
+                    help="--single-process with an explicit member list, e.g. 0,0 = two members sharing device 0 (how a one-GPU box "
+                         "exercises the group path end to end)")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip per_window / launch_defaults / frontend_beside_backend / group")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dry run of the N>1 code path (time slabs, communicator, parity gather) with whatever world size is launched")
     args = ap.parse_args()
@@ -788,7 +1088,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    group_devices = None
+    if args.single_process or args.group_devices:
+        if world != 1:
+            sys.exit("bench.py --single-process runs in ONE process: launch it without torch.distributed.run")
+        group_devices = [int(d) for d in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
+        args.gpus = len(set(group_devices))
+    elif world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
@@ -799,8 +1105,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.force_sharded
-    if sharded:
+    sharded = world > 1 or args.force_sharded or (group_devices is not None and len(group_devices) > 1)
+    if sharded and group_devices is None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -844,27 +1150,57 @@ def main():
                 be["cpu_baseline"] = cpu_baseline("backend", w, pts_b[len(pts_b) // 2], max(3.0, args.cpu_seconds / 3))
             out["backend"] = be
             ev.close()
+            if not args.no_extras:
+                for key, fn in (("per_window", lambda: per_window_pipeline(local_rank, w)),
+                                ("launch_defaults", lambda: launch_default_shapes(local_rank))):
+                    try:
+                        be[key] = fn()
+                    except Exception as e:  # must not cost the headline line
+                        be[key] = {"error": repr(e)}
+                for key, fn in (("frontend_beside_backend", lambda: frontend_beside_backend(local_rank, p, w)),
+                                ("group", lambda: group_on_one_device(local_rank, synth_config4_slab()))):
+                    try:
+                        out[key] = fn()
+                    except Exception as e:
+                        out[key] = {"error": repr(e)}
     else:
         which = "config4" if sharded else "config3"
         per_gpu = args.events or 5_000_000
-        ev, run, w, m, name, img, pts = backend_workload(args, ctx, which, per_gpu, args.steps)
+        ev, run, w, m, name, img, pts = backend_workload(args, ctx, which, per_gpu, args.steps, group_devices)
         c, g = m.pop("_last")
         par = None
-        if sharded and not args.no_parity:
+        if group_devices and not args.no_parity:  # the whole window on ONE context of this process: what the group must equal
+            try:
+                from cmax_slam_amd import evaluator as _e
+                one = _e.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=0)
+                one.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                               w.sample_rate, w.sigma, _lib.VARIANCE, w.IG)
+                one.eval(pts[0], False)
+                c1, g1 = one.eval(pts[(args.steps - 1) % len(pts)], True)
+                one.close()
+                par = {"contrast_rel": abs(c - c1) / abs(c1), "grad_rel_inf": float(np.abs(np.asarray(g) - g1).max() / np.abs(g1).max()),
+                       "tolerance": 1e-5, "events_total": int(len(w.x))}
+            except Exception as e:
+                par = {"error": str(e)}
+        elif sharded and not args.no_parity:
             try:
                 par = parity_vs_one_gpu(ctx, "backend", w, pts[0], pts[(args.steps - 1) % len(pts)], c, g, args)
             except Exception as e:
                 par = {"error": str(e)}
         if rank == 0:
-            out = line(m, world, args, name, len(w.x) * world, img, run.comm_used, mode_desc)
+            out = line(m, len(set(group_devices)) if group_devices else world, args, name, len(w.x) * world, img, run.comm_used, mode_desc)
             if par is not None:
                 out["parity_vs_1gpu"] = par
+            if group_devices:
+                out["group"] = ev.group_info()
+                if args.solves > 0:
+                    out["cmax"] = cmax_solves(max(1, args.solves // 4), ev, "backend", _lib)
             if not sharded and args.solves > 0:
                 out["cmax"] = cmax_solves(args.solves, ev, "backend", _lib)
             if not sharded and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline("backend", w, pts[len(pts) // 2], args.cpu_seconds)
         ev.close()
-        if sharded and not args.no_config5:
+        if sharded and not args.no_config5 and not group_devices:
             try:
                 ev, run, w5, m5, name5, img5, pts5 = backend_workload(args, ctx, "config5", (args.events or 20_000_000 // 8), args.steps)
                 c5, g5 = m5.pop("_last")
@@ -883,10 +1219,11 @@ def main():
             except Exception as e:
                 if rank == 0:
                     out["config5"] = {"error": str(e)}
-    if sharded:
+    if sharded and group_devices is None:
         dist.destroy_process_group()
     if rank == 0:
         out.pop("_last", None)
+        out["summary"] = summary_of(out)  # LAST key: a tail of the line still carries the headline figures
         try:  # whatever native libraries still hold in their C stdio buffers goes where stdout currently points: stderr
             import ctypes
             ctypes.CDLL(None).fflush(None)

@@ -46,6 +46,29 @@ def test_default_line_front_end_with_back_end_nested():
     assert d["cmax"]["iters_per_s"] > 0 and d["pipelined"]["ms_per_evaluation"] > 0 and d["cost_only"]["ms_per_step"] > 0
     b = d["backend"]
     assert "config 3" in b["config"]["workload"] and b["value"] > 0 and b["roofline"]["frac"] <= 1.0 and b["cpu_baseline"]["kind"] == "port"
+    # round 4: the back end's per-window pipeline, the reference's launch-default shapes, the two paths on one GPU, the group
+    for src in ("host_arrays", "device_store"):
+        pw = b["per_window"][src]
+        assert pw["solve_ms"] > 0 and pw["pipelined"]["ms_per_window"] <= pw["sequential"]["ms_per_window"] * 1.05, pw
+    shapes = b["launch_defaults"]["shapes"]
+    assert len(shapes) == 8 and {s["P"] for s in shapes} == {12, 15} and all(s["fdf_ms"] > 0 and s["iters_per_s"] > 0 for s in shapes)
+    fb = d["frontend_beside_backend"]
+    assert fb["back_to_back"]["frontend_fdf_ms"]["ratio"] > 0.9 and fb["at_100hz"]["backend_solve_ms"]["ratio"] > 0.9
+    gr = d["group"]
+    assert gr["group_of_2_on_one_device"]["grad_rel_vs_single"] < 1e-5 and gr["group_of_2_on_one_device"]["contrast_rel_vs_single"] < 1e-5
+    assert list(d)[-1] == "summary" and d["summary"]["fdf_ms"] == d["ms_per_step"] and d["summary"]["backend"]["cmax_iters_per_s"] > 0
+
+
+def test_single_process_group_line():
+    """--group-devices 0,0: the one-process multi-GPU form end to end (two members sharing this box's GPU): config 4 through ONE
+    handle, parity against the single context inside the line."""
+    d = _run("--group-devices", "0,0", "--steps", "20", "--warmup", "3", "--events", "300000", "--no-cpu-baseline", "--solves", "4")
+    _check_line(d, 1, 20, 3)
+    assert "config 4" in d["config"]["workload"] and d["config"]["events_total"] == 600000
+    assert d["group"]["members"] == 2 and d["group"]["events_per_member"] == [300000, 300000]
+    assert d["parity_vs_1gpu"]["grad_rel_inf"] < 1e-5 and d["parity_vs_1gpu"]["contrast_rel"] < 1e-5
+    assert "comm" in d and d["comm"]["collectives_per_step"] >= 2 and d["cmax"]["iters_per_s"] > 0
+    assert list(d)[-1] == "summary"
 
 
 def test_sharded_code_path_as_a_one_rank_dry_run():
