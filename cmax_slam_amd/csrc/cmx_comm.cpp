@@ -150,7 +150,11 @@ static int finish_exchanged(cmx_ctx *c, int kind, double *contrast, double *grad
   // collective is latency-bound either way) whenever run_adjoint can use them; otherwise as the 2P-double buffer
   c->shard_acc = true;
   int rc = finish_begin(c, kind, grad != nullptr);
-  if (!rc && c->pending_P > 0) {
+  // a GROUP's members skip this collective: the gradient is linear in the rows ((2/N)(S1 - mu S2), mu from the all-reduced
+  // planes: the same on every member), so each member finalizes its own rows and the group's one host thread adds the members'
+  // gradients in member order (cmx_group.cpp: group_eval) -- one collective per evaluation instead of two
+  c->group_partial_grad = c->group != nullptr && c->pending_P > 0;  // (derivative planes: all-reduced with the IWE -- every member's gradient is the whole one)
+  if (!rc && c->pending_P > 0 && !c->group) {
     const bool rows = !c->deterministic && c->d_gacc && 2 * c->pending_P <= kGaccStride;  // (run_adjoint's condition: rank-invariant)
     rc = rows ? comm_allreduce(c, c->d_gacc, (size_t)kTailShards * kGaccStride, CMX_DT_F64)
               : comm_allreduce(c, c->d_gsum, (size_t)2 * c->pending_P, CMX_DT_F64);  // adjoint mode: S1,S2 partial sums

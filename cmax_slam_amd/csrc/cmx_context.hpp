@@ -42,6 +42,7 @@ struct cmx_ctx {
   int kind = 0, device = 0;
   cmx_group *group = nullptr;  // set on every member of a group; the member with group_rank 0 is the handle the caller holds
   int group_rank = 0;
+  bool group_partial_grad = false;  // the last evaluation's gradient covers this member's events only (cmx_comm.cpp: finish_exchanged)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;

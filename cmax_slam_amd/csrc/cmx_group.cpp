@@ -5,9 +5,9 @@
 // form that drops into it: cmx_backend_create_group() returns an ordinary cmx_ctx handle; the unchanged global_contrast_fdf
 // body calls cmx_backend_eval(handle, ...) and the evaluation fans out to the N member contexts -- member r holds the
 // contiguous range of whole event batches dist.batch_range gives rank r (event_pano_warper.cpp:188-196 is the loop being
-// sharded), the members exchange their partial planes after the splat and their gradient rows after the gather exactly as
-// the one-process-per-GPU form does (cmx_comm.cpp: same collectives, same exchange set), and ONE contrast / gradient comes
-// back.  No replicated optimisers, no launcher.
+// sharded), the members exchange their partial planes after the splat exactly as the one-process-per-GPU form does (cmx_comm.cpp:
+// same collective, same exchange set); the gradient rows need no collective here -- the gradient is linear in them, every member
+// finalizes its own and the calling thread adds the members' gradients -- and ONE contrast / gradient comes back.  No replicated optimisers, no launcher.
 //
 // How the fan-out runs.  Queueing one member's evaluation is ~10 launches + 2 collectives of host work (~40-60 us with RCCL's
 // enqueue path); eight members queued by one thread would take longer than the ~150 us the evaluation runs for.  So every
@@ -391,15 +391,22 @@ int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *g
   const int rc = group_all(leader, [&](cmx_ctx *m, int r) { return be_eval_one(m, drotv, &g->out_c[r], grad ? g->out_g[r].data() : nullptr); });
   if (rc) return rc;
   g->evals++;
-  // every member finished on the same all-reduced planes and rows: the numbers are the same bits (cmx_comm.cpp) -- a difference
-  // means the members' states diverged and nothing they report can be trusted
+  // every member finished on the same all-reduced planes: the contrast is the same bits everywhere (cmx_comm.cpp) -- a difference
+  // means the members' states diverged and nothing they report can be trusted.  The gradient rows were NOT exchanged
+  // (finish_exchanged): member r reports (2/N)(S1_r - mu S2_r) over its own events, and the whole gradient is their sum, added
+  // here in member order (the same bits in every run that splits the window the same way).
   for (int r = 1; r < g->n; r++) {
-    if (memcmp(&g->out_c[r], &g->out_c[0], sizeof(double)) != 0 ||
-        (grad && P > 0 && memcmp(g->out_g[r].data(), g->out_g[0].data(), sizeof(double) * (size_t)P) != 0))
+    if (memcmp(&g->out_c[r], &g->out_c[0], sizeof(double)) != 0)
       return fail(leader, CMX_ERR_STATE, "group members disagree (member %d: contrast %.17g vs %.17g)", r, g->out_c[r], g->out_c[0]);
   }
   if (contrast) *contrast = g->out_c[0];
-  if (grad) for (int k = 0; k < P; k++) grad[k] = g->out_g[0][k];
+  const bool partial = g->m[0]->group_partial_grad;  // (rank-invariant: a function of the options)
+  if (grad)
+    for (int k = 0; k < P; k++) {
+      double s = g->out_g[0][k];
+      for (int r = 1; r < g->n && partial; r++) s += g->out_g[r][k];
+      grad[k] = s;
+    }
   return CMX_OK;
 }
 

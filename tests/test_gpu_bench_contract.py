@@ -67,7 +67,7 @@ def test_single_process_group_line():
     assert "config 4" in d["config"]["workload"] and d["config"]["events_total"] == 600000
     assert d["group"]["members"] == 2 and d["group"]["events_per_member"] == [300000, 300000]
     assert d["parity_vs_1gpu"]["grad_rel_inf"] < 1e-5 and d["parity_vs_1gpu"]["contrast_rel"] < 1e-5
-    assert "comm" in d and d["comm"]["collectives_per_step"] >= 2 and d["cmax"]["iters_per_s"] > 0
+    assert "comm" in d and d["comm"]["collectives_per_step"] >= 1 and d["cmax"]["iters_per_s"] > 0
     assert list(d)[-1] == "summary"
 
 

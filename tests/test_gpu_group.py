@@ -3,7 +3,8 @@
 The reference's host is one process / one back-end thread / one GSL instance (src/cmax_slam.cpp:92,
 src/backend/global_optim_contrast_gsl.cpp:23-33).  A group is driven exactly like a single context: ONE thread calls
 set_window / eval / setupProblemAndOptimize on ONE handle; the library shards the window by whole batches, fans the
-evaluation out, exchanges the partial planes and gradient rows between the members and returns one contrast / gradient.
+evaluation out, exchanges the partial planes between the members, adds the members' gradients (linear in their rows: no second
+collective) and returns one contrast / gradient.
 
 A one-GPU box runs the members on the SAME device (the direct transport: peer reduce-scatter + all-gather kernels ordered
 by HIP events); the variants over 2 / 4 / 8 devices (RCCL through ncclCommInitAll, and the direct transport across
