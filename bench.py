@@ -105,6 +105,19 @@ def load_pmc():
     return pmc, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (%s, git %s)" % (pmc.get("_source"), str(stamp.get("git_head"))[:12])
 
 
+# What the counters and the same-box A/B diagnostics say binds the dominant kernels (`bound` stays the roofline `frac` is computed
+# against -- HBM, the only roofline this scatter / gather / stream path has; it is not what the launch waits for at these sizes).
+LIMITED_BY = {
+    ("frontend", "gather"): "launch + tail latency: dispatching ~1000 workgroups 4.1 us + last-arriver finalize 4.7 us of 13.5 us; the event "
+                            "loop (24 MB of streams, warps, Jt cells) runs 6.1 us = 3.9 TB/s (profiles/r04_fe_gather_anatomy.txt)",
+    ("backend", "gather"): "fp64 VALU issue + dependent chains at 3 waves/SIMD (163 VGPRs): 322 VALU instructions/event, VALU pipes 63 % "
+                           "busy, no single part removes more than 10 % (profiles/r03_be_splat_bound.txt sections 1, 5)",
+    ("backend", "splat"): "per-iteration dependent chain (stream loads -> pose gather -> projection -> LDS votes) at 3 waves/SIMD; the 1.5x "
+                          "fabric traffic of the pose gather costs no time (profiles/r04_be_splat_pose_traffic.txt)",
+    ("frontend", "splat"): "launch latency of its shape (profiles/r02_splat_timeline.txt)",
+}
+
+
 # ---------------------------------------------------------------------------------------------- measurement core
 class Runner:
     """One evaluator + its exchange path; knows how to run an fdf / cost-only step at a given parameter vector."""
@@ -314,6 +327,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)), "traffic_note": pmc_note,
                      "model": "hbm-mandatory bytes per launch (coalesced per-event streams + one pass over each plane + one 4-byte "
                               "write per non-zero IWE pixel) / live kernel duration",
+                     "limited_by": LIMITED_BY.get((kind, dom)),
                      "bytes_per_launch": dom_mand, "avg_launch_ms": dms, "events_per_launch": int(n_local),
                      "alg_bytes_per_launch_8d": dom_alg, "ratio_8d_bytes_to_peak": dom_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "ratio_8d_bytes_to_peak uses SURVEY 8(d)'s algorithmic bytes (vote read-modify-writes counted as memory "
@@ -1016,7 +1030,7 @@ def summary_of(out):
     if "backend" in out:
         b = out["backend"]
         s["backend"] = {"fdf_ms": b.get("ms_per_step"), "events_per_s": b.get("value"), "roofline_frac": g(b, "roofline", "frac"),
-                        "roofline_kernel": g(b, "roofline", "kernel"), "roofline_bound": g(b, "roofline", "bound"),
+                        "roofline_kernel": g(b, "roofline", "kernel"), "roofline_bound": g(b, "roofline", "bound"), "roofline_limited_by": (g(b, "roofline", "limited_by") or "")[:60],
                         "whole_evaluation_frac": g(b, "whole_evaluation", "frac"),
                         "cmax_iters_per_s": g(b, "cmax", "iters_per_s"),
                         "per_window_ratio_to_solve_store_pipelined": g(b, "per_window", "device_store", "pipelined", "ratio_to_solve"),
