@@ -7,7 +7,10 @@
 // with gsl_multimin_function_fdf-shaped callbacks (global_contrast_f / _df / _fdf,
 // src/backend/global_optim_contrast_gsl_analytical.cpp:17-81) over cmx_frcg_minimize.  No Python, no torch, no Eigen.
 //
-//   run:  examples/backend_window_host window.bin     (written by tests/test_gpu_cpp_host.py)
+//   run:  examples/backend_window_host window.bin [devices]    (window.bin written by tests/test_gpu_cpp_host.py)
+//
+// devices (optional, e.g. "0,1,2,3" or "0,0"): the same host code on a GROUP handle (cmx_backend_create_group) -- one
+// process, one thread, one optimiser, the window's batches sharded over the listed devices; nothing else in this file changes.
 //
 // window.bin (little endian): int32 W, H, Wp, Hp, order, K, num_fixed, n_av; int64 n, start_ns, dt_ns, t_next_ns,
 //   t_win_beg_ns, t_win_end_ns; double dt_knots; uint16 x[n], y[n]; int64 t_ns[n]; double lut[W*H*3];
@@ -15,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "cmax_hip.h"
@@ -70,7 +74,7 @@ bool read_vec(FILE *fp, std::vector<T> &v, size_t n) {
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s window.bin\n", argv[0]);
+    fprintf(stderr, "usage: %s window.bin [devices, e.g. 0,1]\n", argv[0]);
     return 2;
   }
   FILE *fp = fopen(argv[1], "rb");
@@ -112,7 +116,16 @@ int main(int argc, char **argv) {
   }
 
   // --- the window solve on the device
-  CHECK_RC(cmx_backend_create(&opt.cmx, 0, W, H, lut.data(), Wp, Hp));
+  std::vector<int> devices;
+  if (argc > 2)
+    for (const char *p = argv[2]; *p;) {
+      char *end;
+      devices.push_back((int)strtol(p, &end, 10));
+      p = (*end == ',') ? end + 1 : end;
+      if (end == p && *end) break;
+    }
+  if (devices.size() > 1) CHECK_RC(cmx_backend_create_group(&opt.cmx, devices.data(), (int)devices.size(), W, H, lut.data(), Wp, Hp, CMX_GROUP_AUTO));
+  else CHECK_RC(cmx_backend_create(&opt.cmx, devices.empty() ? 0 : devices[0], W, H, lut.data(), Wp, Hp));
   CHECK_RC(cmx_backend_set_window(opt.cmx, n, x.data(), y.data(), t.data(), order, K, knots.data(), start_ns, dt_ns, num_fixed,
                                   t_next_ns, 100, 1, 1.0, CMX_VARIANCE, CMX_KEEP_MAP));  // the global map stays on the GPU
   std::vector<double> v0((size_t)opt.n_params, 0.0), g0((size_t)opt.n_params), drotv((size_t)opt.n_params, 0.0);

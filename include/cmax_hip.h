@@ -345,8 +345,9 @@ int cmx_comm_attach_custom(cmx_ctx *ctx, cmx_allreduce_fn fn, void *user, int ra
  * src/backend/global_optim_contrast_gsl.cpp:23-33): it cannot be started once per GPU.  cmx_backend_create_group returns an
  * ordinary back-end handle whose evaluations fan out to n_devices member contexts: cmx_backend_set_window shards the window
  * by whole event batches (member r = rank r of the one-process-per-GPU form; event_pano_warper.cpp:188-196 is the loop being
- * split), cmx_backend_eval / cmx_backend_solve run the members' splat, the plane / tile-set exchange, blur, gather and the
- * gradient-row exchange on all devices and return ONE contrast / gradient -- the bodies of global_contrast_{f,df,fdf} do not
+ * split), cmx_backend_eval / cmx_backend_solve run the members' splat, the plane / tile-set exchange, blur and gather on all
+ * devices, add the members' gradients on the calling thread (the gradient is linear in the members' row sums: no second
+ * collective) and return ONE contrast / gradient -- the bodies of global_contrast_{f,df,fdf} do not
  * change, there is one optimiser and no launcher.  The map upkeep calls, cmx_set_option and cmx_destroy act on every member
  * (each keeps its own replica of IG); cmx_backend_get_plane / get_alpha / get_map / cmx_get_stats read member 0.  The caller
  * stays single-threaded; the group owns one worker thread per further member (queueing eight devices' launches from one

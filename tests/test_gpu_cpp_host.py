@@ -46,10 +46,12 @@ def test_cpp_host_matches_oracle(oracle, tmp_path):
     assert abs(float(line[-1]) - rep_ref["final_cost"]) < 1e-3 * abs(rep_ref["final_cost"])
 
 
-def test_cpp_backend_window_host(oracle, tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0"])
+def test_cpp_backend_window_host(oracle, tmp_path, devices):
     """examples/backend_window_host.cpp: one whole back-end window from C++ -- angular-velocity integration and
     control-pose fit (host fp64), window hand-over with the resident map, GSL-shaped callbacks + FR-CG, trajectory
-    update, map upkeep."""
+    update, map upkeep.  devices = "0,0" / "0,0,0": the SAME host code on a group handle (cmx_backend_create_group; two / three
+    members sharing this box's GPU) -- the one-process multi-GPU form the reference's single back-end thread can use."""
     exe = os.path.join(ROOT, "examples", "backend_window_host")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s", "backend_window_host"])
@@ -70,7 +72,7 @@ def test_cpp_backend_window_host(oracle, tmp_path):
         fh.write(np.ascontiguousarray(w.knots_init, "<f8").tobytes())
         fh.write(av_t.astype("<i8").tobytes())
         fh.write(np.ascontiguousarray(av_w, "<f8").tobytes())
-    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(f)] + ([devices] if devices else []), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     vals = {}
     for ln in out.stdout.strip().splitlines():
