@@ -193,7 +193,7 @@ def record_trajectory(ev, x0, kind, params, max_points=8):
 
 def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb, P, adjoint, pmc_prefix):
     """Warm-up, per-kernel calibration (HIP events carried by every kernel class), then the timed region (EXACTLY `steps`
-    fdf evaluations between two fences, dominant kernel timed live on every 4th), then the cost-only loop."""
+    fdf evaluations between two fences, dominant kernel timed live on ~12 of them), then the cost-only loop."""
     ev = run.ev
     npts = len(points)
     # the GPU drops its clocks while the host works (set-up, the recorded solve's python callbacks, the previous workload's
@@ -233,7 +233,12 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     # per step between the evaluations.  (--comm torch keeps the Python loop: its exchange lives in Python.)
     native_loop = run.sh is None
     xs_timed = np.vstack([points[i % npts] for i in range(steps)])
-    ev.timing_enable([dom], every=4)
+    # live duration of the dominant kernel: ~12 samples spread over the timed region (at least every 8th step).  A launch that carries
+    # timing events costs the step 4-8 us (hipExtLaunchKernelGGL's start / stop signals): every 4th step took 0.8-2.2 us off EVERY step
+    # of the headline (tools/fixed_overhead.py: 38.4 us untimed, 39.2-41.5 us at every 4th, K = 1000 ... 20)
+    if native_loop:  # (untimed) the calibration's read-back left the GPU idle for a millisecond or two: a short timed region would
+        ev.eval_each(xs_timed[:16], True)  # otherwise start on a device that has begun to clock down (K = 20: +1.5 us per step)
+    ev.timing_enable([dom], every=max(8, steps // 12))
     run.fence()
     t0 = time.perf_counter()
     if native_loop:
@@ -247,7 +252,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     tim = ev.timing_get()
     ev.timing_enable(False)
     stats = ev.stats()
-    for i in range(3):
+    for i in range(16):
         run.step(points[i % npts], False)
     run.fence()
     t0 = time.perf_counter()
