@@ -913,6 +913,27 @@ def frontend_beside_backend(device, p, w, seconds=0.35):
                        "note": "front end: one 1M-event FR-CG solve started every 10 ms (a packet per dt_ang_vel); back end: config-3 "
                                "solves in a loop"}
     res["settings"] = "default streams (no priority, no CU mask): see profiles/r04_fe_beside_be.txt for the sweep"
+    # ---- cooperative scheduling (cmx_set_sched_class): the back end holds its NEXT evaluation while the front end's solve is on
+    # the device -- the front end waits for at most the one back-end evaluation already running
+    try:
+        fe.set_sched_class(_lib.SCHED_URGENT)
+        be.set_sched_class(_lib.SCHED_BACKGROUND)
+        fe_tick.lat = []
+        _, bs_co = loops(True, True, fe_tick, lambda: be.setupProblemAndOptimize(), 0.5)
+        s_co = float(np.mean(fe_tick.lat)) * 1e3
+        p95 = float(np.percentile(fe_tick.lat, 95)) * 1e3
+        for ev in (fe, be):
+            ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+        f_co, b_co = loops(True, True, lambda: fe.eval(xf, True), lambda: be.eval(xb, True), seconds)
+        res["cooperative"] = {"at_100hz": {"frontend_solve_ms": {"solo": s_solo, "beside": s_co, "ratio": s_co / s_solo, "p95": p95,
+                                                                   "solves": len(fe_tick.lat)},
+                                           "backend_solve_ms": {"solo": bs_solo, "beside": bs_co, "ratio": bs_co / bs_solo}},
+                              "back_to_back": {"frontend_fdf_ms": {"solo": f_solo, "beside": f_co, "ratio": f_co / f_solo},
+                                               "backend_fdf_ms": {"solo": b_solo, "beside": b_co, "ratio": b_co / b_solo},
+                                               "note": "front end at 100 % duty: the back end runs in its 5 ms starvation guard only"},
+                              "settings": "front end CMX_SCHED_URGENT, back end CMX_SCHED_BACKGROUND (host-side, evaluation granularity)"}
+    except Exception as e:
+        res["cooperative"] = {"error": repr(e)}
     fe.close()
     be.close()
     return res
@@ -1061,7 +1082,9 @@ def summary_of(out):
         s["frontend_beside_backend"] = {"fe_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "frontend_fdf_ms", "ratio"),
                                         "be_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "backend_fdf_ms", "ratio"),
                                         "fe_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "frontend_solve_ms", "ratio"),
-                                        "be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "backend_solve_ms", "ratio")}
+                                        "be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "backend_solve_ms", "ratio"),
+                                         "cooperative_fe_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "cooperative", "at_100hz", "frontend_solve_ms", "ratio"),
+                                         "cooperative_be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "cooperative", "at_100hz", "backend_solve_ms", "ratio")}
     if "group" in out and isinstance(out["group"], dict):
         s["group_overhead_ms_2_members_one_device"] = out["group"].get("overhead_ms")
     if "parity_vs_1gpu" in out:

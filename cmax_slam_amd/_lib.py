@@ -16,6 +16,7 @@ GRAD_PLANES, GRAD_ADJOINT = 0, 1
 DT_U8, DT_F32, DT_F64 = 0, 1, 2
 OP_SUM, OP_MAX = 0, 1
 GROUP_AUTO, GROUP_RCCL, GROUP_DIRECT = 0, 1, 2
+SCHED_BACKGROUND, SCHED_NORMAL, SCHED_URGENT = -1, 0, 1
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE = 1, 2, 3, 4, 5, 6
 OPT_COMPOSITE_IMAGE, OPT_FOLD_BATCH, OPT_GATED_DF, OPT_CHAIN_SOLVE = 8, 9, 10, 11
@@ -40,6 +41,7 @@ SYMBOLS = {
     "cmx_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
     "cmx_set_stream_priority": (C.c_int, [ctx_p, C.c_int]),
     "cmx_set_cu_mask": (C.c_int, [ctx_p, C.POINTER(C.c_uint32), C.c_int]),
+    "cmx_set_sched_class": (C.c_int, [ctx_p, C.c_int]),
     "cmx_backend_create_group": (C.c_int, [C.POINTER(ctx_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_int,
                                            C.c_int]),
     "cmx_group_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), c_i64p, c_dp]),

@@ -262,6 +262,7 @@ static int be_prepare_one(cmx_ctx *c, const double *drotv_hint) {
 }
 
 static int be_accumulate(cmx_ctx *c, const double *drotv, bool want_grad) {
+  yield_to_urgent(c);
   c->timing_tick++;  // see fe_accumulate
   const size_t np = (size_t)c->Wp * c->Hp;
   const int Kopt = c->K - c->num_fixed;
@@ -422,6 +423,7 @@ static int be_finish_one(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_backend_eval(cmx_ctx *c, const double *drotv, double *contrast, double *grad) {
+  UrgentScope urgent(c);
   if (is_group(c)) return group_eval(c, drotv, contrast, grad);  // one call, N devices, one contrast / gradient
   return be_eval_one(c, drotv, contrast, grad);
 }

@@ -455,6 +455,55 @@ int cmx_set_cu_mask(cmx_ctx *c, const uint32_t *mask, int n_words) {
   return replace_own_stream(c, 0, mask, n_words);
 }
 
+// ---- cooperative scheduling (see cmx_set_sched_class in the header).  Stream priorities do not pre-empt the back end's resident
+// workgroups and CU masks split the chip statically (profiles/r04_fe_beside_be.txt); what the two paths of the reference need is
+// that the back end does not START an evaluation while the front end's short solve is on the device.
+namespace {
+constexpr int kSchedDevices = 64;
+constexpr long long kUrgentLingerNs = 20000, kYieldCapNs = 5000000;
+std::atomic<int> g_urgent_active[kSchedDevices];
+std::atomic<long long> g_urgent_last_end_ns[kSchedDevices];
+long long sched_now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+UrgentScope::UrgentScope(cmx_ctx *ctx) : c((ctx && ctx->sched_class > 0 && ctx->device >= 0 && ctx->device < kSchedDevices) ? ctx : nullptr) {
+  if (c) g_urgent_active[c->device].fetch_add(1, std::memory_order_acq_rel);
+}
+UrgentScope::~UrgentScope() {
+  if (!c) return;
+  g_urgent_last_end_ns[c->device].store(sched_now_ns(), std::memory_order_release);
+  g_urgent_active[c->device].fetch_sub(1, std::memory_order_acq_rel);
+}
+void yield_to_urgent(cmx_ctx *c) {
+  if (!c || c->sched_class >= 0 || c->device < 0 || c->device >= kSchedDevices) return;
+  const int d = c->device;
+  long long t0 = 0;
+  for (unsigned spins = 0;; spins++) {
+    if (g_urgent_active[d].load(std::memory_order_acquire) == 0) {
+      const long long last = g_urgent_last_end_ns[d].load(std::memory_order_acquire);
+      if (last == 0) return;  // no urgent context has ever run on this device
+      const long long now = sched_now_ns();
+      if (now - last >= kUrgentLingerNs) return;
+      if (!t0) t0 = now;
+      if (now - t0 > kYieldCapNs) return;
+    } else if ((spins & 63u) == 63u) {
+      const long long now = sched_now_ns();
+      if (!t0) t0 = now;
+      if (now - t0 > kYieldCapNs) return;  // never starve: an urgent caller that stays busy gets at most this much in a row
+    }
+    if (!t0) t0 = sched_now_ns();
+    __builtin_ia32_pause();
+  }
+}
+int cmx_set_sched_class(cmx_ctx *c, int sched_class) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  if (sched_class < CMX_SCHED_BACKGROUND || sched_class > CMX_SCHED_URGENT) return fail(c, CMX_ERR_INVALID_ARG, "bad scheduling class %d", sched_class);
+  if (is_group(c)) return group_all(c, [&](cmx_ctx *m, int) { m->sched_class = sched_class; return (int)CMX_OK; });
+  c->sched_class = sched_class;
+  return CMX_OK;
+}
+
 int cmx_abi_version(void) { return CMX_ABI_VERSION; }
 
 int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {

@@ -42,6 +42,7 @@ struct cmx_ctx {
   int kind = 0, device = 0;
   cmx_group *group = nullptr;  // set on every member of a group; the member with group_rank 0 is the handle the caller holds
   int group_rank = 0;
+  int sched_class = 0;  // cmx_set_sched_class: -1 background (yields to urgent contexts of its device), 0 normal, 1 urgent
   bool group_partial_grad = false;  // the last evaluation's gradient covers this member's events only (cmx_comm.cpp: finish_exchanged)
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -370,6 +371,14 @@ int finish_begin(cmx_ctx *c, int kind, int want_grad);
 int finish_end(cmx_ctx *c, int kind, double *contrast, double *grad);
 int be_ensure_time_bearings(cmx_ctx *c);  // cmx_backend.cpp: the gather's time-ordered bearing stream (once per window)
 int be_first_iter(cmx_ctx *c);  // cmx_backend.cpp: IGp <- IG and alpha on the first evaluation of a window
+
+// ---- cooperative scheduling between the contexts of this process that share a device (cmx_set_sched_class, cmx_context.cpp)
+struct UrgentScope {  // around every entry point that puts an urgent context's evaluations on the device (nests)
+  cmx_ctx *c;
+  explicit UrgentScope(cmx_ctx *ctx);
+  ~UrgentScope();
+};
+void yield_to_urgent(cmx_ctx *c);  // first thing of a background context's evaluation: hold it while an urgent burst is on the device
 
 // ---- cmx_group.cpp: the entry points of the C ABI hand a group's handle to these
 bool is_group(const cmx_ctx *c);

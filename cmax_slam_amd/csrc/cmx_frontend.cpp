@@ -97,6 +97,7 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
 }
 
 int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+  yield_to_urgent(c);
   c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
   const size_t np = (size_t)c->W * c->H;
   int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);
@@ -199,6 +200,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
 }
 
 int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, double *grad) {
+  UrgentScope urgent(c);
   const bool sharded = c && c->sharded();
   if (c && c->kind == KIND_FE && omega && can_reuse(c, omega, 3, grad != nullptr)) {
     c->last_adjoint = true;  // image of this very point is resident: adjoint blur + gather only

@@ -892,9 +892,11 @@ static int eval_many(cmx_ctx *c, int kind, int m, const double *xs, double *cont
   return CMX_OK;
 }
 int cmx_frontend_eval_many(cmx_ctx *c, int m, const double *omegas, double *contrasts, double *grads) {
+  UrgentScope urgent(c);
   return eval_many(c, KIND_FE, m, omegas, contrasts, grads);
 }
 int cmx_backend_eval_many(cmx_ctx *c, int m, const double *drotvs, double *contrasts, double *grads) {
+  UrgentScope urgent(c);
   return eval_many(c, KIND_BE, m, drotvs, contrasts, grads);
 }
 
@@ -903,6 +905,7 @@ int cmx_backend_eval_many(cmx_ctx *c, int m, const double *drotvs, double *contr
 // whose own loop is expensive per call (an interpreter): the evaluation sequence of a line search cannot be known in
 // advance, but replaying a recorded one, or timing the evaluator without the caller's overhead, can use it.
 int cmx_frontend_eval_each(cmx_ctx *c, int m, const double *omegas, double *contrasts, double *grads) {
+  UrgentScope urgent(c);
   if (!c || m < 0 || (m > 0 && (!omegas || !contrasts))) return c ? fail(c, CMX_ERR_INVALID_ARG, "bad arguments") : CMX_ERR_INVALID_ARG;
   for (int i = 0; i < m; i++) {
     const int rc = cmx_frontend_eval(c, omegas + 3 * (size_t)i, contrasts + i, grads ? grads + 3 * (size_t)i : nullptr);
@@ -911,6 +914,7 @@ int cmx_frontend_eval_each(cmx_ctx *c, int m, const double *omegas, double *cont
   return CMX_OK;
 }
 int cmx_backend_eval_each(cmx_ctx *c, int m, const double *drotvs, double *contrasts, double *grads) {
+  UrgentScope urgent(c);
   if (!c || m < 0 || (m > 0 && (!drotvs || !contrasts))) return c ? fail(c, CMX_ERR_INVALID_ARG, "bad arguments") : CMX_ERR_INVALID_ARG;
   const size_t P = (size_t)(c->order > 0 ? 3 * (c->K - c->num_fixed) : 0);
   for (int i = 0; i < m; i++) {

@@ -95,6 +95,7 @@ void drive(const cmx::FunctionFdf &user, double *x_inout, double initial_step_si
 }
 
 int solve(cmx_ctx *ctx, bool backend, int n, double *x_inout, double tol, double epsabs_grad, cmx_solve_report *rep) {
+  UrgentScope urgent(ctx);  // the whole solve is one burst
   SolveState st;
   st.ctx = ctx;
   st.backend = backend;

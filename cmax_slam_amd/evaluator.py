@@ -110,6 +110,11 @@ class _Evaluator:
         """cmx_set_stream_priority: > 0 highest (the front end beside a back-end solve), 0 normal, < 0 lowest."""
         self._ck(self._L.cmx_set_stream_priority(self._ctx, int(level)))
 
+    def set_sched_class(self, sched_class):
+        """cmx_set_sched_class: +1 urgent (the front end), 0 normal, -1 background (the back end: holds its next evaluation while an
+        urgent context of the same device is busy)."""
+        self._ck(self._L.cmx_set_sched_class(self._ctx, int(sched_class)))
+
     def set_cu_mask(self, n_cus=None, first=0, mask_words=None):
         """cmx_set_cu_mask: run on `n_cus` compute units starting at bit `first` (on MI355X consecutive bits walk the eight
         XCDs, so any run of bits is spread over all of them), or on an explicit list of 32-bit words; None / 0 = all."""

@@ -135,6 +135,16 @@ int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
  * Results never depend on either call. */
 int cmx_set_stream_priority(cmx_ctx *ctx, int level);
 int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
+/* What DOES give the front end its latency back without a static split: cooperative scheduling between the contexts of one
+ * process that share a device, at evaluation granularity.  A context of class CMX_SCHED_BACKGROUND (the back end) holds its
+ * NEXT evaluation -- between two evaluations of a solve there is nothing of it on the GPU -- while a context of class
+ * CMX_SCHED_URGENT on the same device (the front end: a 0.5 ms solve every 10 ms) has a call of cmx_*_eval / _eval_each /
+ * _solve in progress, or finished one less than 20 us ago (so that a GSL-driven sequence of evaluations counts as one burst).
+ * The urgent call then waits for at most the one background evaluation already on the device.  A background context never
+ * waits longer than 5 ms in a row.  Host-side only: no kernel, stream or result changes.  Default: CMX_SCHED_NORMAL (neither
+ * waits nor is waited for).  Measured: bench.py frontend_beside_backend.cooperative. */
+enum { CMX_SCHED_BACKGROUND = -1, CMX_SCHED_NORMAL = 0, CMX_SCHED_URGENT = 1 };
+int cmx_set_sched_class(cmx_ctx *ctx, int sched_class);
 
 /* ------------------------------------------------------------------ front end -------------------------
  * replaces AngVelEstimator::computeImageOfWarpedEvents + computeContrast
