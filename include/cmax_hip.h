@@ -56,7 +56,11 @@ enum {
                           pass over the events gathers from one plane; no derivative planes */
 };
 
-/* cmx_set_option keys */
+/* cmx_set_option keys.  A host needs at most three of them: CMX_OPT_DETERMINISTIC (bitwise reproducibility), CMX_OPT_SPIN_WAIT (0 to
+ * give the waiting core back) and CMX_OPT_GRAD_MODE / CMX_OPT_SPLAT_MODE together to select the reference-shaped data flow.  The
+ * others (REUSE_IMAGE, TAIL_FINALIZE, COMPOSITE_IMAGE, FOLD_BATCH, GATED_DF, CHAIN_SOLVE) switch between forms that the library
+ * also selects BY ITSELF from the configuration (image size, blur radius, batch size, deterministic mode, communicator attached):
+ * they exist so that tests and same-box A/B measurements can reach every form on any input, and default to the fastest one. */
 enum {
   CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_ADJOINT (default) | CMX_GRAD_PLANES */
   CMX_OPT_SPLAT_MODE = 2, /* 0 = one global fp32 atomic per vote;
