@@ -939,6 +939,25 @@ def frontend_beside_backend(device, p, w, seconds=0.35):
     return res
 
 
+def large_launch(args, ctx, events=16_000_000, steps=40):
+    """The SAME front-end kernels on a launch large enough to leave the latency-bound regime (16M events instead of config 2's 1M;
+    640x480, everything else as config 2): what fraction of the HBM roofline the per-event kernels reach when dispatch, tail and
+    round-trip latencies stop being the launch.  Not the headline (BASELINE's metric is quoted at 1M events): evidence about the
+    kernels."""
+    import copy
+    a = copy.copy(args)
+    a.steps, a.warmup = steps, 5
+    ev, run, p, m, name, img, pts = frontend_workload(a, ctx, events)
+    ev.close()
+    return {"workload": name, "events": events, "fdf_ms": m["ms_per_step"], "events_per_s": m["value"],
+            "cost_only_ms": m["cost_only"]["ms_per_step"],
+            "kernels": [{"kernel": k["kernel"], "ms": k["ms"], "hbm_mandatory_bytes": k["hbm_mandatory_bytes"], "frac": k["frac"]}
+                        for k in m["kernels"]],
+            "whole_evaluation_frac": m["whole_evaluation"]["frac"],
+            "note": "frac = HBM-mandatory bytes / live kernel duration / 8 TB/s, as in `roofline`; the 1M-event headline's fractions are "
+                    "set by launch and tail latencies (roofline.limited_by)"}
+
+
 def group_on_one_device(device, w, steps=200):
     """One-process multi-GPU group (cmx_backend_create_group) exercised on the ONE device this box has: two members sharing the
     GPU, direct transport, against the single context on the same window -- what the group machinery (fan-out to the worker
@@ -1087,6 +1106,10 @@ def summary_of(out):
                                          "cooperative_be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "cooperative", "at_100hz", "backend_solve_ms", "ratio")}
     if "group" in out and isinstance(out["group"], dict):
         s["group_overhead_ms_2_members_one_device"] = out["group"].get("overhead_ms")
+    if isinstance(out.get("large_launch"), dict) and "kernels" in out["large_launch"]:
+        ll = out["large_launch"]
+        s["large_launch_16M_events"] = {"events_per_s": ll.get("events_per_s"), "whole_evaluation_frac": ll.get("whole_evaluation_frac"),
+                                        "kernel_fracs": {k["kernel"]: k["frac"] for k in ll["kernels"]}}
     if "parity_vs_1gpu" in out:
         s["parity_vs_1gpu"] = out["parity_vs_1gpu"]
     return s
@@ -1217,7 +1240,8 @@ def main():
                     except Exception as e:  # must not cost the headline line
                         be[key] = {"error": repr(e)}
                 for key, fn in (("frontend_beside_backend", lambda: frontend_beside_backend(local_rank, p, w)),
-                                ("group", lambda: group_on_one_device(local_rank, synth_config4_slab()))):
+                                ("group", lambda: group_on_one_device(local_rank, synth_config4_slab())),
+                                ("large_launch", lambda: large_launch(args, ctx))):
                     try:
                         out[key] = fn()
                     except Exception as e:
