@@ -1607,6 +1607,72 @@ int fe_gather_blocks(int n) {
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
 }
 
+// The front-end gather's event loop for the tile-ordered streams (the production form), in branch-free phases: every load of a
+// phase is in flight at once -- U x 24 B of streams, then (after the U warps) the U x 4 Jt cells.  With the loads behind
+// `if (act && ok)` the compiler cannot hoist them and the events' trips to the Jt plane follow one another.  Same operations per
+// event, same order of a thread's additions: the sums are the generic loop's bit for bit.  At 1M events the launch is bound by its
+// fixed costs and the two forms time the same (profiles/r04_fe_gather_anatomy.txt); at 16M events per launch the loop IS the launch
+// (116 -> 99 us).
+template <int U>
+__device__ __forceinline__ void fe_gather_streams(const FeGatherArgs &g, const FeSplatArgs &a, int blk_beg, int blk_end, double acc[3],
+                                                  double acc2[3]) {
+  const int W = a.W, H = a.H, r = g.r;
+  for (int i0 = blk_beg + (int)threadIdx.x; i0 < blk_end; i0 += 256 * U) {
+    double2 bv[U];
+    double dt[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * 256;
+      ok[u] = i < blk_end;
+      const int ii = ok[u] ? i : blk_beg;
+      bv[u] = *reinterpret_cast<const double2 *>(g.sb + 2 * (size_t)ii);
+      dt[u] = g.sdt[ii];
+    }
+    FeWarp w[U];
+    const float *q[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      w[u] = fe_warp_math<true>(a, bv[u].x, bv[u].y, 1.0, dt[u]);
+      ok[u] = ok[u] && w[u].ok;
+      q[u] = g.itilde + (ok[u] ? (size_t)w[u].yy * W + w[u].xx : (size_t)0);  // (cells 0 .. W+1 exist in every image the path accepts)
+    }
+    float i00[U], i01[U], i10[U], i11[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { i00[u] = q[u][0]; i01[u] = q[u][1]; i10[u] = q[u][W]; i11[u] = q[u][W + 1]; }
+    bool edge = false;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float dx = w[u].dx, dy = w[u].dy;
+      const float A = (1.f - dy) * (i01[u] - i00[u]) + dy * (i11[u] - i10[u]);
+      const float B = (1.f - dx) * (i10[u] - i00[u]) + dx * (i11[u] - i01[u]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double t = (double)w[u].r0[k] * (double)A + (double)w[u].r1[k] * (double)B;
+        acc[k] = ok[u] ? acc[k] + t : acc[k];
+      }
+      edge = edge || (ok[u] && (w[u].xx <= r || w[u].xx + 1 >= W - 1 - r || w[u].yy <= r || w[u].yy + 1 >= H - 1 - r));
+    }
+    if (g.cx && __any(edge)) {  // votes within r of the border: rare, wave-uniform
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (!ok[u]) continue;
+        float Ac, Bc;
+        border_grad(g.cx, g.cy, W, H, r, w[u].xx, w[u].yy, w[u].dx, w[u].dy, Ac, Bc);
+        if (Ac != 0.f || Bc != 0.f) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc2[k] += (double)w[u].r0[k] * (double)Ac + (double)w[u].r1[k] * (double)Bc;
+        }
+      }
+    }
+  }
+}
+// U = 4 (same-box A/B of builds, gather us at 1M / 4M / 16M events): generic loop 13.6 / 29.0 / 116; phases U = 2 13.6 / 30.4 / 110;
+// phases U = 4 13.8 / 29.4 / 99 (127 VGPRs: four waves per SIMD, what ~1000 workgroups of four waves need)
+#ifndef CMX_FE_GATHER_U
+#define CMX_FE_GATHER_U 4
+#endif
+
 // CHAIN: 0 plain; 1 device-driven solve, gated by the flag the cost stage's finalize wrote; 2 device-driven solve, SELF-GATING:
 // the image pass in front left the image's two moments in accumulator rows and ran no finalize -- every workgroup of this
 // launch forms the contrast from them (16 loads, the same expression the finalize uses) and evaluates the machine's
@@ -1644,6 +1710,8 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
   const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
   const int stride = 256;
+  if (CMX_FE_GATHER_U > 0 && g.sb) fe_gather_streams<(CMX_FE_GATHER_U > 0 ? CMX_FE_GATHER_U : 1)>(g, a, blk_beg, blk_end, acc, acc2);
+  else
   for (int i0 = blk_beg + threadIdx.x; i0 < blk_end; i0 += stride * U) {
     double dt[U], px[U], py[U], pz[U];
     bool act[U];
