@@ -1710,7 +1710,9 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
   const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
   const int stride = 256;
-  if (CMX_FE_GATHER_U > 0 && g.sb) fe_gather_streams<(CMX_FE_GATHER_U > 0 ? CMX_FE_GATHER_U : 1)>(g, a, blk_beg, blk_end, acc, acc2);
+  // (the device-driven solve's variants keep the generic loop: with the finalize and the machine's step inlined, four events in
+  //  flight cost them registers -- a 1M-event solve 0.558 -> 0.585 ms, same-box A/B -- and their launches are never large)
+  if (CHAIN == 0 && CMX_FE_GATHER_U > 0 && g.sb) fe_gather_streams<(CMX_FE_GATHER_U > 0 ? CMX_FE_GATHER_U : 1)>(g, a, blk_beg, blk_end, acc, acc2);
   else
   for (int i0 = blk_beg + threadIdx.x; i0 < blk_end; i0 += stride * U) {
     double dt[U], px[U], py[U], pz[U];
