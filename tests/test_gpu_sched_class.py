@@ -96,3 +96,39 @@ def test_background_alone_is_not_delayed(hip):
         be.set_sched_class(5)
     fe.close()
     be.close()
+
+
+def test_background_group_beside_an_urgent_front_end(hip):
+    """The one-process multi-GPU handle takes a class too (every member, their worker threads included, yields): a background
+    group of two members evaluates beside an urgent front end and returns what the single context returns."""
+    p, w, fe, be = _contexts(hip)
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0])
+    grp.set_fast_path()
+    grp.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    d = np.full(w.P, 0.003)
+    c0, g0 = be.eval(d)
+    fe.set_sched_class(_lib.SCHED_URGENT)
+    grp.set_sched_class(_lib.SCHED_BACKGROUND)
+    om = np.array([0.3, -0.5, 0.2])
+    errors, n = [], [0]
+    stop = time.perf_counter() + 0.5
+
+    def front():
+        try:
+            while time.perf_counter() < stop:
+                fe.setupProblemAndOptimize(np.zeros(3))
+                fe.eval(om)
+                time.sleep(0.002)      # a front end with pauses: the group advances in them
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=front)
+    t.start()
+    while time.perf_counter() < stop:
+        c, g = grp.eval(d)
+        assert rel_scalar(c, c0) < 1e-6 and rel_vec(g, g0) < 1e-6
+        n[0] += 1
+    t.join(timeout=60)
+    assert not errors and not t.is_alive() and n[0] >= 10, (errors, n)
+    for e in (fe, be, grp):
+        e.close()
