@@ -15,9 +15,17 @@ evaluation sees the drift a real solve produces (votes leaving their LDS windows
                     events / 8 per GPU, 1280x720 sensor, 4096x2048 map.  --workload frontend keeps round 1's front-end
                     variant (N x 1M events over one packet).
 
+  N > 1 (plain `python bench.py --gpus N`, no launcher): the same config 4 through ONE handle -- the one-process group
+                    (cmx_backend_create_group over devices 0..N-1, the form the reference's single back-end thread can use) is
+                    the headline, and the process-per-GPU form is self-spawned (torch.distributed.run) as a nested leg.  Fewer
+                    devices than N: what is there runs, `n_gpus` says how many, an `error` field says why; exit status 0.
+
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|frontend|backend] [--no-backend] [--no-cpu-baseline]
-Rank 0 prints ONE JSON line.  Every number is measured in this run except `roofline.traffic` / `kernels[].pmc_bytes`,
-which are read from profiles/pmc_traffic.json (rocprofv3 --pmc passes of this same command, see profiles/README.md).
+Rank 0 prints ONE JSON line on stdout, at most LINE_BUDGET bytes: the contract's keys, `roofline`, `cpu_baseline`, `summary`.
+Everything else measured in the run (per-kernel table, per-packet / per-window pipelines, launch-default shapes, front end beside
+back end, group, large launch, concurrent contexts, the nested back-end leg in full) goes to bench_detail.json (--detail-out) and,
+as one line, to stderr.  Every number is measured in this run except `roofline.traffic` / `kernels[].pmc_bytes`, which are
+read from profiles/pmc_traffic.json (rocprofv3 --pmc passes of this same command, see profiles/README.md).
 """
 import argparse
 import json
@@ -410,6 +418,39 @@ def prior_map_config5(ctx):
     return t.cpu().numpy().reshape(Hp, Wp)
 
 
+def _slabs(make, n, per_gpu):
+    """The n time slabs of a window, generated on a thread pool (numpy releases the GIL in the heavy parts: 9 s per 5M-event slab
+    on one core would be 75 s for config 4's 40M events)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if n == 1:
+        return [make(0, 1, per_gpu)]
+    with ThreadPoolExecutor(max_workers=max(1, min(n, usable_cores()))) as ex:
+        return list(ex.map(lambda r: make(r, n, per_gpu), range(n)))
+
+
+def one_gpu_same_workload(device, which, n_slabs, per_gpu, pts, steps, mode):
+    """Weak-scaling reference for the N > 1 lines: slab 0 of the SAME window (per_gpu events, the same spline, map and options) on ONE plain
+    context -- the per-GPU work of the sharded run without a partner.  value(N) / (N x this) is the efficiency a reader wants;
+    the N = 1 headline is another workload (config 2)."""
+    from cmax_slam_amd import _lib, evaluator, synth
+    w = (synth.config4_slab if which == "config4" else synth.config5_slab)(0, n_slabs, per_gpu)
+    ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device)
+    ev.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                  w.sample_rate, w.sigma, _lib.VARIANCE)
+    (ev.set_fast_path if mode == "fast" else ev.set_reference_path)()
+    ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+    xs = np.vstack([pts[i % len(pts)] for i in range(max(steps, 16))])
+    t_end = time.perf_counter() + SETTLE_S
+    while time.perf_counter() < t_end:
+        ev.eval_each(xs[:16], True)
+    t0 = time.perf_counter()
+    ev.eval_each(xs, True)
+    ms = (time.perf_counter() - t0) * 1e3 / len(xs)
+    ev.close()
+    return {"workload": "%s slab 0 of %d, %d events, one plain context" % (which, n_slabs, len(w.x)), "fdf_ms": ms,
+            "value": len(w.x) / ms * 1e3, "unit": "events/s"}
+
+
 def backend_workload(args, ctx, which, per_gpu, steps, group_devices=None):
     """which = 'config3' (single window, N=1), 'config4' (time slab per rank), 'config5' (time slab per rank).
     group_devices = [d0, d1, ...]: ONE process, the whole window (all slabs) handed to a group handle (--single-process)."""
@@ -420,10 +461,10 @@ def backend_workload(args, ctx, which, per_gpu, steps, group_devices=None):
     if which == "config3":
         w = synth.config3(per_gpu)
     elif which == "config4":
-        w = (synth.concat_slabs([synth.config4_slab(r, n_members, per_gpu) for r in range(n_members)]) if group_devices
+        w = (synth.concat_slabs(_slabs(synth.config4_slab, n_members, per_gpu)) if group_devices
              else synth.config4_slab(rank, world, per_gpu))
     else:
-        w = (synth.concat_slabs([synth.config5_slab(r, n_members, per_gpu) for r in range(n_members)]) if group_devices
+        w = (synth.concat_slabs(_slabs(synth.config5_slab, n_members, per_gpu)) if group_devices
              else synth.config5_slab(rank, world, per_gpu))
         IG = prior_map_config5(ctx)
     w.IG = IG
@@ -1078,7 +1119,7 @@ def synth_config4_slab():
 
 
 def summary_of(out):
-    """Compact headline figures, emitted as the LAST key of the line (the driver's stdout tail cut the front)."""
+    """Compact headline figures of every leg (the stdout line carries this; the legs themselves live in bench_detail.json)."""
     def g(d, *ks):
         for k in ks:
             if not isinstance(d, dict) or k not in d:
@@ -1086,40 +1127,225 @@ def summary_of(out):
             d = d[k]
         return d
     s = {"fdf_ms": out.get("ms_per_step"), "events_per_s": out.get("value"), "n_gpus": out.get("n_gpus"),
+         "cost_only_ms": g(out, "cost_only", "ms_per_step"),
          "roofline_frac": g(out, "roofline", "frac"), "roofline_kernel": g(out, "roofline", "kernel"),
-         "whole_evaluation_frac": g(out, "whole_evaluation", "frac"), "cmax_iters_per_s": g(out, "cmax", "iters_per_s"), "cmax_iters_per_s_idle_start": g(out, "cmax", "idle_start", "iters_per_s"),
+         "whole_evaluation_frac": g(out, "whole_evaluation", "frac"), "cmax_iters_per_s": g(out, "cmax", "iters_per_s"),
+         "cmax_iters_per_s_idle_start": g(out, "cmax", "idle_start", "iters_per_s"),
          "cpu_baseline_events_per_s": g(out, "cpu_baseline", "value")}
-    if "backend" in out:
+    if isinstance(out.get("kernel_ms"), dict):
+        s["kernel_us"] = {k: round(v * 1e3, 2) for k, v in out["kernel_ms"].items()}
+    if isinstance(out.get("backend"), dict):
         b = out["backend"]
-        s["backend"] = {"fdf_ms": b.get("ms_per_step"), "events_per_s": b.get("value"), "roofline_frac": g(b, "roofline", "frac"),
-                        "roofline_kernel": g(b, "roofline", "kernel"), "roofline_bound": g(b, "roofline", "bound"), "roofline_limited_by": (g(b, "roofline", "limited_by") or "")[:60],
+        s["backend"] = {"fdf_ms": b.get("ms_per_step"), "events_per_s": b.get("value"), "roofline": {k: g(b, "roofline", k) for k in
+                        ("bound", "kernel", "frac", "hbm_frac", "achieved", "peak", "unit") if g(b, "roofline", k) is not None},
                         "whole_evaluation_frac": g(b, "whole_evaluation", "frac"),
                         "cmax_iters_per_s": g(b, "cmax", "iters_per_s"),
-                        "per_window_ratio_to_solve_store_pipelined": g(b, "per_window", "device_store", "pipelined", "ratio_to_solve"),
-                        "per_window_ratio_to_solve_host_pipelined": g(b, "per_window", "host_arrays", "pipelined", "ratio_to_solve")}
+                        "cpu_baseline_events_per_s": g(b, "cpu_baseline", "value"),
+                        "per_window_ratio_to_solve": {"store_seq": g(b, "per_window", "device_store", "sequential", "ratio_to_solve"),
+                                                      "store_pipelined": g(b, "per_window", "device_store", "pipelined", "ratio_to_solve"),
+                                                      "host_seq": g(b, "per_window", "host_arrays", "sequential", "ratio_to_solve"),
+                                                      "host_pipelined": g(b, "per_window", "host_arrays", "pipelined", "ratio_to_solve")}}
+        if isinstance(b.get("kernel_ms"), dict):
+            s["backend"]["kernel_us"] = {k: round(v * 1e3, 2) for k, v in b["kernel_ms"].items()}
     if "frontend_beside_backend" in out:
-        s["frontend_beside_backend"] = {"fe_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "frontend_fdf_ms", "ratio"),
-                                        "be_ratio_back_to_back": g(out, "frontend_beside_backend", "back_to_back", "backend_fdf_ms", "ratio"),
-                                        "fe_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "frontend_solve_ms", "ratio"),
-                                        "be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "at_100hz", "backend_solve_ms", "ratio"),
-                                         "cooperative_fe_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "cooperative", "at_100hz", "frontend_solve_ms", "ratio"),
-                                         "cooperative_be_solve_ratio_at_100hz": g(out, "frontend_beside_backend", "cooperative", "at_100hz", "backend_solve_ms", "ratio")}
-    if "group" in out and isinstance(out["group"], dict):
-        s["group_overhead_ms_2_members_one_device"] = out["group"].get("overhead_ms")
+        f = out["frontend_beside_backend"]
+        s["frontend_beside_backend"] = {"fe_b2b": g(f, "back_to_back", "frontend_fdf_ms", "ratio"),
+                                        "be_b2b": g(f, "back_to_back", "backend_fdf_ms", "ratio"),
+                                        "fe_solve_100hz": g(f, "at_100hz", "frontend_solve_ms", "ratio"),
+                                        "be_solve_100hz": g(f, "at_100hz", "backend_solve_ms", "ratio"),
+                                        "coop_fe_solve_100hz": g(f, "cooperative", "at_100hz", "frontend_solve_ms", "ratio"),
+                                        "coop_be_solve_100hz": g(f, "cooperative", "at_100hz", "backend_solve_ms", "ratio")}
+    if isinstance(out.get("group"), dict):
+        if "overhead_ms" in out["group"]:
+            s["group_2_members_one_device"] = {"overhead_ms": out["group"].get("overhead_ms"),
+                                               "per_window_ratio_to_solve_store": g(out["group"], "per_window", "device_store", "sequential", "ratio_to_solve")}
+        else:
+            s["group"] = {k: out["group"].get(k) for k in ("members", "devices", "transport", "last_fanout_us")}
+    if isinstance(out.get("comm"), dict):
+        s["comm"] = {k: out["comm"].get(k) for k in ("nranks_seen", "transport", "ms_per_step", "share_of_step", "collectives_per_step",
+                                                     "bytes_last_evaluation")}
     if isinstance(out.get("large_launch"), dict) and "kernels" in out["large_launch"]:
         ll = out["large_launch"]
         s["large_launch_16M_events"] = {"events_per_s": ll.get("events_per_s"), "whole_evaluation_frac": ll.get("whole_evaluation_frac"),
                                         "kernel_fracs": {k["kernel"]: k["frac"] for k in ll["kernels"]}}
+    if isinstance(out.get("concurrent_contexts"), dict) and out["concurrent_contexts"].get("runs"):
+        r = out["concurrent_contexts"]["runs"][-1]
+        s["concurrent_contexts"] = {"contexts": r["contexts"], "events_per_s": r["value"], "whole_evaluation_frac": r["whole_evaluation_frac"]}
     if "parity_vs_1gpu" in out:
-        s["parity_vs_1gpu"] = out["parity_vs_1gpu"]
+        s["parity_vs_1gpu"] = {k: g(out, "parity_vs_1gpu", k) for k in ("contrast_rel", "grad_rel_inf", "tolerance", "error")
+                               if g(out, "parity_vs_1gpu", k) is not None}
+    if isinstance(out.get("config5"), dict):
+        c5 = out["config5"]
+        s["config5"] = {"fdf_ms": c5.get("ms_per_step"), "events_per_s": c5.get("value"),
+                        "parity_grad_rel_inf": g(c5, "parity_vs_1gpu", "grad_rel_inf"), "error": c5.get("error")}
+    if isinstance(out.get("one_gpu_same_workload"), dict):
+        s["one_gpu_same_workload_events_per_s"] = out["one_gpu_same_workload"].get("value")
+    if isinstance(out.get("process_per_gpu"), dict):
+        c = out["process_per_gpu"]
+        s["process_per_gpu"] = ({"error": c["error"][:200]} if "error" in c and "value" not in c else
+                                {"n_gpus": c.get("n_gpus"), "fdf_ms": c.get("ms_per_step"), "events_per_s": c.get("value"),
+                                 "nranks_seen": g(c, "summary", "comm", "nranks_seen"),
+                                 "parity_grad_rel_inf": g(c, "summary", "parity_vs_1gpu", "grad_rel_inf")})
+    ps = parity_sweep_record()
+    if ps:
+        s["parity_sweep"] = ps
     return s
+
+
+def parity_sweep_record():
+    """profiles/sweep300.json: how many of the back-end sweep's evaluations pass the strict 1e-5 gate against the oracle and how many need
+    the all-fp64 arbiter (written by tests/test_gpu_sweep300.py on the GPU box -- the bench itself never touches the oracle outside
+    cpu_baseline); reported with whether it was taken on this build."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "sweep300.json")))
+        return {"evaluations": rec["evaluations"], "via_arbiter": rec["via_arbiter"], "max_rel_vs_oracle": rec.get("max_rel_vs_oracle"),
+                "this_build": rec.get("src_sha256") == csrc_hash()}
+    except Exception:
+        return None
+
+
+LINE_BUDGET = 4096  # bytes of the ONE stdout line (round 4's 21 KB line was not parsed by the driver)
+DTYPE = "f64"  # the arithmetic the path computes in: fp64 warp, moments and gradient sums (planes are f32, votes 64-bit fixed point)
+DTYPE_NOTE = ("f64 warp; votes in 64-bit 2^-30 fixed point (LDS) -> f32 planes; f32 blur (f64-accumulated adjoint operator); f64 moments "
+              "and gradient sums")
+
+
+def plan_launch(gpus, world_env, n_devices, single_process=False, group_devices=None):
+    """Which form of the bench a command line asks for -- pure logic, tested on the CPU (tests/test_bench_helpers.py).
+
+      world_env > 1            : launched by torch.distributed.run -> one process per GPU ("ranks"); n_gpus = the world size
+      --group-devices a,b,...  : one process, a group handle over exactly those members ("group")
+      --gpus N > 1, no launcher: one process, a group over devices 0..N-1 ("group") and the process-per-GPU form self-spawned
+                                 as a nested leg (spawn = N); with fewer visible devices than N: whatever is there (one device =
+                                 config 4's slab on a plain context), n_gpus = what ran, `error` says so, nothing spawned
+      otherwise                : the single-GPU line ("single")."""
+    if world_env > 1:
+        err = None if gpus in (1, world_env) else "--gpus %d ignored: launched with WORLD_SIZE=%d" % (gpus, world_env)
+        return {"form": "ranks", "devices": None, "n_gpus": world_env, "spawn": 0, "error": err}
+    if group_devices:
+        devs = [int(d) for d in group_devices]
+        bad = [d for d in devs if d < 0 or d >= max(n_devices, 0)]
+        if bad:
+            return {"form": "none", "devices": [], "n_gpus": 0, "spawn": 0,
+                    "error": "--group-devices names device(s) %s; %d visible" % (bad, n_devices)}
+        return {"form": "group", "devices": devs, "n_gpus": len(set(devs)), "spawn": 0, "error": None}
+    if n_devices <= 0:
+        return {"form": "none", "devices": [], "n_gpus": 0, "spawn": 0, "error": "no HIP device visible"}
+    if gpus > 1 or single_process:
+        if n_devices >= gpus:
+            return {"form": "group" if gpus > 1 else "single", "devices": list(range(gpus)) if gpus > 1 else None, "n_gpus": gpus,
+                    "spawn": 0 if single_process or gpus == 1 else gpus, "error": None}
+        return {"form": "group", "devices": list(range(n_devices)), "n_gpus": n_devices, "spawn": 0,
+                "error": "--gpus %d requested, %d device(s) visible: ran on %d" % (gpus, n_devices, n_devices)}
+    return {"form": "single", "devices": None, "n_gpus": 1, "spawn": 0, "error": None}
+
+
+def leg_errors(out, path="", acc=None):
+    """Every nested {"error": ...} a leg's try/except left behind, as "path: text" strings: they go into the stdout line."""
+    acc = [] if acc is None else acc
+    if isinstance(out, dict):
+        for k, v in out.items():
+            if k == "error" and isinstance(v, str) and path:
+                acc.append("%s: %s" % (path, v[:120]))
+            elif isinstance(v, (dict, list)):
+                leg_errors(v, (path + "." if path else "") + str(k), acc)
+    elif isinstance(out, list):
+        for i, v in enumerate(out):
+            leg_errors(v, "%s[%d]" % (path, i), acc)
+    return acc
+
+
+def _r(v, sig=5):
+    """Floats to `sig` significant digits (the line is read by a machine; twelve digits of a timer are noise)."""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "hbm_frac")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "ms_per_step", "host")
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config")
+
+
+def compact_line(out, detail_name="bench_detail.json"):
+    """The ONE stdout line: the contract's keys + roofline + cpu_baseline + summary, <= LINE_BUDGET bytes whatever the legs
+    produced (optional parts are dropped in a fixed order until it fits; the contract's keys never are)."""
+    d = {k: out.get(k) for k in CONTRACT_KEYS}
+    cfg = dict(out.get("config") or {})
+    for k, n in (("workload", 200), ("parallelism", 160), ("parameters", 80), ("mode", 60)):
+        if isinstance(cfg.get(k), str):
+            cfg[k] = cfg[k][:n]
+    d["config"] = cfg
+    if "error" in out:
+        d["error"] = str(out["error"])[:300]
+    if isinstance(out.get("roofline"), dict):
+        d["roofline"] = {k: out["roofline"].get(k) for k in ROOFLINE_KEYS if k in out["roofline"]}
+    if isinstance(out.get("cpu_baseline"), dict):
+        d["cpu_baseline"] = {k: out["cpu_baseline"].get(k) for k in CPU_BASELINE_KEYS if k in out["cpu_baseline"]}
+    d["summary"] = summary_of(out)
+    errs = leg_errors({k: v for k, v in out.items() if k != "error"})
+    if errs:
+        d["leg_errors"] = errs[:6]
+    d["detail"] = detail_name
+    d = _r(d)
+    # never over budget: optional parts go first, in this order
+    drop = (("summary", "large_launch_16M_events"), ("summary", "frontend_beside_backend"), ("summary", "process_per_gpu"),
+            ("summary", "backend"), ("leg_errors",), ("cpu_baseline", "host"), ("cpu_baseline", "sample"), ("config", "parameters"),
+            ("config", "parallelism"), ("summary",))
+    for path in drop:
+        if len(json.dumps(d, separators=(",", ":"))) <= LINE_BUDGET:
+            break
+        t = d
+        for k in path[:-1]:
+            t = t.get(k) if isinstance(t, dict) else None
+        if isinstance(t, dict):
+            t.pop(path[-1], None)
+    return json.dumps(d, separators=(",", ":"))
+
+
+def spawn_process_per_gpu(n, args, timeout_s=900):
+    """The process-per-GPU form of the same command as a child job: `python -m torch.distributed.run --nproc-per-node n bench.py
+    --gpus n ...`; returns the child's stdout line (parsed) or {"error": ...}.  Runs after this process has released its contexts."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--mode", args.mode, "--comm", args.comm, "--detail-out", os.path.splitext(args.detail_out)[0] + "_ranks.json"]
+    if args.events:
+        cmd += ["--events", str(args.events)]
+    if args.no_config5:
+        cmd += ["--no-config5"]
+    if args.no_parity:
+        cmd += ["--no-parity"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "process-per-GPU child timed out after %d s" % timeout_s}
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.strip().startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "process-per-GPU child rc %d: %s" % (p.returncode, p.stderr.strip()[-300:])}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "process-per-GPU child line did not parse: %s" % e}
 
 
 def line(m, world, args, name, n_total, img, comm_used, mode_desc):
     out = {
         "metric": METRIC, "value": m["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 warp; votes in 64-bit 2^-30 fixed point (LDS) -> f32 planes; f32 blur (f64-accumulated adjoint operator); f64 moments and gradient sums", "data": "synthetic",
+        "dtype": DTYPE, "dtype_note": DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": name, "events_total": int(n_total), "image": img, "evaluation": "cost+gradient (fdf)", "mode": mode_desc,
                    "parameters": "cycled through %d points of a recorded FR-CG solve" % m["trajectory_points"],
                    "parallelism": ("events sharded by contiguous batch range (time slab) x%d, all-reduce of the partial planes + partial "
@@ -1161,6 +1387,9 @@ def main():
                     help="--single-process with an explicit member list, e.g. 0,0 = two members sharing device 0 (how a one-GPU box "
                          "exercises the group path end to end)")
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip per_window / launch_defaults / frontend_beside_backend / group")
+    ap.add_argument("--no-spawn", action="store_true", help="plain --gpus N: skip the self-spawned process-per-GPU leg")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where everything that is not on the stdout line goes (JSON)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dry run of the N>1 code path (time slabs, communicator, parity gather) with whatever world size is launched")
     args = ap.parse_args()
@@ -1170,24 +1399,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    group_devices = None
-    if args.single_process or args.group_devices:
-        if world != 1:
-            sys.exit("bench.py --single-process runs in ONE process: launch it without torch.distributed.run")
-        group_devices = [int(d) for d in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
-        args.gpus = len(set(group_devices))
-    elif world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
 
     import torch
     import torch.distributed as dist
     from cmax_slam_amd import _lib
 
+    n_devices = int(_lib.lib().cmx_device_count())
+    plan = plan_launch(args.gpus, world, n_devices, args.single_process,
+                       [int(d) for d in args.group_devices.split(",")] if args.group_devices else None)
+    if plan["form"] == "none":  # nothing can run: still ONE parseable line and exit status 0 (the driver records the reason)
+        out = {"metric": METRIC, "value": 0.0, "unit": "events/s", "n_gpus": 0, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+               "config": {"workload": "none"}, "error": plan["error"]}
+        if rank == 0:
+            emit(out, args)
+        return
+    group_devices = plan["devices"] if plan["form"] == "group" else None
+    if group_devices is not None and len(group_devices) == 1 and args.workload == "auto":
+        args.workload = "backend"  # (--gpus N on a one-GPU box: config 4's slab on the one device, not the N = 1 headline)
+    args.gpus = plan["n_gpus"]
+
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.force_sharded or (group_devices is not None and len(group_devices) > 1)
+    sharded = world > 1 or args.force_sharded or group_devices is not None
     if sharded and group_devices is None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -1274,8 +1508,17 @@ def main():
             out = line(m, len(set(group_devices)) if group_devices else world, args, name, len(w.x) * world, img, run.comm_used, mode_desc)
             if par is not None:
                 out["parity_vs_1gpu"] = par
+            if sharded and "comm" in out:
+                try:  # what the communicator itself says it spans (not what the launcher believes)
+                    ci = ev.comm_info()
+                    out["comm"]["nranks_seen"] = ci["nranks"] if ci["transport"] != "none" else 1
+                    out["comm"]["transport"] = ci["transport"]
+                except Exception as e:
+                    out["comm"]["nranks_seen"] = None
+                    out["comm"]["error"] = repr(e)
             if group_devices:
                 out["group"] = ev.group_info()
+                out["config"]["form"] = "one process, group handle over devices %s" % group_devices
                 if args.solves > 0:
                     out["cmax"] = cmax_solves(max(1, args.solves // 4), ev, "backend", _lib)
             if not sharded and args.solves > 0:
@@ -1302,20 +1545,46 @@ def main():
             except Exception as e:
                 if rank == 0:
                     out["config5"] = {"error": str(e)}
+        if sharded and rank == 0 and not args.no_extras:
+            n_slabs = len(group_devices) if group_devices else world
+            try:
+                out["one_gpu_same_workload"] = one_gpu_same_workload(local_rank, which, n_slabs, per_gpu, pts, args.steps, args.mode)
+            except Exception as e:
+                out["one_gpu_same_workload"] = {"error": repr(e)}
     if sharded and group_devices is None:
         dist.destroy_process_group()
     if rank == 0:
         out.pop("_last", None)
-        out["summary"] = summary_of(out)  # LAST key: a tail of the line still carries the headline figures
-        try:  # whatever native libraries still hold in their C stdio buffers goes where stdout currently points: stderr
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        if _STDOUT_FD is not None:
-            os.dup2(_STDOUT_FD, 1)  # the real stdout back: it carries the ONE JSON line and nothing else
-        print(json.dumps(out), flush=True)
+        if plan["error"]:
+            out["error"] = plan["error"]
+        if plan["spawn"] > 1 and not args.no_spawn:
+            # the process-per-GPU form of the same command (one rank per device over RCCL), as a child job now that this process holds no context
+            child = spawn_process_per_gpu(plan["spawn"], args)
+            out["process_per_gpu"] = child
+        emit(out, args)
+
+
+def emit(out, args):
+    """Detail -> bench_detail.json (+ one stderr line); the compact line -> the real stdout, and nothing else there."""
+    detail_name = os.path.basename(args.detail_out)
+    out["summary"] = summary_of(out)
+    try:
+        with open(args.detail_out, "w") as f:
+            json.dump(out, f)
+    except OSError as e:
+        detail_name = "stderr (%s)" % e
+    text = compact_line(out, detail_name)
+    try:  # whatever native libraries still hold in their C stdio buffers goes where stdout currently points: stderr
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    sys.stderr.write("bench detail: " + json.dumps(out) + "\n")
+    sys.stderr.flush()
+    if _STDOUT_FD is not None:
+        os.dup2(_STDOUT_FD, 1)  # the real stdout back: it carries the ONE JSON line and nothing else
+    print(text, flush=True)
 
 
 _STDOUT_FD = None

@@ -70,6 +70,8 @@ SYMBOLS = {
     "cmx_backend_get_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
     "cmx_backend_set_map": (C.c_int, [ctx_p, c_fp, C.POINTER(C.c_uint8)]),
     "cmx_events_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_size_t]),
+    "cmx_events_create_group": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_size_t]),
+    "cmx_events_devices": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "cmx_events_destroy": (None, [C.c_void_p]),
     "cmx_events_last_error": (C.c_char_p, [C.c_void_p]),
     "cmx_events_push": (C.c_int, [C.c_void_p, C.c_int64, c_u16p, c_u16p, c_i64p]),
@@ -100,6 +102,7 @@ SYMBOLS = {
     "cmx_comm_attach": (C.c_int, [ctx_p, C.c_char_p, C.c_int, C.c_int]),
     "cmx_comm_detach": (C.c_int, [ctx_p]),
     "cmx_comm_attach_custom": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "cmx_comm_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cmx_frontend_solve": (C.c_int, [ctx_p, c_dp, C.c_void_p]),
     "cmx_backend_solve": (C.c_int, [ctx_p, C.c_int, c_dp, C.c_void_p]),
     "cmx_frcg_minimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dp, C.c_double, C.c_double,

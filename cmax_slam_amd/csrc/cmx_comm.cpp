@@ -13,6 +13,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
@@ -30,6 +32,8 @@ RcclApi &rccl() {
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+    a.CommCount = (decltype(a.CommCount))dlsym(a.handle, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.handle, "ncclCommUserRank");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
     return a;
@@ -257,6 +261,26 @@ int cmx_comm_detach(cmx_ctx *c) {
   c->comm_size = 1;
   c->comm_rank = 0;
   comm_reset_xset(c);
+  return CMX_OK;
+}
+int cmx_comm_info(cmx_ctx *c, int *rank, int *nranks, int *transport) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  int r = 0, n = 1, t = 0;
+  if (c->comm) {
+    t = 1;
+    r = c->comm_rank;
+    n = c->comm_size;
+    // the live communicator's own view (a mismatch with what the launcher believes is exactly what a caller wants to see)
+    if (rccl().CommCount && rccl().CommCount(c->comm, &n) != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclCommCount failed");
+    if (rccl().CommUserRank && rccl().CommUserRank(c->comm, &r) != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclCommUserRank failed");
+  } else if (c->comm_fn) {
+    t = 2;
+    r = c->comm_rank;
+    n = c->comm_size;
+  }
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
+  if (transport) *transport = t;
   return CMX_OK;
 }
 int cmx_comm_attach_custom(cmx_ctx *c, cmx_allreduce_fn fn, void *user, int rank, int nranks) {

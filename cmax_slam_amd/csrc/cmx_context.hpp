@@ -260,15 +260,30 @@ struct cmx_ctx {
 // device-resident event store: the stream is uploaded once; packets and windows are
 // cut from it on the device
 struct cmx_events {
-  int device = 0, W = 0, H = 0;
+  int device = 0, W = 0, H = 0;  // device = the first replica's
   size_t capacity = 0;
   int64_t first_index = 0;   // global sequence number of slot 0
   size_t size = 0;           // events held
-  uint32_t *d_xy[2] = {nullptr, nullptr};  // x | y << 16 ; two buffers: drop_before compacts into the other one
-  int64_t *d_t[2] = {nullptr, nullptr};
+  // One replica of the stream per device (cmx_events_create: one; cmx_events_create_group: one per DISTINCT device of a
+  // group's member list -- 40M events x 12 B is nothing in 288 GB, and every member cuts its own batch range on its own device).
+  struct Replica {
+    int device = 0;
+    uint32_t *d_xy[2] = {nullptr, nullptr};  // x | y << 16 ; two buffers: drop_before compacts into the other one
+    int64_t *d_t[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;            // uploads / compactions of the replicas run side by side
+  };
+  std::vector<Replica> rep;
   int cur = 0;
+  uint32_t *h_xy = nullptr;  // pinned staging of a push (packed coordinates, then the timestamps): one host pass, N async uploads
+  int64_t *h_tp = nullptr;
+  size_t stage_cap = 0;
   std::vector<int64_t> h_t;  // host mirror of the timestamps (per-batch pose times are formed on the host)
   std::string err;
+  const Replica *on(int dev) const {
+    for (const Replica &r : rep)
+      if (r.device == dev) return &r;
+    return nullptr;
+  }
 };
 
 
@@ -389,6 +404,9 @@ int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16
                      const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
                      int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
 int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *grad);
+int group_set_window_from(cmx_ctx *leader, const cmx_events *e, int64_t first, int64_t count, int order, int K, const double *knots_xyzw,
+                          int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size,
+                          int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
 int be_eval_one(cmx_ctx *c, const double *drotv, double *contrast, double *grad);  // cmx_backend.cpp: one context's evaluation
 #define CMX_NOT_FOR_GROUPS(c, what) \
   do { if ((c) && (c)->group) return fail((c), CMX_ERR_STATE, what " is not available on a group (the group runs its own exchange)"); } while (0)

@@ -383,6 +383,35 @@ int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16
   return rc;
 }
 
+int group_member_window_from(cmx_ctx *m, const cmx_events *e, int64_t first, int64_t beg, int64_t end, int order, int K,
+                             const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                             int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);  // cmx_events.cpp
+
+int group_set_window_from(cmx_ctx *leader, const cmx_events *e, int64_t first, int64_t count, int order, int K, const double *knots_xyzw,
+                          int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size,
+                          int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG) {
+  cmx_group *g = leader->group;
+  const int N = g->n;
+  if (!e) return fail(leader, CMX_ERR_INVALID_ARG, "null event store");
+  for (int r = 0; r < N; r++)
+    if (!e->on(g->m[r]->device))
+      return fail(leader, CMX_ERR_INVALID_ARG, "the event store holds no replica on device %d (member %d): create it with cmx_events_create_group",
+                  g->m[r]->device, r);
+  const bool shardable = count > 0 && event_batch_size > 0;
+  const int rc = group_all(leader, [&](cmx_ctx *m, int r) {
+    int64_t beg = 0, end = (r == 0) ? count : 0;
+    if (shardable) {
+      batch_range(count, event_batch_size, r, N, &beg, &end);
+      if (end > beg && end < count) end += 1;  // (group_set_window: the member's last batch is a whole one, the extra event is in none of its batches)
+    }
+    return group_member_window_from(m, e, first, beg, end, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns,
+                                    event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
+  });
+  if (rc)
+    for (int r = 0; r < N; r++) g->m[r]->have_data = false;
+  return rc;
+}
+
 int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *grad) {
   cmx_group *g = leader->group;
   const int P = 3 * (leader->K - leader->num_fixed);

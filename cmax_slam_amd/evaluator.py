@@ -171,6 +171,12 @@ class _Evaluator:
     def comm_detach(self):
         self._ck(self._L.cmx_comm_detach(self._ctx))
 
+    def comm_info(self):
+        """{'rank', 'nranks', 'transport'} as the attached communicator itself reports them (cmx_comm_info)."""
+        r, n, t = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.cmx_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(t)))
+        return {"rank": r.value, "nranks": n.value, "transport": ("none", "rccl", "custom/direct")[t.value]}
+
     def set_grad_buffer(self, device_ptr, n_doubles):
         self._ck(self._L.cmx_set_grad_buffer(self._ctx, C.c_void_p(device_ptr), int(n_doubles)))
 
@@ -239,10 +245,22 @@ class EventStore:
     """Device-resident copy of the event stream (the reference's AngVelEstimator::events_): push chunks as they
     arrive, cut packets / windows from it by global event index, drop the prefix like deleteOldEvents."""
 
-    def __init__(self, W, H, capacity, device=0):
+    def __init__(self, W, H, capacity, device=0, devices=None):
+        """devices = [d0, d1, ...] (a group's member list): one replica of the stream on every distinct device
+        (cmx_events_create_group); a group handle over the same list cuts its windows from it member by member."""
         self._L = _lib.lib()
         self._h = C.c_void_p()
-        check(None, self._L.cmx_events_create(C.byref(self._h), int(device), int(W), int(H), int(capacity)))
+        if devices is None:
+            check(None, self._L.cmx_events_create(C.byref(self._h), int(device), int(W), int(H), int(capacity)))
+        else:
+            dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+            check(None, self._L.cmx_events_create_group(C.byref(self._h), dv, len(devices), int(W), int(H), int(capacity)))
+
+    @property
+    def devices(self):
+        dv = (C.c_int * 16)()
+        n = self._L.cmx_events_devices(self._h, dv, 16)
+        return list(dv[:n])
 
     def _ck(self, status):
         if status != _lib.OK:

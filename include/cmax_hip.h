@@ -278,9 +278,16 @@ int64_t cmx_traj_temp_start_ns(double t_beg, int idx_traj_beg, double dt_knots);
  * cmx_events_drop_before is deleteOldEvents (ang_vel_estimator.cpp:149-173).  Results are identical to
  * cmx_frontend_set_packet / cmx_backend_set_window on the same events.  One store per GPU, shared by the front-end and
  * back-end contexts of that GPU; not thread-safe (serialise push/drop against set_*_from, as the reference does with
- * mutex_events). */
+ * mutex_events).
+ * cmx_events_create_group: ONE store with a replica of the stream on every distinct device of a group's member list (the list
+ * given to cmx_backend_create_group): cmx_events_push packs once on the host and uploads to all replicas side by side,
+ * cmx_events_drop_before compacts all of them, cmx_backend_set_window_from on the group's handle lets every member cut ITS
+ * batch range on its own device (no event crosses the host at hand-over), and any front-end / back-end context on one of
+ * those devices can cut from it too.  cmx_events_devices lists the replicas' devices (returns their number). */
 typedef struct cmx_events cmx_events;
 int cmx_events_create(cmx_events **out, int device, int W, int H, size_t capacity);
+int cmx_events_create_group(cmx_events **out, const int *devices, int n_devices, int W, int H, size_t capacity);
+int cmx_events_devices(const cmx_events *ev, int *devices, int max_devices);
 void cmx_events_destroy(cmx_events *ev);
 const char *cmx_events_last_error(const cmx_events *ev);
 int cmx_events_push(cmx_events *ev, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns);
@@ -353,6 +360,10 @@ enum { CMX_DT_U8 = 0, CMX_DT_F32 = 1, CMX_DT_F64 = 2 };
 enum { CMX_OP_SUM = 0, CMX_OP_MAX = 1 };
 typedef int (*cmx_allreduce_fn)(void *user, void *device_buf, size_t count, int dtype, int op, void *hip_stream);
 int cmx_comm_attach_custom(cmx_ctx *ctx, cmx_allreduce_fn fn, void *user, int rank, int nranks);
+/* What is attached, AS THE COMMUNICATOR ITSELF REPORTS IT: *transport = 0 none, 1 RCCL (rank / nranks from ncclCommUserRank /
+ * ncclCommCount of the live communicator -- not the numbers passed at attach), 2 caller-supplied or a group's direct transport
+ * (the numbers given at attach).  On a group handle: member 0's communicator.  Any pointer may be NULL. */
+int cmx_comm_info(cmx_ctx *ctx, int *rank, int *nranks, int *transport);
 
 /* ------------------------------------------------------------------ one-process multi-GPU: a GROUP ---------
  * The reference's host is ONE process with ONE back-end thread and ONE GSL instance (src/cmax_slam.cpp:92,
@@ -366,7 +377,8 @@ int cmx_comm_attach_custom(cmx_ctx *ctx, cmx_allreduce_fn fn, void *user, int ra
  * (each keeps its own replica of IG); cmx_backend_get_plane / get_alpha / get_map / cmx_get_stats read member 0.  The caller
  * stays single-threaded; the group owns one worker thread per further member (queueing eight devices' launches from one
  * thread would take longer than the evaluation runs).  Not available on a group: the split-phase interface, caller-owned
- * buffers / streams, cmx_comm_attach*, cmx_backend_set_window_from, cmx_backend_eval_many.
+ * buffers / streams, cmx_comm_attach*, cmx_backend_eval_many.  cmx_backend_set_window_from works on a group when the store was
+ * created with cmx_events_create_group over the same devices.
  *   transport: CMX_GROUP_RCCL  -- ncclCommInitAll, one communicator per member (devices must be distinct);
  *              CMX_GROUP_DIRECT -- peer-to-peer reduce-scatter + all-gather kernels over the members' own buffers, ordered by
  *                                  HIP events (needs peer access between the devices; the only form for members that share
@@ -470,8 +482,9 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes
  * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added;
- *  4: groups, cmx_backend_get_pose_table, stream priority / CU mask) */
-#define CMX_ABI_VERSION 4
+ *  4: groups, cmx_backend_get_pose_table, stream priority / CU mask;
+ *  5: cmx_comm_info; the event store behind a group (cmx_events_create_group, cmx_backend_set_window_from on a group)) */
+#define CMX_ABI_VERSION 5
 int cmx_abi_version(void);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);

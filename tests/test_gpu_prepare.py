@@ -118,7 +118,7 @@ def test_tiny_image_sigma_change_keeps_the_operator_tables_consistent(hip, oracl
 
 def test_stats_take_their_length(hip):
     import ctypes as C
-    assert _lib.lib().cmx_abi_version() == 4
+    assert _lib.lib().cmx_abi_version() == 5
     p = synth.frontend_packet(1_000, 64, 48, 60.0, 60.0, 31.5, 23.5, seed=1)
     fe = _fe(hip, p)
     fe.eval(np.zeros(3))
