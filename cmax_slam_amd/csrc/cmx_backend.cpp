@@ -153,7 +153,10 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     else
       HIP_TRY(c, hipMemcpyAsync(c->d_xy, xy, (size_t)n_packed_total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   }
-  if (nb && !d_raw) HIP_TRY(c, hipMemcpy(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice));
+  // (on the context's stream, not the null stream: a masked stream -- cmx_set_cu_mask -- is a BLOCKING stream, and a null-stream
+  //  copy would serialise this hand-over against every other context's null-stream work on the device; `bt` lives until the
+  //  synchronisation at the end of this function)
+  if (nb && !d_raw) HIP_TRY(c, hipMemcpyAsync(c->d_batch_t, bt.data(), (size_t)nb * sizeof(long long), hipMemcpyHostToDevice, c->stream));
   if (nb && d_raw) {  // batch times + their validation on the device; the two error words come back with the final sync
     if (!c->d_batch_err) HIP_TRY(c, hipMalloc((void **)&c->d_batch_err, 2 * sizeof(long long)));
     long long *d_err = c->d_batch_err;
@@ -183,7 +186,8 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (nb && d_raw) {
     long long e[2] = {0, 0};
-    HIP_TRY(c, hipMemcpy(e, c->d_batch_err, sizeof(e), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(e, c->d_batch_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (e[0] == CMX_ERR_TIME_ORDER) return fail(c, CMX_ERR_TIME_ORDER, "batch at event %lld spans a negative time interval", e[1]);
     if (e[0] == CMX_ERR_SPLINE_RANGE)
       return fail(c, CMX_ERR_SPLINE_RANGE, "batch time %lld ns outside the support of %d knots (start %lld, dt %lld)", e[1], K,
@@ -244,6 +248,11 @@ static int be_prepare_one(cmx_ctx *c, const double *drotv_hint) {
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
   int rc = bind_device(c);
   if (rc) return rc;
+  // whatever this call goes on to do, the resident pose table / image no longer stand for "the last evaluation's point" -- cleared
+  // BEFORE the early return: a group member whose shard is empty must take the same decision (recompute + exchange) as its peers
+  // in the next evaluation, or the collectives no longer match
+  c->x_valid = false;
+  c->jt_valid = false;
   if (c->splat_mode != 1 || !adjoint_ok(c) || c->n_packed <= 0) return CMX_OK;
   std::vector<double> zero((size_t)3 * (c->K - c->num_fixed > 0 ? c->K - c->num_fixed : 1), 0.0);
   be_update_knots(c, drotv_hint ? drotv_hint : zero.data());
@@ -541,29 +550,41 @@ int cmx_backend_get_plane(cmx_ctx *c, int which, float *host) {
   return sync_and_collect(c);
 }
 
-int cmx_backend_get_pose_table(cmx_ctx *c, int max_batches, double *R, float *Jcp, int *idx, int64_t *t_batch_ns, int *n_batches) {
-  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
-  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
-  if (max_batches < 0) return fail(c, CMX_ERR_INVALID_ARG, "bad row count");
+// One context's rows, computed into SCRATCH tables from a COPY of the spline description: neither the live pose table (the tile
+// sort of a prepared window was built on it) nor h_spline (a prepare may have moved it to its hint) is touched.  The knots are
+// those of the last evaluation (last_x), or zero increments before the first one of the window.
+static int be_pose_table_rows(cmx_ctx *c, int max_batches, double *R, float *Jcp, int *idx, int64_t *t_batch_ns, int *n_rows) {
   int rc = bind_device(c);
   if (rc) return rc;
-  if (n_batches) *n_batches = c->nb;
   const int n = c->nb < max_batches ? c->nb : max_batches;
+  *n_rows = n;
   if (n <= 0) return CMX_OK;
-  if (!c->accumulated) {  // no evaluation yet in this window: the table at zero increments
-    std::vector<double> zero((size_t)3 * (c->K - c->num_fixed > 0 ? c->K - c->num_fixed : 1), 0.0);
-    be_update_knots(c, zero.data());
+  SplineArgs sp = *c->h_spline;
+  for (int i = 0; i < c->K; i++) {
+    Quat q = c->knots0[(size_t)i];
+    if (c->accumulated && i >= c->num_fixed) {
+      const double *d = c->last_x + 3 * (i - c->num_fixed);
+      q = q_mul(so3_exp(d[0], d[1], d[2]), q);
+    }
+    sp.knots[i] = q;
   }
-  // the same launch an evaluation issues (h_spline holds the knots of the last one), Jacobians included
-  launch_be_pose_table(*c->h_spline, c->d_batch_t, c->nb, c->order, true, c->d_poseR, c->d_poses, c->stream);
-  HIP_TRY(c, hipGetLastError());
+  PoseR *d_r = nullptr;
+  PoseEntry *d_e = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_r, (size_t)c->nb * sizeof(PoseR)));
+  if (hipMalloc((void **)&d_e, (size_t)c->nb * sizeof(PoseEntry)) != hipSuccess) { (void)hipFree(d_r); return fail(c, CMX_ERR_HIP, "hipMalloc failed"); }
+  // the same launch an evaluation issues, Jacobians included
+  launch_be_pose_table(sp, c->d_batch_t, c->nb, c->order, true, d_r, d_e, c->stream);
   std::vector<PoseR> hr((size_t)n);
   std::vector<PoseEntry> he((size_t)n);
   std::vector<long long> ht((size_t)n);
-  HIP_TRY(c, hipMemcpyAsync(hr.data(), c->d_poseR, (size_t)n * sizeof(PoseR), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(he.data(), c->d_poses, (size_t)n * sizeof(PoseEntry), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(ht.data(), c->d_batch_t, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(hr.data(), d_r, (size_t)n * sizeof(PoseR), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(he.data(), d_e, (size_t)n * sizeof(PoseEntry), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ht.data(), c->d_batch_t, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_r);
+  (void)hipFree(d_e);
+  if (e != hipSuccess) return fail(c, CMX_ERR_HIP, "pose-table read-back failed: %s", hipGetErrorString(e));
   for (int b = 0; b < n; b++) {
     if (R) memcpy(R + (size_t)9 * b, hr[(size_t)b].R, 9 * sizeof(double));
     if (Jcp) memcpy(Jcp + (size_t)36 * b, he[(size_t)b].Jcp, 36 * sizeof(float));
@@ -571,6 +592,36 @@ int cmx_backend_get_pose_table(cmx_ctx *c, int max_batches, double *R, float *Jc
     if (t_batch_ns) t_batch_ns[b] = (int64_t)ht[(size_t)b];
   }
   return CMX_OK;
+}
+int cmx_backend_get_pose_table(cmx_ctx *c, int max_batches, double *R, float *Jcp, int *idx, int64_t *t_batch_ns, int *n_batches) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_backend_set_window has not succeeded");
+  if (max_batches < 0) return fail(c, CMX_ERR_INVALID_ARG, "bad row count");
+  if (!is_group(c)) {
+    if (n_batches) *n_batches = c->nb;
+    int n = 0;
+    return be_pose_table_rows(c, max_batches, R, Jcp, idx, t_batch_ns, &n);
+  }
+  // a group: the members' rows one after the other ARE the window's batches (every member holds whole batches of it, in order);
+  // a diagnostic call: the members are read one at a time from the calling thread
+  int total = 0, written = 0;
+  cmx_ctx *members[64];
+  const int nm = group_members(c, members, 64);
+  for (int r = 0; r < nm; r++) total += members[r]->nb;
+  if (n_batches) *n_batches = total;
+  for (int r = 0; r < nm && written < max_batches; r++) {
+    int n = 0;
+    const int rc = be_pose_table_rows(members[r], max_batches - written, R ? R + (size_t)9 * written : nullptr,
+                                      Jcp ? Jcp + (size_t)36 * written : nullptr, idx ? idx + written : nullptr,
+                                      t_batch_ns ? t_batch_ns + written : nullptr, &n);
+    if (rc) {
+      if (r) c->err = members[r]->err;
+      (void)bind_device(c);
+      return rc;
+    }
+    written += n;
+  }
+  return bind_device(c);
 }
 
 int cmx_backend_get_alpha(cmx_ctx *c, double *alpha) {

@@ -10,6 +10,7 @@
 // plain global-atomic path -- the result is exact for any parameters, only the speed depends on the binning.
 // The sort is a counting sort (below); the (key, index) radix-sort kernels at the top of the file are its fallback for
 // panoramas with more than 16 400 destination-tile keys.  The sorted order also carries per-event bearing / dt streams.
+#include <mutex>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -234,14 +235,21 @@ size_t count_sort_scratch_ints(int n, int nbins) {  // [bin totals | slices x bi
   bin_grid(n, blocks, per_block);
   return (size_t)nbins * (size_t)(blocks + 1);
 }
+// (per DEVICE: a group's members sit on several devices of one process and launch from concurrent worker threads -- the attribute
+//  is set once on each device, behind that device's own once-flag)
 static void allow_big_lds() {  // 16400 bins x 4 B is just above the 64 KB default of dynamic LDS
-  static bool done = false;
-  if (done) return;
-  const int bytes = kCountSortMaxBins * (int)sizeof(int);
-  hipFuncSetAttribute((const void *)fe_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  hipFuncSetAttribute((const void *)be_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  hipFuncSetAttribute((const void *)scatter_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done = true;
+  constexpr int kMaxDev = 64;
+  static std::once_flag done[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  auto set = [] {
+    const int bytes = kCountSortMaxBins * (int)sizeof(int);
+    hipFuncSetAttribute((const void *)fe_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipFuncSetAttribute((const void *)be_bin_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipFuncSetAttribute((const void *)scatter_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  };
+  if (dev < kMaxDev) std::call_once(done[dev], set);
+  else set();
 }
 // keys: n u32 scratch; scratch: count_sort_scratch_ints(n, nbins) ints (contents irrelevant); tile_start: nbins + 1 ints
 void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x, int ntiles_img, const uint32_t *xy,

@@ -84,17 +84,49 @@ static int ensure_xset(cmx_ctx *c, size_t ntiles) {
   c->xset_n = -1;  // (whatever set was known lived in the old buffers)
   return CMX_OK;
 }
+// Sum of `count` floats across the ranks, staged: `in` is this rank's packed contribution, *result is where the sum is afterwards.
+// RCCL and a group's direct transport are out of place (in -> out: nobody writes a buffer a peer may be reading, so the direct
+// transport needs ONE host barrier and one set of event waits per collective, cmx_group.cpp); a caller-supplied all-reduce is in place.
+static int comm_allreduce_staged(cmx_ctx *c, float *in, float *out, size_t count, float **result) {
+  *result = in;
+  if (!c->sharded() || count == 0) return CMX_OK;
+  if (c->comm_fn && !c->comm_fn_oop) return comm_allreduce(c, in, count, CMX_DT_F32);
+  c->comm_bytes_eval += (int64_t)count * 4;
+  c->comm_calls_eval++;
+  Span sp(c, CMX_T_COMM);
+  *result = out;
+  if (c->comm_fn_oop) {
+    const int r = c->comm_fn_oop(c->comm_user, in, out, count, (void *)c->stream);
+    if (r != 0) return fail(c, CMX_ERR_HIP, "the group's one-shot all-reduce failed with status %d", r);
+    return CMX_OK;
+  }
+  const ncclResult_t r = rccl().AllReduce(in, out, count, ncclFloat, ncclSum, c->comm, c->stream);
+  if (r != ncclSuccess) return fail(c, CMX_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(r));
+  return CMX_OK;
+}
 // both planes' tiles of `list` (and, with `flags`, the occupancy map as floats behind them) -> staging -> ONE all-reduce -> back
 static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *flags, int ntiles) {
   if (n <= 0 && !flags) return CMX_OK;
   const size_t np = (size_t)c->Wp * c->Hp;
   const size_t need = (size_t)2 * (n > 0 ? n : 0) * kTileX * kTileY + (flags ? (size_t)ntiles : 0);
-  int rc = ensure(c, c->d_xstage, c->xstage_cap, need);
+  const bool oop = c->comm_fn_oop || (c->comm && !c->comm_fn);
+  // out-of-place transports: the buffers are sized ONCE for the largest set this panorama can produce (every tile of both planes + the
+  // map) -- a peer of the one-shot transport may still be reading the previous collective's send buffer, which must never be freed under it
+  const size_t cap = oop ? 2 * np + (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY) : need;
+  int rc = ensure(c, c->d_xstage, c->xstage_cap, cap > need ? cap : need);
+  if (!rc && oop) rc = ensure(c, c->d_xstage_b, c->xstage_b_cap, cap);
+  if (!rc && oop) rc = ensure(c, c->d_xstage_out, c->xstage_out_cap, cap);
   if (rc) return rc;
-  launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, c->d_xstage, flags, ntiles, c->stream);
-  rc = comm_allreduce(c, c->d_xstage, need, CMX_DT_F32);
+  float *in = c->d_xstage;
+  if (oop) {
+    c->xstage_sel ^= 1;
+    in = c->xstage_sel ? c->d_xstage_b : c->d_xstage;
+  }
+  launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, in, flags, ntiles, c->stream);
+  float *sum = in;
+  rc = comm_allreduce_staged(c, in, c->d_xstage_out, need, &sum);
   if (rc) return rc;
-  launch_xset_copy(true, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, c->d_xstage, flags, ntiles, c->stream);
+  launch_xset_copy(true, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, sum, flags, ntiles, c->stream);
   HIP_TRY(c, hipGetLastError());
   return CMX_OK;
 }

@@ -1,5 +1,8 @@
 // cmx_context.cpp -- context life cycle, options, timing and error text of the C ABI (include/cmax_hip.h), plus the
 // host-side helpers every entry point shares.  All compute is in cmx_kernels.hip / cmx_binning.hip.
+#include <condition_variable>
+#include <mutex>
+
 #include "cmx_context.hpp"
 
 int fail(cmx_ctx *c, int code, const char *fmt, ...) {
@@ -327,7 +330,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_My);
   hipFree(c->d_gpartials);
   hipFree(c->d_tflags); hipFree(c->d_tflags_alt); hipFree(c->d_igp_flags);
-  hipFree(c->d_xlist[0]); hipFree(c->d_xlist[1]); hipFree(c->d_xmember[0]); hipFree(c->d_xmember[1]); hipFree(c->d_xmiss); hipFree(c->d_xstage);
+  hipFree(c->d_xlist[0]); hipFree(c->d_xlist[1]); hipFree(c->d_xmember[0]); hipFree(c->d_xmember[1]); hipFree(c->d_xmiss); hipFree(c->d_xstage); hipFree(c->d_xstage_b); hipFree(c->d_xstage_out);
   hipFree(c->d_tile_list); hipFree(c->d_tile_count);
   hipFree(c->d_vparts);
   hipFree(c->d_tail_counters);
@@ -374,7 +377,10 @@ static int set_option_one(cmx_ctx *c, int key, int value) {
       c->x_valid = false;  // a resident image of the other mode is not reused
       return CMX_OK;
     case CMX_OPT_SPIN_WAIT:
+      if (value < 0 || value > 1000000) return fail(c, CMX_ERR_INVALID_ARG, "bad spin budget %d", value);
       c->ticket_wait = value != 0;
+      c->spin_eval_us = value == 1 ? -1 : value;  // 1: an evaluation is waited for on its ticket however long it runs
+      c->spin_idle_us = value == 1 ? 50 : value;  // threads with nothing on the device give their core back after 50 us by default
       return CMX_OK;
     case CMX_OPT_TAIL_FINALIZE:
       c->tail_finalize = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -463,6 +469,10 @@ constexpr int kSchedDevices = 64;
 constexpr long long kUrgentLingerNs = 20000, kYieldCapNs = 5000000;
 std::atomic<int> g_urgent_active[kSchedDevices];
 std::atomic<long long> g_urgent_last_end_ns[kSchedDevices];
+// a background context that has spun for its idle budget sleeps here until the urgent burst ends (or its starvation guard expires)
+std::mutex g_urgent_mu[kSchedDevices];
+std::condition_variable g_urgent_cv[kSchedDevices];
+std::atomic<int> g_urgent_sleepers[kSchedDevices];
 long long sched_now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -472,25 +482,39 @@ UrgentScope::UrgentScope(cmx_ctx *ctx) : c((ctx && ctx->sched_class > 0 && ctx->
 }
 UrgentScope::~UrgentScope() {
   if (!c) return;
-  g_urgent_last_end_ns[c->device].store(sched_now_ns(), std::memory_order_release);
-  g_urgent_active[c->device].fetch_sub(1, std::memory_order_acq_rel);
+  const int d = c->device;
+  g_urgent_last_end_ns[d].store(sched_now_ns(), std::memory_order_release);
+  if (g_urgent_active[d].fetch_sub(1, std::memory_order_seq_cst) == 1 && g_urgent_sleepers[d].load(std::memory_order_seq_cst) > 0) {
+    std::lock_guard<std::mutex> lk(g_urgent_mu[d]);
+    g_urgent_cv[d].notify_all();
+  }
 }
 void yield_to_urgent(cmx_ctx *c) {
   if (!c || c->sched_class >= 0 || c->device < 0 || c->device >= kSchedDevices) return;
   const int d = c->device;
+  const long long spin_ns = (long long)c->spin_idle_us * 1000;
   long long t0 = 0;
   for (unsigned spins = 0;; spins++) {
     if (g_urgent_active[d].load(std::memory_order_acquire) == 0) {
       const long long last = g_urgent_last_end_ns[d].load(std::memory_order_acquire);
       if (last == 0) return;  // no urgent context has ever run on this device
       const long long now = sched_now_ns();
-      if (now - last >= kUrgentLingerNs) return;
+      if (now - last >= kUrgentLingerNs) return;  // (the linger is 20 us: spun through, never slept)
       if (!t0) t0 = now;
       if (now - t0 > kYieldCapNs) return;
-    } else if ((spins & 63u) == 63u) {
+    } else if ((spins & 63u) == 63u || spin_ns == 0) {
       const long long now = sched_now_ns();
       if (!t0) t0 = now;
       if (now - t0 > kYieldCapNs) return;  // never starve: an urgent caller that stays busy gets at most this much in a row
+      if (now - t0 >= spin_ns) {
+        // the burst outlasts the spin budget (a front-end solve is ~0.5 ms): give the core back until it ends
+        std::unique_lock<std::mutex> lk(g_urgent_mu[d]);
+        g_urgent_sleepers[d].fetch_add(1, std::memory_order_seq_cst);
+        g_urgent_cv[d].wait_for(lk, std::chrono::nanoseconds(kYieldCapNs - (now - t0)),
+                                [&] { return g_urgent_active[d].load(std::memory_order_seq_cst) == 0; });
+        g_urgent_sleepers[d].fetch_sub(1, std::memory_order_seq_cst);
+        continue;
+      }
     }
     if (!t0) t0 = sched_now_ns();
     __builtin_ia32_pause();

@@ -188,6 +188,11 @@ struct cmx_ctx {
   unsigned long long ticket_issued = 0;  // ticket of the last finalize launch (see sync_and_collect)
   int ticket_nout = 0;                   // result words that launch writes
   bool ticket_wait = true;
+  // CMX_OPT_SPIN_WAIT, one policy for the three places a host thread waits (include/cmax_hip.h): spin_eval_us = how long an evaluation
+  // spins on its completion ticket before it blocks in hipStreamSynchronize (-1: for as long as it takes, bounded by 20 ms);
+  // spin_idle_us = how long a thread that has NOTHING on the device spins before it sleeps (a group's workers between commands, a
+  // background context held behind an urgent burst)
+  int spin_eval_us = -1, spin_idle_us = 50;
   size_t result_cap = 0;
   double *h_many = nullptr, *d_many = nullptr;  // cmx_*_eval_many: one 4096-double result block per evaluation of the list
   size_t many_cap = 0;
@@ -229,6 +234,9 @@ struct cmx_ctx {
   ncclComm_t comm = nullptr;
   cmx_allreduce_fn comm_fn = nullptr;  // caller-supplied transport (cmx_comm_attach_custom) instead of RCCL
   void *comm_user = nullptr;
+  // internal (cmx_group.cpp's direct transport): out-of-place sum of `count` floats, in -> out, ONE host barrier; consecutive calls
+  // must alternate their `in` buffer (exchange_tiles does)
+  int (*comm_fn_oop)(void *user, const void *in, void *out, size_t count, void *hip_stream) = nullptr;
   int comm_rank = 0, comm_size = 1;
   bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
   // exchange set of the sparse plane exchange (cmx_comm.cpp): the tiles whose partial sums travel.  Two list / membership buffers
@@ -239,6 +247,11 @@ struct cmx_ctx {
   size_t xset_tiles_cap = 0;
   float *d_xstage = nullptr;       // staging of the listed tiles of both planes (what the collective runs on)
   size_t xstage_cap = 0;
+  // out-of-place transports (a group's one-shot direct all-reduce, RCCL): a second send buffer alternating with d_xstage (a peer may
+  // still be reading the previous collective's while the next one is being packed) and the receive buffer the unpack reads
+  float *d_xstage_b = nullptr, *d_xstage_out = nullptr;
+  size_t xstage_b_cap = 0, xstage_out_cap = 0;
+  int xstage_sel = 0;
   int xset_cur = 0, xset_n = -1;   // tiles in [xset_cur]; -1: no set known (first evaluation of a window) -> whole planes
   bool xset_pending = false;       // the last evaluation ran xset_kernel: its words wait in h_result[kXsetSlot..]
   bool xset_used = false;          // ... and exchanged the set (not the whole planes)
@@ -375,7 +388,7 @@ int collect_gated(cmx_ctx *c, int P, double *contrast, double *grad, bool *serve
 bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
-bool spin_for_ticket(const double *h_block, unsigned long long want, int nout);
+bool spin_for_ticket(const double *h_block, unsigned long long want, int nout, int budget_us = -1);
 int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes);  // cmx_frontend.cpp
 // cmx_chain.cpp: run the solve on the device as far as it goes.  `hs` = the host's machine, begun (sm_begin) with x = start;
 // on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
@@ -398,6 +411,7 @@ void yield_to_urgent(cmx_ctx *c);  // first thing of a background context's eval
 // ---- cmx_group.cpp: the entry points of the C ABI hand a group's handle to these
 bool is_group(const cmx_ctx *c);
 int group_size(const cmx_ctx *c);
+int group_members(const cmx_ctx *c, cmx_ctx **out, int max);  // the member contexts in rank order (a plain context: itself); returns their number
 int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn);  // fn(member, rank) on every member; first failure
 void group_destroy(cmx_ctx *leader);
 int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,

@@ -13,8 +13,8 @@
 // enqueue path); eight members queued by one thread would take longer than the ~150 us the evaluation runs for.  So every
 // member but the first has a WORKER thread owned by the group, parked on the group's command word; the calling thread
 // publishes the command, runs member 0 itself, and collects.  Between the calls of a solve the workers spin (hand-over
-// ~0.2 us); after kSpinIdleUs without a command they sleep on a condition variable.  The caller sees a synchronous,
-// single-threaded API.
+// ~0.2 us); after 50 us without a command (CMX_OPT_SPIN_WAIT) they sleep on a condition variable: an idle group holds no core.
+// The caller sees a synchronous, single-threaded API.
 //
 // Transports (what an all-reduce between the members is):
 //   CMX_GROUP_RCCL    ncclCommInitAll over the members' devices, one communicator per member, used from its worker
@@ -37,32 +37,70 @@
 namespace {
 
 constexpr int kMaxMembers = 16;
-constexpr double kSpinIdleUs = 300.0;     // a worker spins this long for the next command before it sleeps
 constexpr double kBarrierTimeoutMs = 20000.0;
 
 // ---- the direct transport's kernels.  ptrs[m] = member m's buffer (same length everywhere); member `me` owns slice `me`.
 struct PeerPtrs { void *p[kMaxMembers]; };
 
+// Every access is ONE 16-byte load / store per lane (global_load_dwordx4): across xGMI a 4-byte access per lane is the worst width
+// there is.  Slices start on 16-byte boundaries (direct_launch); the last (count % (16 / sizeof T)) elements go one by one.
+template <typename T>
+struct alignas(16) Vec16 { T v[16 / sizeof(T)]; };
+template <typename T, bool MAX>
+__device__ inline T red(T a, T b) { return MAX ? (b > a ? b : a) : (T)(a + b); }
+
 template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void peer_reduce_scatter_kernel(PeerPtrs pp, int n, int me, size_t beg, size_t end) {
+  constexpr int L = 16 / sizeof(T);
   T *mine = static_cast<T *>(pp.p[me]);
-  for (size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) {
-    T acc = static_cast<const T *>(pp.p[0])[i];
+  const size_t nv = (end - beg) / L;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    const size_t at = beg + i * L;
+    Vec16<T> acc = *reinterpret_cast<const Vec16<T> *>(static_cast<const T *>(pp.p[0]) + at);
     for (int m = 1; m < n; m++) {  // member order: whoever computes a slice, the bits are the same
-      const T v = static_cast<const T *>(pp.p[m])[i];
-      acc = MAX ? (v > acc ? v : acc) : (T)(acc + v);
+      const Vec16<T> v = *reinterpret_cast<const Vec16<T> *>(static_cast<const T *>(pp.p[m]) + at);
+#pragma unroll
+      for (int k = 0; k < L; k++) acc.v[k] = red<T, MAX>(acc.v[k], v.v[k]);
     }
+    *reinterpret_cast<Vec16<T> *>(mine + at) = acc;
+  }
+  for (size_t i = beg + nv * L + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) {
+    T acc = static_cast<const T *>(pp.p[0])[i];
+    for (int m = 1; m < n; m++) acc = red<T, MAX>(acc, static_cast<const T *>(pp.p[m])[i]);
     mine[i] = acc;
   }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void peer_all_gather_kernel(PeerPtrs pp, int n, int me, size_t per, size_t count) {
+  constexpr int L = 16 / sizeof(T);
   T *mine = static_cast<T *>(pp.p[me]);
   for (int m = 0; m < n; m++) {
     if (m == me) continue;
-    const size_t beg = (size_t)m * per, end = beg + per < count ? beg + per : count;
+    const size_t beg = (size_t)m * per < count ? (size_t)m * per : count, end = beg + per < count ? beg + per : count;
     const T *src = static_cast<const T *>(pp.p[m]);
-    for (size_t i = beg + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) mine[i] = src[i];
+    const size_t nv = (end - beg) / L;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256)
+      *reinterpret_cast<Vec16<T> *>(mine + beg + i * L) = *reinterpret_cast<const Vec16<T> *>(src + beg + i * L);
+    for (size_t i = beg + nv * L + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) mine[i] = src[i];
+  }
+}
+// ONE-SHOT all-reduce of a staged message (every production exchange: the tile set, < 2 MB): every member reads ALL members' send
+// buffers over the whole range and writes the sum, added in member order (the same bits everywhere), to its OWN receive buffer.
+// Nobody writes a buffer a peer reads: one host barrier, one set of event waits, no gather phase (cmx_group.cpp: direct_oneshot).
+__global__ __launch_bounds__(256) void peer_sum_oneshot_kernel(PeerPtrs in, float *__restrict out, int n, size_t count) {
+  const size_t nv = count / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    float4 acc = static_cast<const float4 *>(in.p[0])[i];
+    for (int m = 1; m < n; m++) {
+      const float4 v = static_cast<const float4 *>(in.p[m])[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4 *>(out)[i] = acc;
+  }
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    float acc = static_cast<const float *>(in.p[0])[i];
+    for (int m = 1; m < n; m++) acc += static_cast<const float *>(in.p[m])[i];
+    out[i] = acc;
   }
 }
 
@@ -108,6 +146,8 @@ struct cmx_group {
   int rc[kMaxMembers] = {0};
   std::atomic<int> abort_flag{0};  // a member failed: peers waiting for it in the direct transport give up
   bool quit = false;
+  std::string setup_err;
+  bool ready = false;  // the workers are running: until then (and after a failed set-up) no call may fan out -- nothing would collect it
   std::mutex mu;
   std::condition_variable cv;
   std::atomic<int> sleepers{0};
@@ -115,6 +155,11 @@ struct cmx_group {
   struct DirectUser { cmx_group *g; int rank; } duser[kMaxMembers];
   void *slot_ptr[kMaxMembers] = {nullptr};
   hipEvent_t ev_ready[kMaxMembers] = {nullptr}, ev_rs[kMaxMembers] = {nullptr}, ev_ag[kMaxMembers] = {nullptr};
+  // one-shot (out-of-place) collectives: send pointers and "my send buffer is complete" events, two sets alternating per collective
+  // (a member may publish collective k+1 while a slower peer is still launching collective k)
+  const void *os_in[2][kMaxMembers] = {{nullptr}};
+  hipEvent_t ev_os[2][kMaxMembers] = {{nullptr}};
+  unsigned long long os_seq[kMaxMembers] = {0};
   std::atomic<int> bar_count{0};
   std::atomic<unsigned> bar_gen{0};
   // ---- results of the members of the call in flight
@@ -193,16 +238,43 @@ int direct_allreduce(void *user, void *buf, size_t count, int dt, int op, void *
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// The one-shot form (cmx_ctx::comm_fn_oop; called by member `rank`'s thread, the member's device current).  Per collective: ONE host
+// barrier and n-1 stream waits.  Why that is enough: (1) a member reads the peers' SEND buffers and writes only its own RECEIVE buffer, so
+// no peer ever waits for this member's kernel; (2) the caller alternates two send buffers, and a member's "ready" event of collective
+// k+1 is recorded on its stream behind its kernel of collective k -- whoever has waited for the peers' events of collective k+1 knows
+// that every read of its collective-k send buffer is over before it packs collective k+2 into the same buffer.
+int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hip_stream) {
+  auto *u = static_cast<cmx_group::DirectUser *>(user);
+  cmx_group *g = u->g;
+  const int me = u->rank, n = g->n;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int par = (int)(g->os_seq[me]++ & 1ull);
+  g->os_in[par][me] = in;
+  if (hipEventRecord(g->ev_os[par][me], s) != hipSuccess) return 1;  // my send buffer is complete behind this point
+  if (!group_barrier(g)) return 2;                                   // every pointer published, every event recorded
+  PeerPtrs pp{};
+  for (int k = 0; k < n; k++) {
+    pp.p[k] = const_cast<void *>(g->os_in[par][k]);
+    if (k != me && hipStreamWaitEvent(s, g->ev_os[par][k], 0) != hipSuccess) return 1;
+  }
+  int blocks = (int)((count / 4 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(peer_sum_oneshot_kernel, dim3(blocks), dim3(256), 0, s, pp, static_cast<float *>(out), n, count);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 void worker_loop(cmx_group *g, int rank) {
   unsigned long long seen = 0;
   for (;;) {
     // wait for the next command: spin first (the calls of a solve follow one another within microseconds), then sleep
-    const double t0 = now_us();
-    bool have = false;
-    for (unsigned spins = 0;; spins++) {
+    // (CMX_OPT_SPIN_WAIT: 50 us by default -- the evaluations of a solve follow one another within a few microseconds, and an idle
+    //  group must not hold a core per member; 0: straight to sleep)
+    const double t0 = now_us(), idle_us = (double)g->m[rank]->spin_idle_us;
+    bool have = g->seq.load(std::memory_order_acquire) != seen;
+    for (unsigned spins = 0; !have && idle_us > 0; spins++) {
       if (g->seq.load(std::memory_order_acquire) != seen) { have = true; break; }
       __builtin_ia32_pause();
-      if ((spins & 255u) == 255u && now_us() - t0 > kSpinIdleUs) break;
+      if ((spins & 63u) == 63u && now_us() - t0 > idle_us) break;
     }
     if (!have) {
       std::unique_lock<std::mutex> lk(g->mu);
@@ -239,11 +311,21 @@ void batch_range(int64_t n, int B, int rank, int world, int64_t *beg, int64_t *e
 
 bool is_group(const cmx_ctx *c) { return c && c->group && c->group_rank == 0; }
 int group_size(const cmx_ctx *c) { return (c && c->group) ? c->group->n : 1; }
+int group_members(const cmx_ctx *c, cmx_ctx **out, int max) {
+  if (!c) return 0;
+  if (!c->group) { if (max > 0) out[0] = const_cast<cmx_ctx *>(c); return 1; }
+  const int n = c->group->n < max ? c->group->n : max;
+  for (int r = 0; r < n; r++) out[r] = c->group->m[r];
+  return n;
+}
 
 // run fn(member, rank) on every member -- member 0 on the calling thread, the others on their workers -- and return the first
 // failure (its text copied to the handle)
 int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn) {
   cmx_group *g = leader->group;
+  if (!g->ready)
+    return fail(leader, CMX_ERR_STATE, "the group was not set up (cmx_backend_create_group failed: %s): only cmx_destroy is valid on this handle",
+                g->setup_err.c_str());
   const double t0 = now_us();
   g->abort_flag.store(0, std::memory_order_relaxed);
   g->bar_count.store(0, std::memory_order_relaxed);  // (a call that failed half-way may have left arrivals behind)
@@ -277,45 +359,22 @@ static void group_teardown(cmx_group *g) {
     if (g->ev_ready[r]) hipEventDestroy(g->ev_ready[r]);
     if (g->ev_rs[r]) hipEventDestroy(g->ev_rs[r]);
     if (g->ev_ag[r]) hipEventDestroy(g->ev_ag[r]);
+    for (int k = 0; k < 2; k++)
+      if (g->ev_os[k][r]) hipEventDestroy(g->ev_os[k][r]);
   }
   for (int r = g->n - 1; r >= 0; r--) {  // members: the ordinary single-context destroy (communicators included)
     cmx_ctx *m = g->m[r];
     if (!m) continue;
     m->group = nullptr;
-    if (m->comm_fn) { m->comm_fn = nullptr; m->comm_user = nullptr; }
+    if (m->comm_fn) { m->comm_fn = nullptr; m->comm_fn_oop = nullptr; m->comm_user = nullptr; }
     cmx_destroy(m);
   }
   delete g;
 }
 void group_destroy(cmx_ctx *leader) { group_teardown(leader->group); }
 
-int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, int W, int H, const double *lut, int Wp, int Hp,
-                             int transport) {
-  if (!out) return CMX_ERR_INVALID_ARG;
-  *out = nullptr;
-  if (!devices || n_devices < 1 || n_devices > kMaxMembers || transport < CMX_GROUP_AUTO || transport > CMX_GROUP_DIRECT)
-    return CMX_ERR_INVALID_ARG;
-  if (n_devices == 1) return cmx_backend_create(out, devices[0], W, H, lut, Wp, Hp);  // a group of one IS a plain context
-  bool same_device = false;
-  for (int a = 0; a < n_devices; a++)
-    for (int b = a + 1; b < n_devices; b++) same_device = same_device || devices[a] == devices[b];
-  if (transport == CMX_GROUP_AUTO) transport = same_device ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL;
-  cmx_group *g = new cmx_group();
-  g->n = n_devices;
-  g->transport = transport;
-  int rc = CMX_OK;
-  for (int r = 0; r < n_devices && !rc; r++) {
-    rc = cmx_backend_create(&g->m[r], devices[r], W, H, lut, Wp, Hp);
-    if (g->m[r]) { g->m[r]->group = g; g->m[r]->group_rank = r; }
-  }
-  cmx_ctx *leader = g->m[0];
-  *out = leader;  // returned on failure too when it exists: the caller reads cmx_last_error and destroys it
-  if (rc) {
-    if (!leader) { group_teardown(g); return rc; }
-    for (int r = 1; r < n_devices; r++)
-      if (g->m[r] && !g->m[r]->err.empty()) { leader->err = g->m[r]->err; break; }
-    return rc;
-  }
+// transport set-up + worker threads of a group whose members exist; on failure the group stays "not ready" (group_all refuses)
+static int group_connect(cmx_group *g, cmx_ctx *leader, const int *devices, int n_devices, int transport, bool same_device) {
   if (transport == CMX_GROUP_RCCL) {
     if (same_device) return fail(leader, CMX_ERR_INVALID_ARG, "RCCL cannot place two ranks on one device: use CMX_GROUP_DIRECT");
     if (!rccl_group().ok) return fail(leader, CMX_ERR_HIP, "librccl.so.1 could not be loaded (ncclCommInitAll)");
@@ -343,17 +402,54 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
       HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ready[r], flags));
       HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_rs[r], flags));
       HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ag[r], flags));
+      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[0][r], flags));
+      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[1][r], flags));
       g->duser[r].g = g;
       g->duser[r].rank = r;
       g->m[r]->comm_fn = direct_allreduce;
+      g->m[r]->comm_fn_oop = direct_oneshot;
       g->m[r]->comm_user = &g->duser[r];
       g->m[r]->comm_rank = r;
       g->m[r]->comm_size = n_devices;
     }
   }
   for (int r = 1; r < n_devices; r++) g->workers.emplace_back(worker_loop, g, r);
+  g->ready = true;
   HIP_TRY(leader, hipSetDevice(devices[0]));
   return CMX_OK;
+}
+
+int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, int W, int H, const double *lut, int Wp, int Hp,
+                             int transport) {
+  if (!out) return CMX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > kMaxMembers || transport < CMX_GROUP_AUTO || transport > CMX_GROUP_DIRECT)
+    return CMX_ERR_INVALID_ARG;
+  if (n_devices == 1) return cmx_backend_create(out, devices[0], W, H, lut, Wp, Hp);  // a group of one IS a plain context
+  bool same_device = false;
+  for (int a = 0; a < n_devices; a++)
+    for (int b = a + 1; b < n_devices; b++) same_device = same_device || devices[a] == devices[b];
+  if (transport == CMX_GROUP_AUTO) transport = same_device ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL;
+  cmx_group *g = new cmx_group();
+  g->n = n_devices;
+  g->transport = transport;
+  int rc = CMX_OK;
+  for (int r = 0; r < n_devices && !rc; r++) {
+    rc = cmx_backend_create(&g->m[r], devices[r], W, H, lut, Wp, Hp);
+    if (g->m[r]) { g->m[r]->group = g; g->m[r]->group_rank = r; }
+  }
+  cmx_ctx *leader = g->m[0];
+  *out = leader;  // returned on failure too when it exists: the caller reads cmx_last_error and destroys it
+  if (rc) {
+    if (!leader) { group_teardown(g); return rc; }
+    for (int r = 1; r < n_devices; r++)
+      if (g->m[r] && !g->m[r]->err.empty()) { leader->err = g->m[r]->err; break; }
+    g->setup_err = leader->err;
+    return rc;
+  }
+  rc = group_connect(g, leader, devices, n_devices, transport, same_device);
+  if (rc) g->setup_err = leader->err;  // the handle is returned (the caller reads cmx_last_error and destroys it); every other call on it fails with CMX_ERR_STATE
+  return rc;
 }
 
 // ---- the group forms of the entry points (called from the C ABI functions when the handle is a group's)

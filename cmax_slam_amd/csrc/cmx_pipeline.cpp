@@ -661,10 +661,13 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
 }
 
 // spin on a completion ticket in a mapped result block; true once a consistent snapshot carrying `want` has been read
-bool spin_for_ticket(const double *h_block, unsigned long long want, int nout) {
+// (budget_us >= 0: give up after that long -- the caller then blocks in hipStreamSynchronize; -1: the 20 ms safety bound only)
+bool spin_for_ticket(const double *h_block, unsigned long long want, int nout, int budget_us) {
   const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(h_block);
   const auto t0 = std::chrono::steady_clock::now();
   bool done = false;
+  const double limit_ms = budget_us >= 0 ? budget_us * 1e-3 : 20.0;
+  const unsigned check = budget_us >= 0 ? 63u : 1023u;
   for (unsigned spins = 0;; spins++) {
     if (w[kTicketSlot] == want) {  // ticket seen: accept only a consistent snapshot of the results
       unsigned long long x = w[kFallbackSlot];
@@ -672,8 +675,8 @@ bool spin_for_ticket(const double *h_block, unsigned long long want, int nout) {
       if ((x ^ (want * kTicketMix)) == w[kChecksumSlot]) { done = true; break; }
     }
     __builtin_ia32_pause();
-    if ((spins & 1023u) == 1023u &&
-        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+    if ((spins & check) == check &&
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms)
       break;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -686,7 +689,7 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
   // anything slower than the spin budget, and every caller that queued copies or other kernels after the finalize,
   // takes the ordinary stream synchronisation.
   bool done = false;
-  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) done = spin_for_ticket(c->h_result, c->ticket_issued, c->ticket_nout);
+  if (ends_in_finalize && c->ticket_wait && c->ticket_issued) done = spin_for_ticket(c->h_result, c->ticket_issued, c->ticket_nout, c->spin_eval_us);
   if (!done) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (ends_in_finalize && c->ticket_issued) {
@@ -761,7 +764,7 @@ int collect_gated(cmx_ctx *c, int P, double *contrast, double *grad, bool *serve
   if (!c->gated_pending) return CMX_OK;
   c->gated_pending = false;
   if (!c->gated_fired) return CMX_OK;  // the gate stayed shut (the caller asks anyway): ordinary gradient pass
-  bool done = spin_for_ticket(c->h_result2, c->ticket2_issued, c->ticket2_nout);
+  bool done = spin_for_ticket(c->h_result2, c->ticket2_issued, c->ticket2_nout, c->spin_eval_us);
   if (!done) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (reinterpret_cast<const unsigned long long *>(c->h_result2)[kTicketSlot] != c->ticket2_issued)

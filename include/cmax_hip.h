@@ -111,10 +111,17 @@ enum {
                                the slots (a finalize behind the image pass, a flag-gated gradient pass) also where the self-gating
                                form applies (A/B) */
   CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
-  CMX_OPT_SPIN_WAIT = 4   /* 1 (default): an evaluation waits for its last kernel by spinning on a completion ticket
-                             that kernel writes to mapped host memory after the results (a few microseconds sooner
-                             than hipStreamSynchronize returns; one host core busy for the ~50-250 us of an
-                             evaluation).  0: plain hipStreamSynchronize */
+  CMX_OPT_SPIN_WAIT = 4   /* ONE policy for the three places a host thread of this library waits:
+                             (a) an evaluation waiting for its last kernel -- spins on a completion ticket that kernel writes to
+                                 mapped host memory after the results (a few microseconds sooner than hipStreamSynchronize returns);
+                             (b) a group's worker threads between two commands;  (c) a CMX_SCHED_BACKGROUND context held behind an
+                                 urgent burst (cmx_set_sched_class).
+                             1 (default): (a) spins for as long as the evaluation runs (the calling thread is blocked in a
+                                 synchronous call either way: one core busy for its ~40-250 us); (b), (c) -- threads with NOTHING
+                                 on the device -- spin for 50 us, then sleep on a condition variable: an idle group and a held back
+                                 end use no core.
+                             0: never spin: (a) is plain hipStreamSynchronize, (b) / (c) sleep at once.
+                             n >= 2: spin budget in microseconds for all three ((a): then hipStreamSynchronize). */
 };
 
 const char *cmx_version(void);
@@ -136,7 +143,10 @@ int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
  * costs the front end x1.9 and the back end x1.23; priorities change nothing (the back end's launches are one resident round of
  * workgroups that fill the register files; a queue's priority does not pre-empt them); disjoint masks isolate the two (beside =
  * solo x1.04-1.09) at the price of a static split -- e.g. front end 51.8 us (x1.34) / back end x1.82 with half of every XCD each.
- * Results never depend on either call. */
+ * A masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags; every other stream of this library is
+ * hipStreamNonBlocking): the per-packet / per-window / per-evaluation paths issue nothing on the null stream, but the rare
+ * synchronous calls that do (cmx_backend_get_map / _set_map, context creation, the device-driven solve's early-stop word) are then
+ * ordered against a masked context's queue like any null-stream work.  Results never depend on either call. */
 int cmx_set_stream_priority(cmx_ctx *ctx, int level);
 int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
 /* What DOES give the front end its latency back without a static split: cooperative scheduling between the contexts of one

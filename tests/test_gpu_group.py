@@ -224,3 +224,194 @@ def test_group_over_several_devices(hip, n_dev, transport):
     assert abs(rg["final_cost"] - r1["final_cost"]) < 2e-3 * abs(r1["final_cost"])
     grp.close()
     one.close()
+
+
+# ---------------------------------------------------------------- round 5: the device event store behind a group
+def _from(be, store, first, n, w, rate=None, IG=None):
+    be.set_window_from(store, first, n, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                       w.sample_rate if rate is None else rate, w.sigma, _lib.VARIANCE, IG)
+
+
+@pytest.mark.parametrize("members,first,n,batch,rate", [(2, 5_000, 50_001, 100, 1), (3, 0, 60_001, 128, 1), (4, 1_000, 150, 100, 1),
+                                                        (2, 7, 40_000, 100, 3), (3, 0, 2_001, 1, 1)])
+def test_group_window_cut_from_the_replicated_store_vs_oracle(hip, oracle, members, first, n, batch, rate):
+    """cmx_backend_set_window_from on a group handle: every member cuts ITS batch range from the store's replica on its own
+    device (pose_graph_optimizer.cpp:131-165 without the copy).  Against the oracle on the same slice: the window whose last batch is
+    the single trailing event (50_001 / 60_001 / 2_001 events), members without events, sub-sampling restarting at every batch."""
+    w = synth.backend_window(60_001, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 10, 3, 0.35, seed=52 + members)
+    w.batch = batch
+    store = hip.EventStore(w.W, w.H, capacity=100_000, devices=[0] * members)
+    assert store.devices == [0]
+    store.push(w.x[:20_000], w.y[:20_000], w.t_ns[:20_000])     # the stream arrives in chunks
+    store.push(w.x[20_000:], w.y[20_000:], w.t_ns[20_000:])
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0] * members)
+    grp.set_fast_path()
+    _from(grp, store, first, n, w, rate)
+    sl = slice(first, first + n)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, batch, rate, w.sigma, oracle.VARIANCE)
+    ref.set_window(w.x[sl], w.y[sl], w.t_ns[sl], w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    # the same window handed over from host arrays: identical shards, identical bits
+    host = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0] * members)
+    host.set_fast_path()
+    host.set_window(w.x[sl], w.y[sl], w.t_ns[sl], w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, batch,
+                    rate, w.sigma, _lib.VARIANCE, None)
+    assert grp.group_info()["events_per_member"] == host.group_info()["events_per_member"]
+    rng = np.random.default_rng(3)
+    for k, want in enumerate([True, False, True]):
+        d = rng.normal(0, 0.005, w.P) if k else np.zeros(w.P)
+        c_ref, g_ref = ref.eval(d)
+        c, g = grp.eval(d, want)
+        ch, gh = host.eval(d, want)
+        assert rel_scalar(c, c_ref) < RTOL and rel_scalar(c, ch) < 1e-7, (k, c, c_ref, ch)
+        if want:
+            assert rel_vec(g, g_ref) < RTOL and rel_vec(g, gh) < 1e-6, (k, g, g_ref)
+    assert rel_img(grp.get_plane(_lib.PLANE_IL_OLD) + grp.get_plane(_lib.PLANE_IL_NEW), ref.IL_old + ref.IL_new) < RTOL
+    for e in (grp, host):
+        e.close()
+    store.close()
+
+
+def test_group_store_sliding_windows_and_drop(hip):
+    """The reference's flow on a group: the stream is pushed once, overlapping windows are cut by global index
+    (pose_graph_optimizer.cpp:131-165), old events are dropped on every replica (ang_vel_estimator.cpp:149-173) and the indices keep
+    their meaning; a single context on the same device cuts from the same store."""
+    w = synth.backend_window(90_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 8, 0, 0.3, seed=58)
+    store = hip.EventStore(w.W, w.H, capacity=120_000, devices=[0, 0])
+    store.push(w.x, w.y, w.t_ns)
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0])
+    one = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    for e in (grp, one):
+        e.set_fast_path()
+    d = np.random.default_rng(5).normal(0, 0.004, w.P)
+    for k, (first, n) in enumerate([(0, 40_000), (20_000, 40_000), (40_000, 50_000)]):
+        if k == 2:
+            store.drop_before(30_000)
+            assert store.begin == 30_000 and store.end == 90_000
+        _from(grp, store, first, n, w)
+        _from(one, store, first, n, w)
+        (c, g), (c1, g1) = grp.eval(d), one.eval(d)
+        assert rel_scalar(c, c1) < 1e-6 and rel_vec(g, g1) < 1e-6, (k, c, c1)
+    with pytest.raises(hip.CmaxHipError) as e:
+        _from(grp, store, 10_000, 30_000, w)       # dropped events: every member refuses, no half-installed window
+    assert e.value.status == _lib.ERR_INVALID_ARG
+    with pytest.raises(hip.CmaxHipError) as e:
+        grp.eval(d)
+    assert e.value.status == _lib.ERR_STATE
+    _from(grp, store, 40_000, 50_000, w)
+    assert np.isfinite(grp.eval(d)[0])
+    for e in (grp, one):
+        e.close()
+    store.close()
+
+
+def test_group_store_on_other_devices_is_refused(hip):
+    """A store without a replica on a member's device is an argument error (not a peer read across the fabric)."""
+    if _lib.lib().cmx_device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    w = synth.backend_window(10_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 0, 0.2, seed=59)
+    store = hip.EventStore(w.W, w.H, capacity=20_000, device=0)
+    store.push(w.x, w.y, w.t_ns)
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 1])
+    with pytest.raises(hip.CmaxHipError) as e:
+        _from(grp, store, 0, len(w.x), w)
+    assert e.value.status == _lib.ERR_INVALID_ARG and "replica" in str(e.value)
+    both = hip.EventStore(w.W, w.H, capacity=20_000, devices=[0, 1])
+    assert both.devices == [0, 1]
+    both.push(w.x, w.y, w.t_ns)
+    _from(grp, both, 0, len(w.x), w)
+    one = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=1)
+    _from(one, both, 0, len(w.x), w)
+    (c, g), (c1, g1) = grp.eval(np.zeros(w.P)), one.eval(np.zeros(w.P))
+    assert rel_scalar(c, c1) < 1e-6 and rel_vec(g, g1) < 1e-6
+
+
+# ---------------------------------------------------------------- round 5: advisor findings + the spin policy
+def test_group_whose_setup_failed_refuses_calls_instead_of_hanging():
+    """cmx_backend_create_group can fail AFTER the members exist (here: RCCL asked for two members on one device).  The handle
+    comes back for cmx_last_error / cmx_destroy; every other call must fail with CMX_ERR_STATE -- no worker thread exists that
+    would ever collect a fan-out."""
+    import ctypes as C
+    L = _lib.lib()
+    w = synth.backend_window(2_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 0, 0.2, seed=93)
+    lut = np.ascontiguousarray(w.lut, np.float64).reshape(-1)
+    ctx = C.c_void_p()
+    dv = (C.c_int * 2)(0, 0)
+    rc = L.cmx_backend_create_group(C.byref(ctx), dv, 2, w.W, w.H, lut.ctypes.data_as(_lib.c_dp), w.Wp, w.Hp, _lib.GROUP_RCCL)
+    assert rc == _lib.ERR_INVALID_ARG and ctx.value
+    assert b"RCCL cannot place two ranks on one device" in L.cmx_last_error(ctx)
+    assert L.cmx_set_option(ctx, _lib.OPT_REUSE_IMAGE, 0) == _lib.ERR_STATE
+    assert b"was not set up" in L.cmx_last_error(ctx)
+    assert L.cmx_set_sched_class(ctx, 0) == _lib.ERR_STATE
+    x = np.zeros(w.P)
+    c = C.c_double()
+    assert L.cmx_backend_eval(ctx, x.ctypes.data_as(_lib.c_dp), C.byref(c), None) != _lib.OK
+    L.cmx_destroy(ctx)
+
+
+def test_group_pose_table_is_the_windows_and_leaves_the_live_table_alone(hip):
+    """cmx_backend_get_pose_table on a group: the members' rows one after the other = the table of the single context on the whole
+    window, at the LAST EVALUATION's parameters even after a prepare(hint) moved the live table -- and reading it does not disturb
+    the evaluation that follows (the tile sort of the prepared window was built on the live table)."""
+    w = synth.backend_window(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.25, seed=94)
+    grp, one = _pair(hip, w, [0, 0, 0])
+    d = np.random.default_rng(2).normal(0, 0.01, w.P)
+    hint = np.random.default_rng(3).normal(0, 0.02, w.P)
+    R0, J0, i0, t0 = one.get_pose_table()            # before any evaluation: zero increments
+    Rg, Jg, ig, tg = grp.get_pose_table()
+    assert len(tg) == len(t0) == (len(w.x) - 1 + w.batch - 1) // w.batch
+    assert np.array_equal(tg, t0) and np.array_equal(ig, i0) and np.array_equal(Rg, R0) and np.array_equal(Jg, J0)
+    for e in (grp, one):
+        e.eval(d)
+        e.prepare(hint)                              # the live table now stands at the hint
+    R1, J1, i1, t1 = one.get_pose_table()
+    Rg, Jg, ig, tg = grp.get_pose_table()
+    assert np.array_equal(Rg, R1) and np.array_equal(Jg, J1) and np.array_equal(tg, t1)
+    assert not np.array_equal(R1, R0)                # ... the last evaluation's parameters, not zero, not the hint
+    fresh = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    fresh.set_fast_path()
+    _set(fresh, w)
+    fresh.eval(d)
+    assert np.array_equal(fresh.get_pose_table()[0], R1)
+    (c, g), (c1, g1) = grp.eval(hint), fresh.eval(hint)   # the prepared window evaluates at the hint as if nothing had been read
+    assert rel_scalar(c, c1) < 1e-6 and rel_vec(g, g1) < 1e-6
+    for e in (grp, one, fresh):
+        e.close()
+
+
+def test_group_prepare_with_an_empty_member_keeps_the_collectives_matched(hip):
+    """eval(x); prepare(hint); eval(x) on a group where two of four members hold no events: the empty members must drop their
+    'image is resident' state in prepare like their peers, or they skip the exchange the others enter (a 20 s barrier timeout)."""
+    import time
+    w = synth.backend_window(150, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 0, 0.2, seed=95)
+    grp, one = _pair(hip, w, [0, 0, 0, 0])
+    assert grp.group_info()["events_per_member"][2:] == [0, 0]
+    x = np.full(w.P, 0.002)
+    t0 = time.perf_counter()
+    for e in (grp, one):
+        e.eval(x)
+        e.prepare(np.zeros(w.P))
+    (c, g), (c1, g1) = grp.eval(x), one.eval(x)
+    assert time.perf_counter() - t0 < 5.0
+    assert rel_scalar(c, c1) < 1e-6 and rel_vec(g, g1) < 1e-6
+    grp.close()
+    one.close()
+
+
+@pytest.mark.parametrize("spin", [0, 1, 30])
+def test_spin_policy_changes_no_result_and_an_idle_group_gives_its_cores_back(hip, spin):
+    """CMX_OPT_SPIN_WAIT (0 never spin / 1 default / n microseconds): same numbers; after the idle budget the workers of a group
+    sleep -- the process burns no CPU while nothing is on the device."""
+    import time
+    w = synth.backend_window(60_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 0, 0.2, seed=96)
+    grp, one = _pair(hip, w, [0, 0, 0])
+    grp.set_option(_lib.OPT_SPIN_WAIT, spin)
+    d = np.random.default_rng(4).normal(0, 0.004, w.P)
+    _same(grp, one, [(np.zeros(w.P), True), (d, False), (d, True)])
+    time.sleep(0.05)
+    t_cpu, t_wall = time.process_time(), time.perf_counter()
+    time.sleep(0.4)
+    busy = (time.process_time() - t_cpu) / (time.perf_counter() - t_wall)
+    assert busy < 0.25, "an idle group keeps %.2f cores busy" % busy      # (two spinning workers would read 2.0)
+    _same(grp, one, [(d, True)])                                            # woken again
+    grp.close()
+    one.close()
