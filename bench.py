@@ -748,7 +748,7 @@ def per_packet_pipeline(device, which, n_packets=8):
             "note": "solves start at omega = 0 like `cmax`; solve_ms = the solve on a resident, already-sorted packet"}
 
 
-def per_window_pipeline(device, w, n_windows=4):
+def per_window_pipeline(device, w, n_windows=4, devices=None):
     """The per-window pipeline of the back end (reference: PoseGraphOptimizer's loop, src/backend/pose_graph_optimizer.cpp:131-165,
     244-323: a NEW window every stride): hand-over, first evaluation (upload + pose table + destination-tile sort + streams),
     FR-CG solve -- BASELINE config 3's window, from host arrays (cmx_backend_set_window) and cut from the device event store
@@ -759,15 +759,19 @@ def per_window_pipeline(device, w, n_windows=4):
     from cmax_slam_amd import _lib, evaluator
     out = {}
     args_w = (w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch, w.sample_rate, w.sigma, _lib.VARIANCE)
-    store = evaluator.EventStore(w.W, w.H, len(w.x) + 1024, device=device)
+    # devices = a group's member list: the handles are groups, the store holds a replica per member device and every member cuts
+    # its own batch range from it (cmx_events_create_group + cmx_backend_set_window_from on the group's handle)
+    store = evaluator.EventStore(w.W, w.H, len(w.x) + 1024, device=device, devices=devices)
+    t0 = time.perf_counter()
     store.push(w.x, w.y, w.t_ns)
+    out["store_push_ms"] = (time.perf_counter() - t0) * 1e3  # once per stream, not per window: the events arrive as they are sensed
     for source in ("host_arrays", "device_store"):
         def hand_over(ev):
             if source == "host_arrays":
                 ev.set_window(w.x, w.y, w.t_ns, *args_w)
             else:
                 ev.set_window_from(store, 0, len(w.x), *args_w)
-        evs = [evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device) for _ in range(2)]
+        evs = [evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=device, devices=devices) for _ in range(2)]
         x0 = np.zeros(w.P)
         for rep in range(2):  # (first pass untimed: allocations)
             t_set = t_first = t_fresh = t_res = 0.0
@@ -830,7 +834,8 @@ def per_window_pipeline(device, w, n_windows=4):
                        "sequential": {"ms_per_window": seq_ms, "ratio_to_solve": seq_ms / solve_ms},
                        "pipelined": {"ms_per_window": best, "ratio_to_solve": best / solve_ms}}
     store.close()
-    out["window"] = "%d events, %dx%d pano, order %d, K %d" % (len(w.x), w.Wp, w.Hp, w.order, w.K)
+    out["window"] = "%d events, %dx%d pano, order %d, K %d%s" % (len(w.x), w.Wp, w.Hp, w.order, w.K,
+                                                                  (", group over devices %s" % devices) if devices else "")
     out["windows"] = n_windows
     out["note"] = ("solve_ms = the solve on a resident, already-sorted window; pipelined = two contexts, a helper host thread runs "
                    "set_window[_from] + cmx_backend_prepare of window k+1 beside the solve of window k")
@@ -1028,6 +1033,10 @@ def group_on_one_device(device, w, steps=200):
         ev.close()
     res.pop("_g")
     res["overhead_ms"] = res["group_of_2_on_one_device"]["fdf_ms"] - res["single_context"]["fdf_ms"]
+    try:  # the window hand-over through the group: host arrays against the replicated device store
+        res["per_window"] = per_window_pipeline(device, w, n_windows=3, devices=[device, device])
+    except Exception as e:
+        res["per_window"] = {"error": repr(e)}
     res["note"] = ("two members on ONE GPU serialise on its compute units: the difference to the single context is the group's machinery "
                    "(collective kernels, event waits, fan-out), not a speed-up; a group of one is a plain context (no overhead)")
     return res
@@ -1158,9 +1167,17 @@ def summary_of(out):
     if isinstance(out.get("group"), dict):
         if "overhead_ms" in out["group"]:
             s["group_2_members_one_device"] = {"overhead_ms": out["group"].get("overhead_ms"),
-                                               "per_window_ratio_to_solve_store": g(out["group"], "per_window", "device_store", "sequential", "ratio_to_solve")}
+                                               "per_window_ratio_to_solve_store": g(out["group"], "per_window", "device_store", "sequential", "ratio_to_solve"),
+                                               "per_window_ratio_to_solve_host": g(out["group"], "per_window", "host_arrays", "sequential", "ratio_to_solve"),
+                                               "set_window_ms_store": g(out["group"], "per_window", "device_store", "set_window_ms"),
+                                               "set_window_ms_host": g(out["group"], "per_window", "host_arrays", "set_window_ms")}
         else:
             s["group"] = {k: out["group"].get(k) for k in ("members", "devices", "transport", "last_fanout_us")}
+    if isinstance(out.get("per_window"), dict):
+        s["per_window_ratio_to_solve"] = {"store_seq": g(out, "per_window", "device_store", "sequential", "ratio_to_solve"),
+                                          "host_seq": g(out, "per_window", "host_arrays", "sequential", "ratio_to_solve"),
+                                          "store_set_window_ms": g(out, "per_window", "device_store", "set_window_ms"),
+                                          "host_set_window_ms": g(out, "per_window", "host_arrays", "set_window_ms")}
     if isinstance(out.get("comm"), dict):
         s["comm"] = {k: out["comm"].get(k) for k in ("nranks_seen", "transport", "ms_per_step", "share_of_step", "collectives_per_step",
                                                      "bytes_last_evaluation")}
@@ -1519,6 +1536,11 @@ def main():
             if group_devices:
                 out["group"] = ev.group_info()
                 out["config"]["form"] = "one process, group handle over devices %s" % group_devices
+                if len(group_devices) > 1 and not args.no_extras:
+                    try:
+                        out["per_window"] = per_window_pipeline(local_rank, w, n_windows=3, devices=group_devices)
+                    except Exception as e:
+                        out["per_window"] = {"error": repr(e)}
                 if args.solves > 0:
                     out["cmax"] = cmax_solves(max(1, args.solves // 4), ev, "backend", _lib)
             if not sharded and args.solves > 0:

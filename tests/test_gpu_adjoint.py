@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _fe_pair(hip, oracle, p, measure=0, sigma=1.0, batch=100):
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     fe.set_grad_mode(hip.GRAD_ADJOINT)
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, batch, sigma, measure)
     ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, batch, sigma, measure)
@@ -69,7 +69,7 @@ def test_frontend_config2_adjoint(hip, oracle):
 
 
 def _be_pair(hip, oracle, w, measure=0, sigma=1.0, batch=100, rate=1, IG=None):
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     be.set_grad_mode(hip.GRAD_ADJOINT)
     be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
                   batch, rate, sigma, measure, IG)

@@ -17,7 +17,7 @@ def p():
 
 def test_call_sequence_errors(hip, p):
     L = _lib.lib()
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     c, g = C.c_double(), (C.c_double * 3)()
     om = (C.c_double * 3)(0.1, 0.2, 0.3)
     assert L.cmx_frontend_eval(fe._ctx, om, C.byref(c), g) == _lib.ERR_STATE            # before set_packet
@@ -50,7 +50,7 @@ def test_bad_creation_arguments(hip, p):
 
 
 def test_bad_packet_arguments(hip, p):
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     with pytest.raises(hip.CmaxHipError) as e:
         fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, event_batch_size=0)
     assert e.value.status == _lib.ERR_INVALID_ARG
@@ -66,7 +66,7 @@ def test_bad_packet_arguments(hip, p):
 
 def test_backend_argument_errors(hip):
     w = synth.backend_window(3_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 256, 128, 2, 5, 1, 0.2, seed=62)
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     args = (w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns)
     for bad in (dict(num_fixed=9), dict(num_fixed=-1)):
         with pytest.raises(hip.CmaxHipError) as e:

@@ -17,7 +17,7 @@ def _pair(hip, oracle, w, measure=0, sigma=None, batch=None, rate=None, IG=None,
     batch = w.batch if batch is None else batch
     rate = w.sample_rate if rate is None else rate
     knots = w.knots_init if knots is None else knots
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     be.set_window(w.x, w.y, w.t_ns, w.order, knots, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,
                   batch, rate, sigma, measure, IG)
     ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order, batch, rate, sigma, measure)
@@ -115,7 +115,7 @@ def test_batching_quirks_and_sampling(hip, oracle, linear, n, batch, rate):
 
 def test_spline_support_is_checked(hip, cubic):
     w = cubic
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     with pytest.raises(hip.CmaxHipError) as e:  # too few knots for the window: Basalt would assert (so3_spline.h:227-230)
         be.set_window(w.x, w.y, w.t_ns, 4, w.knots_init[:6], w.start_ns, w.dt_ns, 3, w.t_next_win_beg_ns)
     assert e.value.status == 4

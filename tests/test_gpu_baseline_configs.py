@@ -27,7 +27,7 @@ def c1():
 @pytest.mark.parametrize("fast", [False, True])
 def test_config1_full_size_parity(hip, oracle, c1, fast):
     p = c1
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     if fast:
         fe.set_fast_path()
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
@@ -107,7 +107,7 @@ def test_config4_whole_window_on_one_gpu(hip, oracle, c4):
     assert rel_img(il_old, ref.IL_old) < RTOL and rel_img(il_new, ref.IL_new) < RTOL
     assert rel_scalar(fast.eval(d, False)[0], c_ref) < RTOL
     # (2) the reference-shaped GPU path (derivative planes, one global atomic per vote)
-    slow = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    slow = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     _set(slow, w)
     c2, g2 = slow.eval(d)
     slow.close()

@@ -29,7 +29,7 @@ def small():
 def prior_map(hip, small):
     """A previous window's contribution to the global map: IL_old of a neighbouring window, scaled."""
     prev = synth.config5(N=120_000, seed=synth.SEED0 + 55)
-    be = hip.BackendEvaluator(prev.W, prev.H, prev.lut, prev.Wp, prev.Hp)
+    be = hip.reference_shaped.BackendEvaluator(prev.W, prev.H, prev.lut, prev.Wp, prev.Hp)
     _set(be, prev, None)
     be.eval(np.zeros(prev.P), False)
     return np.ascontiguousarray(be.get_plane(_lib.PLANE_IL_OLD) * 2.5)
@@ -44,7 +44,7 @@ def test_config5_parity_with_oracle(hip, oracle, small, prior_map):
     c_ref, g_ref = ref.eval(d)
     assert ref.alpha > 0
     for fast in (False, True):
-        be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+        be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
         if fast:
             be.set_fast_path()
         _set(be, w, prior_map)
@@ -68,7 +68,7 @@ def test_config5_per_gpu_size_properties(hip, prior_map):
     alpha = fast.alpha
     assert alpha > 0 and np.isfinite(c) and np.all(np.isfinite(g))
     # (1) the fast path equals the reference-shaped path (derivative planes, one global atomic per vote)
-    slow = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    slow = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     _set(slow, w, prior_map)
     c2, g2 = slow.eval(d)
     assert rel_scalar(slow.alpha, alpha) < RTOL and rel_scalar(c2, c) < RTOL and rel_vec(g2, g) < RTOL

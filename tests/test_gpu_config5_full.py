@@ -71,7 +71,7 @@ def test_config5_whole_window_on_one_gpu(hip, oracle, c5, prior_map):
     assert rel_scalar(fast.alpha, ref.alpha) < RTOL
     assert rel_scalar(c2, c2_ref) < RTOL and rel_vec(g2, g2_ref) < RTOL, (c2, c2_ref, g2, g2_ref)
     # (2) the reference-shaped GPU path (2 + 15 planes of 32 MB, one global atomic per vote)
-    slow = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    slow = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     _set(slow, w, prior_map)
     cs, gs = slow.eval(d)
     assert rel_scalar(slow.alpha, ref.alpha) < RTOL

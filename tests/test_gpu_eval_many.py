@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("fast", [True, False])
 def test_frontend_eval_many(hip, oracle, fast):
     p = synth.frontend_packet(50_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=81)
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     if fast:
         fe.set_fast_path()
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)

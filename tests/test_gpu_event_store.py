@@ -78,7 +78,7 @@ def test_store_window_batch_times_are_validated_on_the_device(hip):
     w = synth.backend_window(20_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 2, 5, 1, 0.2, seed=53)
     store = hip.EventStore(w.W, w.H, capacity=len(w.x))
     store.push(w.x, w.y, w.t_ns)
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     for kw in (dict(start_ns=w.start_ns + 10_000_000), dict(knots=w.knots_init[:3])):  # starts too late / ends too early
         with pytest.raises(hip.CmaxHipError) as e:
             be.set_window_from(store, 0, len(w.x), w.order, kw.get("knots", w.knots_init), kw.get("start_ns", w.start_ns),
@@ -88,7 +88,7 @@ def test_store_window_batch_times_are_validated_on_the_device(hip):
         c = _lib.C.c_double()
         assert _lib.lib().cmx_backend_eval(be._ctx, x.ctypes.data_as(_lib.c_dp), _lib.C.byref(c), None) == _lib.ERR_STATE  # no half-installed window
     be.set_window_from(store, 0, len(w.x), w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
-    host = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    host = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     host.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
     d = np.full(w.P, 0.004)
     (c0, g0), (c1, g1) = be.eval(d), host.eval(d)
@@ -99,7 +99,7 @@ def test_store_setup_is_cheaper_than_reupload(hip):
     p = synth.config2()
     store = hip.EventStore(p.W, p.H, capacity=len(p.x))
     store.push(p.x, p.y, p.t_ns)
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy)           # warm allocations
     fe.set_packet_from(store, 0, len(p.x), p.t_ref_ns, p.fx, p.fy, p.cx, p.cy)
     t0 = time.perf_counter()

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _pair(hip, oracle, p, measure=0, sigma=None, batch=None):
     sigma = p.sigma if sigma is None else sigma
     batch = p.batch if batch is None else batch
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, batch, sigma, measure)
     ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, batch, sigma, measure)
     ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
@@ -88,7 +88,7 @@ def test_events_warped_outside_are_dropped(hip, oracle, small):
 
 
 def test_invalid_event_coordinates_are_rejected(hip, small):
-    fe = hip.FrontendEvaluator(small.W, small.H, small.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(small.W, small.H, small.lut)
     x = small.x.copy()
     x[5] = small.W  # the reference's .at() would throw std::out_of_range
     with pytest.raises(hip.CmaxHipError) as e:
@@ -99,7 +99,7 @@ def test_invalid_event_coordinates_are_rejected(hip, small):
 
 
 def test_unsorted_batch_is_rejected(hip, small):
-    fe = hip.FrontendEvaluator(small.W, small.H, small.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(small.W, small.H, small.lut)
     t = small.t_ns.copy()
     t[0], t[99] = t[99] + 5, t[0]  # CHECK_GE(time_dt, 0) in the reference (:72)
     with pytest.raises(hip.CmaxHipError) as e:
@@ -125,7 +125,7 @@ def test_linearity_over_batches(hip, small):
     om = (0.6, -0.9, 0.4)
     imgs = []
     for sl in (slice(0, n1), slice(n1, None), slice(None)):
-        fe = hip.FrontendEvaluator(small.W, small.H, small.lut)
+        fe = hip.reference_shaped.FrontendEvaluator(small.W, small.H, small.lut)
         fe.set_packet(small.x[sl], small.y[sl], small.t_ns[sl], small.t_ref_ns, small.fx, small.fy, small.cx, small.cy)
         imgs.append(fe.computeImageOfWarpedEvents(om, blur=False).astype(np.float64))
     assert rel_img(imgs[0] + imgs[1], imgs[2]) < RTOL
@@ -164,7 +164,7 @@ def test_gradient_magnitude_contrast(hip, oracle, small, fast):
 
 def test_unknown_measure_means_variance(hip, oracle, small):
     fe, ref = _pair(hip, oracle, small, measure=0)
-    fe7 = hip.FrontendEvaluator(small.W, small.H, small.lut)
+    fe7 = hip.reference_shaped.FrontendEvaluator(small.W, small.H, small.lut)
     fe7.set_packet(small.x, small.y, small.t_ns, small.t_ref_ns, small.fx, small.fy, small.cx, small.cy, 100, 1.0, 7)
     c_ref, g_ref = ref.eval((0.3, -0.5, 0.2))
     c, g = fe7.eval((0.3, -0.5, 0.2))

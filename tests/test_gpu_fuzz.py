@@ -26,7 +26,7 @@ def test_frontend_random_configuration(hip, oracle, seed):
     sigma = float(rng.choice([0.0, 0.5, 1.0, 1.7, 3.0]))
     measure = int(rng.choice([_lib.VARIANCE, _lib.MEAN_SQUARE]))
     p = synth.frontend_packet(N, W, H, f, f, (W - 1) / 2, (H - 1) / 2, T=float(rng.uniform(0.01, 0.08)), seed=seed)
-    fe = hip.FrontendEvaluator(W, H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(W, H, p.lut)
     if seed % 3 != 2:
         fe.set_fast_path()
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, batch, sigma, measure)
@@ -47,7 +47,7 @@ def test_frontend_random_configuration(hip, oracle, seed):
 @pytest.mark.parametrize("seed", range(N_BE))
 def test_backend_random_configuration(hip, oracle, seed):
     rng, k, w, IG = backend_fuzz_config(seed)
-    be = hip.BackendEvaluator(k["W"], k["H"], w.lut, k["Wp"], k["Hp"])
+    be = hip.reference_shaped.BackendEvaluator(k["W"], k["H"], w.lut, k["Wp"], k["Hp"])
     fast = seed % 4 != 3
     if fast:
         be.set_fast_path()

@@ -27,8 +27,8 @@ def _set(be, w, IG=None, n=None):
 
 
 def _pair(hip, w, devices, IG=None, n=None, transport=0, fast=True):
-    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=devices, transport=transport)
-    one = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    grp = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=devices, transport=transport)
+    one = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     if fast:
         grp.set_fast_path()
         one.set_fast_path()

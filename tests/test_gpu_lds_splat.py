@@ -18,7 +18,7 @@ def small():
 
 
 def _fe(hip, oracle, p, adjoint, measure=0, sigma=1.0):
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     fe.set_splat_mode(1)
     if adjoint:
         fe.set_grad_mode(hip.GRAD_ADJOINT)
@@ -74,7 +74,7 @@ def test_frontend_config2_fast_path(hip, oracle):
 
 
 def _be(hip, oracle, w, IG=None, rate=1):
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     be.set_splat_mode(1)
     be.set_grad_mode(hip.GRAD_ADJOINT)
     be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,

@@ -22,14 +22,14 @@ def test_create_destroy_cycles_do_not_leak(hip):
     def cycle(k):
         store = hip.EventStore(p.W, p.H, capacity=len(p.x))
         store.push(p.x, p.y, p.t_ns)
-        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
         if k % 2:
             fe.set_fast_path()
         fe.set_packet_from(store, 0, len(p.x), p.t_ref_ns, p.fx, p.fy, p.cx, p.cy)
         fe.eval((0.1, 0.2, 0.3))
         fe.setupProblemAndOptimize(np.zeros(3))
         fe.computeImageOfWarpedEvents((0.1, 0.2, 0.3), want_deriv=True)
-        be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+        be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
         if k % 2 == 0:
             be.set_fast_path()
         be.set_window(w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns,

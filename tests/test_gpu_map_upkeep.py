@@ -57,7 +57,7 @@ def test_two_windows_with_resident_map(hip, oracle):
 
 def test_set_and_get_map_roundtrip(hip):
     w = synth.backend_window(2_000, 240, 180, 200.0, 200.0, 119.5, 89.5, 256, 128, 2, 5, 1, 0.2, seed=3)
-    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
     rng = np.random.default_rng(0)
     IG = rng.random((w.Hp, w.Wp)).astype(np.float32)
     v = rng.integers(0, 255, (w.Hp, w.Wp)).astype(np.uint8)

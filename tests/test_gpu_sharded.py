@@ -32,7 +32,7 @@ def test_frontend_two_shards_on_one_gpu(hip, oracle, fast):
     evs, accs, gss = [], [], []
     for r in range(2):
         beg, end = batch_range(len(p.x), p.batch, r, 2)
-        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
         if fast:
             fe.set_fast_path()
         fe.set_packet(p.x[beg:end], p.y[beg:end], p.t_ns[beg:end], p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
@@ -77,7 +77,7 @@ def test_backend_two_shards_on_one_gpu(hip, oracle):
         evs, accs, gss = [], [], []
         for r in range(2):
             beg, end = batch_range(len(w.x), w.batch, r, 2)
-            be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+            be = hip.reference_shaped.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
             if fast:
                 be.set_fast_path()
             be.set_window(w.x[beg:end], w.y[beg:end], w.t_ns[beg:end], w.order, w.knots_init, w.start_ns, w.dt_ns,
@@ -149,7 +149,7 @@ def test_native_rccl_communicator_world1(hip, oracle):
     ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
     ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
     for fast in (True, False):
-        fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+        fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
         if fast:
             fe.set_fast_path()
         fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)

@@ -18,7 +18,7 @@ def _oracle_fdf(ref):
 @pytest.mark.parametrize("fast", [False, True])
 def test_frontend_solve_matches_the_oracle_solve(hip, oracle, fast):
     p = synth.frontend_packet(40_000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=33)
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     if fast:
         fe.set_fast_path()
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
@@ -70,6 +70,6 @@ def test_backend_solve_matches_the_oracle_solve(hip, oracle, order, K, nf, T):
 
 def test_solve_reports_evaluator_errors(hip):
     p = synth.frontend_packet(2000, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=1)
-    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe = hip.reference_shaped.FrontendEvaluator(p.W, p.H, p.lut)
     with pytest.raises(hip.CmaxHipError):  # no packet: the functor fails, the solve returns the status
         fe.setupProblemAndOptimize(np.zeros(3))
