@@ -80,4 +80,12 @@ def test_every_seed_is_within_1e5_of_the_oracle_or_passes_the_arbiter(hip, oracl
     if out:
         with open(out, "w") as f:
             f.write("\n".join(lines) + "\n")
+        # the machine-readable record bench.py's summary quotes (profiles/sweep300.json, stamped with the source hash it was taken on)
+        import json
+        import bench
+        with open(os.path.splitext(out)[0] + ".json", "w") as f:
+            json.dump({"configurations": N_CFG, "evaluations": len(rows), "via_arbiter": len(arbitrated),
+                       "above_1e5_vs_oracle": int((v >= RTOL).sum()), "max_rel_vs_oracle": float(v.max()),
+                       "max_rel_vs_exact_of_arbitrated": max([r["vs_exact"] for r in arbitrated], default=0.0),
+                       "src_sha256": bench.csrc_hash()}, f)
     print("\n".join(lines))
