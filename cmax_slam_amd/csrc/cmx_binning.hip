@@ -436,8 +436,14 @@ void launch_fixed_to_float(unsigned long long *fixed, float *planes, size_t n, h
 static_assert(kBinWindow * kBinWindow % 256 == 0, "window cells per thread");
 constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -> 12.6 us, 1 -> 13.3, 4 -> 14.1, 8 -> 15.2 per 1M events)
 
+#ifndef CMX_FE_SPLAT_NT
+#define CMX_FE_SPLAT_NT 512  // threads per chunk workgroup (round 5 sweep, profiles/r05_fe_shape.txt: 512 threads x chunks of n / 256
+                            // events: splat 8.7 -> 7.9 us, a 1M-event solve 0.556 -> 0.535 ms, a 60k-event solve 0.84 -> 0.80 ms)
+#endif
+constexpr int kFeSplatNT = CMX_FE_SPLAT_NT;
+static_assert(kBinWindow * kBinWindow % kFeSplatNT == 0, "window cells per thread");
 template <bool FIXED, bool STREAM>
-__global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
+__global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
   __shared__ fix_t win[kBinWindow * kBinStride];
   if (a.skip && *a.skip) return;  // device-driven solve: finished
   fe_resolve_omega(a);
@@ -452,16 +458,16 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   __shared__ unsigned sfall;
   if (tid == 0) sfall = 0;
   if (has_win)
-    for (int p = tid; p < kBinWindow * kBinStride; p += 256) win[p] = 0ull;
+    for (int p = tid; p < kBinWindow * kBinStride; p += kFeSplatNT) win[p] = 0ull;
   __syncthreads();
   unsigned nfall = 0;
-  for (int j0 = c.beg + tid; j0 < c.end; j0 += 256 * kUnroll) {
+  for (int j0 = c.beg + tid; j0 < c.end; j0 += kFeSplatNT * kUnroll) {
     bool act[kUnroll];
     double px[kUnroll], py[kUnroll], pz[kUnroll], dt[kUnroll];
     if (STREAM) {  // bearing and dt of every sorted event stream in (coalesced): no table gathers in this kernel
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const int j = j0 + u * 256;
+        const int j = j0 + u * kFeSplatNT;
         act[u] = j < c.end;
         const int jj = act[u] ? j : c.beg;
         const double2 v = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)jj);
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
       uint32_t e[kUnroll], bi[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const int j = j0 + u * 256;
+        const int j = j0 + u * kFeSplatNT;
         act[u] = j < c.end;
         e[u] = act[u] ? b.sxy[j] : 0u;
         bi[u] = act[u] ? b.sbatch[j] : 0u;
@@ -504,18 +510,18 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
   if (has_win) {
     // all of a thread's window cells are read before the first is flushed: one LDS round trip instead of sixteen
     // (the rolled loop waited for every read in turn: ~0.9 of the kernel's ~9 us, profiles/r02_splat_timeline.txt)
-    constexpr int kCells = kBinWindow * kBinWindow / 256;
+    constexpr int kCells = kBinWindow * kBinWindow / kFeSplatNT;
     fix_t cell[kCells];
 #pragma unroll
     for (int k = 0; k < kCells; k++) {
-      const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
+      const int p = tid + kFeSplatNT * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
       cell[k] = win[ly * kBinStride + lx];
     }
 #pragma unroll
     for (int k = 0; k < kCells; k++) {
       const fix_t v = cell[k];
       if (v != 0ull) {
-        const int p = tid + 256 * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
+        const int p = tid + kFeSplatNT * k, ly = p / kBinWindow, lx = p - ly * kBinWindow;
         const size_t at = (size_t)(c.wy0 + ly) * a.W + (c.wx0 + lx);
         if (FIXED) atomicAdd(b.fixed + at, v);
         else atomic_add_f32(a.planes + at, (float)((double)v * kFixInv));
@@ -525,8 +531,8 @@ __global__ __launch_bounds__(256) void fe_splat_lds_kernel(FeSplatArgs a, Binned
 }
 template <bool FIXED, bool STREAM>
 static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(256), 0, s, t0, t1, 0, a, b);
-  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(256), 0, s, a, b);
+  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b);
+  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(kFeSplatNT), 0, s, a, b);
 }
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   if (b.nchunks <= 0) return;
@@ -569,23 +575,26 @@ __global__ __launch_bounds__(256) void be_splat_lds_kernel(BeSplatArgs a, Binned
       e[u] = act[u] ? b.sxy[j] : 0u;
       bi[u] = act[u] ? b.sbatch[j] : 0u;
     }
-    double b0[U], b1[U], b2[U], R[U][9];
+    double rx[U], ry[U], rz[U];  // e_ray_w = R * bearing of the U events in flight
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (b.sb) {
-        const int jj = act[u] ? j0 + u * 256 : c.beg;
-        const double2 v = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)jj);
-        b0[u] = v.x; b1[u] = v.y; b2[u] = 1.0;
-      } else {
-        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
-      }
+      double R[9];
       const double *Rp = a.poseR[bi[u]].R;
 #pragma unroll
-      for (int k = 0; k < 9; k++) R[u][k] = Rp[k];
+      for (int k = 0; k < 9; k++) R[k] = Rp[k];
+      if (b.sb) {  // tile-ordered bearing stream: (x, y), z = 1
+        const int jj = act[u] ? j0 + u * 256 : c.beg;
+        const double2 v = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)jj);
+        be_rotate<true>(R, v.x, v.y, 1.0, rx[u], ry[u], rz[u]);
+      } else {
+        double b0, b1, b2;
+        load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0, b1, b2);
+        be_rotate<false>(R, b0, b1, b2, rx[u], ry[u], rz[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const BeWarp w = be_warp_math<0>(a, e[u], (int)bi[u], b0[u], b1[u], b2[u], R[u]);
+      const BeWarp w = be_project<0>(a, e[u], (int)bi[u], rx[u], ry[u], rz[u]);
       if (act[u] && w.ok) {
         const int lx = w.xx - c.wx0, ly = w.yy - c.wy0;
         if (has_win && lx >= 0 && lx < kBinWindow - 1 && ly >= 0 && ly < kBinWindow - 1) {

@@ -1592,7 +1592,16 @@ int gather_blocks(int n) {
 // (tools/sweep_fe_gather2.sh, two events in flight per thread): the kernel alone is indifferent between 512 and 1024
 // events (10.9-11.3 us), 2048 -> 12.2 us, 3072 -> 16 us; the evaluation prefers 1024 (47.2 us against 49.2 us at 512)
 // because finalize then sums half as many partial rows
-constexpr int kFeGatherPerBlock = 1024, kFeGatherCap = 2048;
+// (round 5, profiles/r05_fe_shape.txt: threads per workgroup x events per workgroup swept with the tail finalize on -- the two
+//  macros exist for that sweep, tools/sweep_fe_shape.sh)
+#ifndef CMX_FE_GATHER_NT
+#define CMX_FE_GATHER_NT 256
+#endif
+#ifndef CMX_FE_GATHER_PER_BLOCK
+#define CMX_FE_GATHER_PER_BLOCK 1024
+#endif
+constexpr int kFeGatherNT = CMX_FE_GATHER_NT;
+constexpr int kFeGatherPerBlock = CMX_FE_GATHER_PER_BLOCK, kFeGatherCap = 2048;
 int fe_gather_blocks(int n) {
   // small packets (the reference's own: tens of thousands of events) would leave most CUs without a workgroup at 1024 events
   // each: below 512k events the slices shrink to n / 512 events (a multiple of 256, at least 256) -- 60k events: 235 workgroups
@@ -1600,8 +1609,8 @@ int fe_gather_blocks(int n) {
   // against 15.0 at 512 and 15.2 at 768)
   int per = kFeGatherPerBlock;
   if (n < 512 * 1024) {
-    per = ((n / 512 + 255) / 256) * 256;
-    per = per < 256 ? 256 : (per > kFeGatherPerBlock ? kFeGatherPerBlock : per);
+    per = ((n / 512 + kFeGatherNT - 1) / kFeGatherNT) * kFeGatherNT;
+    per = per < kFeGatherNT ? kFeGatherNT : (per > kFeGatherPerBlock ? kFeGatherPerBlock : per);
   }
   int blocks = (n + per - 1) / per;
   return blocks < 1 ? 1 : (blocks > kFeGatherCap ? kFeGatherCap : blocks);
@@ -1617,13 +1626,13 @@ template <int U>
 __device__ __forceinline__ void fe_gather_streams(const FeGatherArgs &g, const FeSplatArgs &a, int blk_beg, int blk_end, double acc[3],
                                                   double acc2[3]) {
   const int W = a.W, H = a.H, r = g.r;
-  for (int i0 = blk_beg + (int)threadIdx.x; i0 < blk_end; i0 += 256 * U) {
+  for (int i0 = blk_beg + (int)threadIdx.x; i0 < blk_end; i0 += kFeGatherNT * U) {
     double2 bv[U];
     double dt[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int i = i0 + u * 256;
+      const int i = i0 + u * kFeGatherNT;
       ok[u] = i < blk_end;
       const int ii = ok[u] ? i : blk_beg;
       bv[u] = *reinterpret_cast<const double2 *>(g.sb + 2 * (size_t)ii);
@@ -1680,10 +1689,10 @@ __device__ __forceinline__ void fe_gather_streams(const FeGatherArgs &g, const F
 // BOTH machine steps (cost, then gradient).  Test failed: workgroup 0 alone runs the cost finalize and the machine's step, the
 // others leave.  The image pass loses its tail (last-arriver protocol + finalize + step: ~4 us of its 13) at every point.
 template <int CHAIN>
-__global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
+__global__ __launch_bounds__(kFeGatherNT) void fe_gather_kernel(FeGatherArgs g) {
   if (CHAIN != 2 && g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
   if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
-  __shared__ double red[4 * 6];
+  __shared__ double red[(kFeGatherNT / 64) * 6];
   __shared__ FinSmem fin_sm;
   if (CHAIN == 2) {
     const FinalizeArgs &fa = g.tail.fin;
@@ -1698,7 +1707,7 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
       FinalizeArgs f = fa;  // cost only: no gradient sums to read
       f.gP = 0;
       f.gacc = nullptr;
-      finalize_body<256, true>(f, fin_sm);
+      finalize_body<kFeGatherNT, true>(f, fin_sm);
       return;
     }
   }
@@ -1707,9 +1716,9 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};
   constexpr int U = 2;  // events in flight per thread (swept on MI355X: 2 -> 11.9 us, 1 -> 12.2, 4 -> 12.9, 8 -> 14.9 per 1M events)
   // every workgroup walks ONE contiguous slice of the event list (in tile order that keeps its LUT / Itilde reads local)
-  const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+  const int per_block = ((a.n + (int)gridDim.x - 1) / (int)gridDim.x + kFeGatherNT - 1) / kFeGatherNT * kFeGatherNT;
   const int blk_beg = blockIdx.x * per_block, blk_end = min(a.n, blk_beg + per_block);
-  const int stride = 256;
+  const int stride = kFeGatherNT;
   // (the device-driven solve's variants keep the generic loop: with the finalize and the machine's step inlined, four events in
   //  flight cost them registers -- a 1M-event solve 0.558 -> 0.585 ms, same-box A/B -- and their launches are never large)
   if (CHAIN == 0 && CMX_FE_GATHER_U > 0 && g.sb) fe_gather_streams<(CMX_FE_GATHER_U > 0 ? CMX_FE_GATHER_U : 1)>(g, a, blk_beg, blk_end, acc, acc2);
@@ -1795,7 +1804,9 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
   const bool tail = g.tail.counters != nullptr;
   if (threadIdx.x < (g.cx ? 6 : 3)) {
     const int k = threadIdx.x;
-    const double v = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
+    double v = red[k] + red[6 + k] + red[12 + k] + red[18 + k];
+#pragma unroll
+    for (int wv = 4; wv < kFeGatherNT / 64; wv++) v += red[6 * wv + k];
     if (g.tail.fin.gacc) {  // accumulator rows instead of the table (see FinalizeArgs::gacc); with or without the tail
       if (v != 0.0)
         __hip_atomic_fetch_add(g.tail.fin.gacc + (size_t)(blockIdx.x % kTailShards) * g.tail.fin.gacc_stride + k, v, __ATOMIC_RELAXED,
@@ -1803,14 +1814,14 @@ __global__ __launch_bounds__(256) void fe_gather_kernel(FeGatherArgs g) {
     } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
     else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
-  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<256, CHAIN != 0>(g.tail.fin, fin_sm);
+  if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<kFeGatherNT, CHAIN != 0>(g.tail.fin, fin_sm);
 }
 
 int launch_fe_gather(const FeGatherArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
   const int blocks = fe_gather_blocks(a.ev.n);
-  if (a.tail.fin.chain.sm && a.tail.fin.chain.stage == 2) CMX_LAUNCH(fe_gather_kernel<2>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
-  else if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<1>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
-  else CMX_LAUNCH(fe_gather_kernel<0>, dim3(blocks), dim3(256), 0, s, t0, t1, a);
+  if (a.tail.fin.chain.sm && a.tail.fin.chain.stage == 2) CMX_LAUNCH(fe_gather_kernel<2>, dim3(blocks), dim3(kFeGatherNT), 0, s, t0, t1, a);
+  else if (a.tail.fin.chain.sm || a.ev.w_dev) CMX_LAUNCH(fe_gather_kernel<1>, dim3(blocks), dim3(kFeGatherNT), 0, s, t0, t1, a);
+  else CMX_LAUNCH(fe_gather_kernel<0>, dim3(blocks), dim3(kFeGatherNT), 0, s, t0, t1, a);
   return blocks;
 }
 
@@ -1908,29 +1919,33 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
       double R[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) R[k] = a.poseR[batch].R[k];
-      double b0[4], b1[4], b2[4];
-      if (g.tb && i0 + 3 < a.n) {  // 64 contiguous bytes per lane from the time-ordered bearing stream
+      double rx[4], ry[4], rz[4];  // e_ray_w = R * bearing of the lane's four events
+      if (g.tb && i0 + 3 < a.n) {  // 64 contiguous bytes per lane from the time-ordered bearing stream: (x, y), z = 1
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const double2 v = *reinterpret_cast<const double2 *>(g.tb + 2 * (size_t)(i0 + u));
-          b0[u] = v.x; b1[u] = v.y; b2[u] = 1.0;
+          be_rotate<true>(R, v.x, v.y, 1.0, rx[u], ry[u], rz[u]);
         }
       } else {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0[u], b1[u], b2[u]);
+          double b0, b1, b2;
+          load_bearing(a, (int)(e[u] & 0xffff), (int)((e[u] >> 16) & 0x7fff), b0, b1, b2);
+          be_rotate<false>(R, b0, b1, b2, rx[u], ry[u], rz[u]);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         if (i0 + u >= a.n) break;
-        const BeWarp w = be_warp_math<2>(a, e[u], batch, b0[u], b1[u], b2[u], R);
+        const BeWarp w = be_project<2>(a, e[u], batch, rx[u], ry[u], rz[u]);
         if (w.ok) {
+#pragma clang fp contract(fast)  // the fp64 sums of fp32 x fp32 products (exact in fp64): two FMAs per component instead of two multiplies + two adds
           float A, B;
           bilinear_grad(g.itilde, a.Wp, w.xx, w.yy, w.dx, w.dy, A, B);
-          V0 += (double)A * (double)w.m[0] + (double)B * (double)w.m[3];
-          V1 += (double)A * (double)w.m[1] + (double)B * (double)w.m[4];
-          V2 += (double)A * (double)w.m[2] + (double)B * (double)w.m[5];
+          const double Ad = (double)A, Bd = (double)B;
+          V0 = __builtin_fma(Bd, (double)w.m[3], __builtin_fma(Ad, (double)w.m[0], V0));
+          V1 = __builtin_fma(Bd, (double)w.m[4], __builtin_fma(Ad, (double)w.m[1], V1));
+          V2 = __builtin_fma(Bd, (double)w.m[5], __builtin_fma(Ad, (double)w.m[2], V2));
           float Ac, Bc;
           border_grad(g.cx, g.cy, a.Wp, a.Hp, g.r, w.xx, w.yy, w.dx, w.dy, Ac, Bc);
           if (Ac != 0.f || Bc != 0.f) {  // rare: votes within r of the panorama border

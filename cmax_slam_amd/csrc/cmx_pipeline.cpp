@@ -97,9 +97,13 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
   // zeroing and flush.  Back end: 135 VGPRs = 3 workgroups per CU, so n / 768 (swept at 5M events, splat us: 512 -> 50,
   // 640 -> 51, 768 -> 44, 1152 -> 50, 1536 -> 48, 3072 -> 53: anything that needs a second round loses more than it gains in
   // latency hiding; 128 VGPRs + 4 per CU and one event per thread + 4 per CU: no gain, 72 vs 81 us per cost evaluation).
-  // Front end (50 VGPRs, LDS-bound at 4 per CU): n / 512 (1M events, splat us: 256 -> 10.0, 384 -> 8.4, 512 -> 8.2, 640 -> 8.5,
-  // 768 -> 8.8; a 1M-event solve 0.567 -> 0.559 ms).
-  int M = n / (fe ? 512 : 768);
+  // Front end (50 VGPRs, LDS-bound): with 256-thread workgroups n / 512 (1M events, splat us: 256 -> 10.0, 384 -> 8.4, 512 -> 8.2,
+  // 640 -> 8.5, 768 -> 8.8); round 5: 512-thread workgroups x chunks of n / 256 (profiles/r05_fe_shape.txt: 7.9 us; 1024 x n / 256: 7.7
+  // but no better as an evaluation).
+#ifndef CMX_FE_CHUNK_DIV
+#define CMX_FE_CHUNK_DIV 256
+#endif
+  int M = n / (fe ? CMX_FE_CHUNK_DIV : 768);
   M = M < 1536 ? 1536 : (M > 32768 ? 32768 : M);  // floor swept on MI355X (1M events: 1536 -> 11.8 us, 1024 -> 15.3)
   M = (M + 255) / 256 * 256;
   // every tile contributes floor(len/M) full chunks and at most one remainder: an upper bound known on the host

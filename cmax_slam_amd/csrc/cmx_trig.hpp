@@ -27,6 +27,23 @@ __device__ constexpr double kAsinQ[13] = {
     1.03228143501857793e-02, 5.45750671864035815e-03, 1.74008794426940214e-02, -1.48518870712472037e-02,
     2.87578513674215663e-02};
 
+// One Horner step p <- p * r + c as the THREE-ADDRESS v_fma_f64.  Written as asm because the compiler turns the plain expression into
+// v_mov_b64 tmp, c ; v_fmac_f64 tmp, p, r (the two-address form clobbers its addend, and the coefficient -- hoisted into a VGPR pair
+// for the whole event loop -- must survive): 33 extra 64-bit moves per event in front of 33 FMAs, a tenth of the back-end kernels'
+// VALU instructions (profiles/r05_be_valu.txt).  Same operation, same operands, same bits.
+#ifndef CMX_HORNER_ASM
+#define CMX_HORNER_ASM 1
+#endif
+__device__ __forceinline__ double horner_step(double p, double r, double c) {
+#if CMX_HORNER_ASM
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "v"(c));
+  return d;
+#else
+  return __builtin_fma(p, r, c);
+#endif
+}
+
 __device__ __forceinline__ double trig_rcp(double d) {  // 1 / d, ~correctly rounded for normal d
   double r = __builtin_amdgcn_rcp(d);
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -45,7 +62,7 @@ __device__ __forceinline__ double lean_atan2(double y, double x) {
   const double r = a * a;
   double p = kAtanQ[20];
 #pragma unroll
-  for (int k = 19; k >= 0; k--) p = __builtin_fma(p, r, kAtanQ[k]);
+  for (int k = 19; k >= 0; k--) p = horner_step(p, r, kAtanQ[k]);
   double t = __builtin_fma(a * r, p, a);
   constexpr double kPi = 3.14159265358979323846, kHalfPi = 1.57079632679489661923;
   t = ay > ax ? kHalfPi - t : t;
@@ -71,7 +88,7 @@ __device__ __forceinline__ double lean_asin(double t) {
   }
   double p = kAsinQ[12];
 #pragma unroll
-  for (int k = 11; k >= 0; k--) p = __builtin_fma(p, r, kAsinQ[k]);
+  for (int k = 11; k >= 0; k--) p = horner_step(p, r, kAsinQ[k]);
   const double u = __builtin_fma(s * r, p, s);
   constexpr double kHalfPi = 1.57079632679489661923;
   const double v = big ? __builtin_fma(-2.0, u, kHalfPi) : u;

@@ -94,34 +94,55 @@ struct BeWarp {
   float m[6];
 };
 
-// the arithmetic of the back-end warp on already-loaded operands: bearing (b0,b1,b2) and the batch rotation R[9].
+// Back-end arithmetic and FMA contraction (round 5).  The library is built with -ffp-contract=off so that the FRONT end's fp64 warp is
+// the reference's x86-64 (no FMA) arithmetic bit for bit.  The back end never was bit-identical -- its atan2 / asin are polynomial forms
+// 1-3 ulp from glibc's (cmx_trig.hpp, themselves FMA chains) -- so the rotation R b, |R b|^2, the Newton steps and the pixel
+// coordinate are contracted too: a difference of ~1e-16 relative in the ray, far below the trig forms' own, for 15 fp64 instructions
+// less per event in kernels whose VALU issue is what binds them (profiles/r05_be_valu.txt).  Every back-end kernel (tile keys, splat,
+// gather, reference-shaped splat) goes through these two functions, so they agree with one another on every vote cell bit for bit.
+// Z1: the bearing's z is the constant 1 (tile- / time-ordered bearing streams hold (x, y) only): R[2], R[5], R[8] are added, not multiplied.
+template <bool Z1>
+__device__ __forceinline__ void be_rotate(const double *R, double b0, double b1, double b2, double &x, double &y, double &z) {
+#pragma clang fp contract(fast)
+  if (Z1) {
+    x = R[0] * b0 + (R[1] * b1 + R[2]);
+    y = R[3] * b0 + (R[4] * b1 + R[5]);
+    z = R[6] * b0 + (R[7] * b1 + R[8]);
+  } else {
+    x = R[0] * b0 + (R[1] * b1 + R[2] * b2);
+    y = R[3] * b0 + (R[4] * b1 + R[5] * b2);
+    z = R[6] * b0 + (R[7] * b1 + R[8] * b2);
+  }
+}
+
+// the arithmetic of the back-end warp behind the rotation: e_ray_w = (x, y, z) = R * bearing.
 // DERIV = 1: d(pixel)/d(rotation) with the projection Jacobian evaluated in fp64 and cast to fp32 entry by entry,
 //            exactly the reference's Matx23f (equirectangular_camera.h:33-44) -- the derivative-plane (faithful) mode.
 // DERIV = 2: the same five entries evaluated in fp32 from the fp64 ray (the reference multiplies them in fp32 anyway,
 //            event_pano_warper.cpp:281-285); relative difference ~1e-7 per entry, saves five fp64 divisions and a
 //            square root per event in the ALU-bound gather pass of the adjoint mode.
 template <int DERIV>
-__device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e, int batch, double b0, double b1,
-                                              double b2, const double *R) {
+__device__ __forceinline__ BeWarp be_project(const BeSplatArgs &a, uint32_t e, int batch, double x, double y, double z) {
   BeWarp w;
   w.is_old = (e >> 31) != 0;
   w.batch = batch;
-  // e_ray_w = R * bearing
-  const double x = R[0] * b0 + R[1] * b1 + R[2] * b2;
-  const double y = R[3] * b0 + R[4] * b1 + R[5] * b2;
-  const double z = R[6] * b0 + R[7] * b1 + R[8] * b2;
-  // equirectangular projection
-  const double phi = lean_atan2(x, z);  // (cmx_trig.hpp: the two transcendental calls were three quarters of this function)
-  // rho = |R b|: the reference's sqrt and division (y / rho) as ONE reciprocal square root -- v_rsq_f64 and two Newton steps
-  // (~14 instructions against ~45; y * (1/rho) is within 2 ulp of y / rho, i.e. 1e-16 of the pixel coordinate)
-  const double rho2 = x * x + y * y + z * z;
-  double inv_rho = __builtin_amdgcn_rsq(rho2);
-  inv_rho = inv_rho * (1.5 - 0.5 * rho2 * inv_rho * inv_rho);
-  inv_rho = inv_rho * (1.5 - 0.5 * rho2 * inv_rho * inv_rho);
-  const double rho = rho2 * inv_rho;
-  const double theta = lean_asin(y * inv_rho);
-  const double pxm = a.cxp + phi * a.fx;
-  const double pym = a.cyp + theta * a.fy;
+  double pxm, pym, rho;
+  {
+#pragma clang fp contract(fast)  // (this block only: the Jacobian entries below keep the reference's operation-by-operation rounding)
+    // equirectangular projection
+    const double phi = lean_atan2(x, z);  // (cmx_trig.hpp: the two transcendental calls were three quarters of this function)
+    // rho = |R b|: the reference's sqrt and division (y / rho) as ONE reciprocal square root -- v_rsq_f64 and two Newton steps
+    // (~14 instructions against ~45; y * (1/rho) is within 2 ulp of y / rho, i.e. 1e-16 of the pixel coordinate)
+    const double rho2 = x * x + (y * y + z * z);
+    double inv_rho = __builtin_amdgcn_rsq(rho2);
+    const double h = 0.5 * rho2;
+    inv_rho = inv_rho * (1.5 - (h * inv_rho) * inv_rho);
+    inv_rho = inv_rho * (1.5 - (h * inv_rho) * inv_rho);
+    rho = rho2 * inv_rho;
+    const double theta = lean_asin(y * inv_rho);
+    pxm = a.cxp + phi * a.fx;
+    pym = a.cyp + theta * a.fy;
+  }
   w.xx = (int)pxm;
   w.yy = (int)pym;
   w.ok = (1 <= w.xx && w.xx < a.Wp - 2 && 1 <= w.yy && w.yy < a.Hp - 2);
@@ -165,6 +186,15 @@ __device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e,
     w.m[5] = d10 * (-rby) + d11 * rbx;
   }
   return w;
+}
+
+// rotation + projection on already-loaded operands: bearing (b0, b1, b2) and the batch rotation R[9]
+template <int DERIV>
+__device__ __forceinline__ BeWarp be_warp_math(const BeSplatArgs &a, uint32_t e, int batch, double b0, double b1,
+                                              double b2, const double *R) {
+  double x, y, z;
+  be_rotate<false>(R, b0, b1, b2, x, y, z);
+  return be_project<DERIV>(a, e, batch, x, y, z);
 }
 
 template <int DERIV>
