@@ -39,6 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# fp64 vector issue: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 fp64 instruction per 4 clocks per SIMD (78.6 TFLOP/s fp64 vector = 2 flop x
+# 64 lanes x this) = 614.4 G wave-instructions/s = 39.3 T lane-instructions/s.  The back-end kernels' VALU instructions are a mix (fp64
+# at 4 clocks, fp32 / integer at 2): pricing every one of them at the fp64 rate is the generous-to-the-hardware reading, frac <= 1.
+VALU_FP64_PEAK_TLANE = 256 * 4 * 2.4e9 / 4 * 64 / 1e12
 METRIC = "warped-events/sec/GPU (1M ev, 640x480 IWE) + CMax iters/sec"
 
 
@@ -329,6 +333,31 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     # the honest per-launch figure: mandatory bytes (<= algorithmic) over the live duration; `frac` <= 1 by construction
     achieved = dom_mand / (dms * 1e-3) / 1e9
     mand_eval = sum(models.get(k, (0, 0))[1] * per_eval.get(k, 1.0) for k in kernel_ms if k != "comm")
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)), "traffic_note": pmc_note,
+                "model": "hbm-mandatory bytes per launch (coalesced per-event streams + one pass over each plane + one 4-byte "
+                         "write per non-zero IWE pixel) / live kernel duration",
+                "limited_by": LIMITED_BY.get((kind, dom)),
+                "bytes_per_launch": dom_mand, "avg_launch_ms": dms, "events_per_launch": int(n_local),
+                "alg_bytes_per_launch_8d": dom_alg, "ratio_8d_bytes_to_peak": dom_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "ratio_8d_bytes_to_peak uses SURVEY 8(d)'s algorithmic bytes (vote read-modify-writes counted as memory "
+                        "traffic although they stay in LDS): it is not an HBM fraction and may exceed 1 for large launches"}
+    # Price the kernel against what BINDS it.  The back end's per-event kernels issue ~260 VALU instructions per event, most of them
+    # fp64 (rotation, atan2 / asin polynomials, fp64 gradient sums): with the SQ counters of this build at hand (profiles/pmc_traffic.json,
+    # rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU passes of this command) the headline roofline of a back-end leg is the VALU
+    # pipe at the fp64 issue rate; the HBM figure stays beside it (hbm_frac, hbm_achieved).
+    valu = pmc.get("%s_%s_valu_insts" % (pmc_prefix, dom))
+    if kind == "backend" and valu:
+        t_lane = valu * 64 / (dms * 1e-3) / 1e12
+        act = pmc.get("%s_%s_valu_active_x4clk" % (pmc_prefix, dom))
+        roofline.update({"bound": "valu_fp64", "achieved": t_lane, "peak": VALU_FP64_PEAK_TLANE, "unit": "Tinstr/s",
+                         "frac": t_lane / VALU_FP64_PEAK_TLANE, "hbm_frac": achieved / HBM_PEAK_GBS, "hbm_achieved_gbs": achieved,
+                         "valu_insts_per_launch": valu, "valu_insts_per_event": valu * 64 / max(n_local, 1),
+                         # the pipe's own busy counter: clocks with a VALU instruction issuing, per SIMD, over the launch's clocks
+                         "valu_busy_frac": (act * 4 / 1024 / (dms * 1e-3 * 2.4e9)) if act else None,
+                         "model": "wave-level VALU instructions per launch (SQ_INSTS_VALU) x 64 lanes / live kernel duration, against the fp64 "
+                                  "vector issue rate (one wave instruction per 4 clocks per SIMD: 39.3 T lane-instructions/s); hbm_frac = the "
+                                  "HBM-mandatory bytes of the same launch / duration / 8 TB/s"})
     out = {
         "ms_per_step": ms_step,
         "value": n_total * steps / elapsed,
@@ -336,15 +365,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
                       "kernel_ms": kernel_ms_f},
         "kernel_ms": kernel_ms,
         "kernels": kernels,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("%s_%s" % (pmc_prefix, dom)), "traffic_note": pmc_note,
-                     "model": "hbm-mandatory bytes per launch (coalesced per-event streams + one pass over each plane + one 4-byte "
-                              "write per non-zero IWE pixel) / live kernel duration",
-                     "limited_by": LIMITED_BY.get((kind, dom)),
-                     "bytes_per_launch": dom_mand, "avg_launch_ms": dms, "events_per_launch": int(n_local),
-                     "alg_bytes_per_launch_8d": dom_alg, "ratio_8d_bytes_to_peak": dom_alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "note": "ratio_8d_bytes_to_peak uses SURVEY 8(d)'s algorithmic bytes (vote read-modify-writes counted as memory "
-                             "traffic although they stay in LDS): it is not an HBM fraction and may exceed 1 for large launches"},
+        "roofline": roofline,
         "whole_evaluation": {
             "ms": ms_step,
             "sum_of_kernels_ms": sum(kernel_ms[k] * per_eval.get(k, 1.0) for k in kernel_ms if k != "comm"),
@@ -1146,7 +1167,8 @@ def summary_of(out):
     if isinstance(out.get("backend"), dict):
         b = out["backend"]
         s["backend"] = {"fdf_ms": b.get("ms_per_step"), "events_per_s": b.get("value"), "roofline": {k: g(b, "roofline", k) for k in
-                        ("bound", "kernel", "frac", "hbm_frac", "achieved", "peak", "unit") if g(b, "roofline", k) is not None},
+                        ("bound", "kernel", "frac", "hbm_frac", "achieved", "peak", "unit", "valu_insts_per_event", "valu_busy_frac", "avg_launch_ms")
+                        if g(b, "roofline", k) is not None},
                         "whole_evaluation_frac": g(b, "whole_evaluation", "frac"),
                         "cmax_iters_per_s": g(b, "cmax", "iters_per_s"),
                         "cpu_baseline_events_per_s": g(b, "cpu_baseline", "value"),
@@ -1283,7 +1305,8 @@ def _r(v, sig=5):
     return v
 
 
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "hbm_frac")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "hbm_frac",
+                 "valu_insts_per_event", "valu_busy_frac")
 CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "ms_per_step", "host")
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config")

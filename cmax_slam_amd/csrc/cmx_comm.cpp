@@ -115,7 +115,7 @@ static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *fla
   const size_t cap = oop ? 2 * np + (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY) : need;
   int rc = ensure(c, c->d_xstage, c->xstage_cap, cap > need ? cap : need);
   if (!rc && oop) rc = ensure(c, c->d_xstage_b, c->xstage_b_cap, cap);
-  if (!rc && oop) rc = ensure(c, c->d_xstage_out, c->xstage_out_cap, cap);
+  if (!rc && oop && !c->comm_fn_peers) rc = ensure(c, c->d_xstage_out, c->xstage_out_cap, cap);
   if (rc) return rc;
   float *in = c->d_xstage;
   if (oop) {
@@ -123,6 +123,19 @@ static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *fla
     in = c->xstage_sel ? c->d_xstage_b : c->d_xstage;
   }
   launch_xset_copy(false, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, in, flags, ntiles, c->stream);
+  if (c->comm_fn_peers) {  // a group's direct transport: the sum over the members happens inside the unpack kernel
+    c->comm_bytes_eval += (int64_t)need * 4;
+    c->comm_calls_eval++;
+    Span sp(c, CMX_T_COMM);
+    const void *ptrs[16];
+    XsetPeers peers{};
+    const int r = c->comm_fn_peers(c->comm_user, in, ptrs, &peers.n, (void *)c->stream);
+    if (r != 0) return fail(c, CMX_ERR_HIP, "the group's one-shot exchange failed with status %d", r);
+    for (int m = 0; m < peers.n; m++) peers.p[m] = static_cast<const float *>(ptrs[m]);
+    launch_xset_sum_unpack(peers, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, flags, ntiles, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CMX_OK;
+  }
   float *sum = in;
   rc = comm_allreduce_staged(c, in, c->d_xstage_out, need, &sum);
   if (rc) return rc;

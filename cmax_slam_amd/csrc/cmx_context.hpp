@@ -237,6 +237,9 @@ struct cmx_ctx {
   // internal (cmx_group.cpp's direct transport): out-of-place sum of `count` floats, in -> out, ONE host barrier; consecutive calls
   // must alternate their `in` buffer (exchange_tiles does)
   int (*comm_fn_oop)(void *user, const void *in, void *out, size_t count, void *hip_stream) = nullptr;
+  // ... and its first half alone: publish `in`, ONE host barrier, wait for the peers' "send buffer complete" events on the stream, hand
+  // back every member's send pointer -- the caller then sums them inside its own unpack kernel (launch_xset_sum_unpack)
+  int (*comm_fn_peers)(void *user, const void *in, const void **ptrs, int *n, void *hip_stream) = nullptr;
   int comm_rank = 0, comm_size = 1;
   bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
   // exchange set of the sparse plane exchange (cmx_comm.cpp): the tiles whose partial sums travel.  Two list / membership buffers

@@ -243,7 +243,8 @@ int direct_allreduce(void *user, void *buf, size_t count, int dt, int op, void *
 // no peer ever waits for this member's kernel; (2) the caller alternates two send buffers, and a member's "ready" event of collective
 // k+1 is recorded on its stream behind its kernel of collective k -- whoever has waited for the peers' events of collective k+1 knows
 // that every read of its collective-k send buffer is over before it packs collective k+2 into the same buffer.
-int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hip_stream) {
+// first half: publish, barrier, waits; ptrs[k] = member k's send buffer (cmx_ctx::comm_fn_peers)
+int direct_peers(void *user, const void *in, const void **ptrs, int *n_out, void *hip_stream) {
   auto *u = static_cast<cmx_group::DirectUser *>(user);
   cmx_group *g = u->g;
   const int me = u->rank, n = g->n;
@@ -252,11 +253,21 @@ int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hi
   g->os_in[par][me] = in;
   if (hipEventRecord(g->ev_os[par][me], s) != hipSuccess) return 1;  // my send buffer is complete behind this point
   if (!group_barrier(g)) return 2;                                   // every pointer published, every event recorded
-  PeerPtrs pp{};
   for (int k = 0; k < n; k++) {
-    pp.p[k] = const_cast<void *>(g->os_in[par][k]);
+    ptrs[k] = g->os_in[par][k];
     if (k != me && hipStreamWaitEvent(s, g->ev_os[par][k], 0) != hipSuccess) return 1;
   }
+  *n_out = n;
+  return 0;
+}
+int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hip_stream) {
+  const void *ptrs[kMaxMembers];
+  int n = 0;
+  const int rc = direct_peers(user, in, ptrs, &n, hip_stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)hip_stream;
+  PeerPtrs pp{};
+  for (int k = 0; k < n; k++) pp.p[k] = const_cast<void *>(ptrs[k]);
   int blocks = (int)((count / 4 + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(peer_sum_oneshot_kernel, dim3(blocks), dim3(256), 0, s, pp, static_cast<float *>(out), n, count);
@@ -366,7 +377,7 @@ static void group_teardown(cmx_group *g) {
     cmx_ctx *m = g->m[r];
     if (!m) continue;
     m->group = nullptr;
-    if (m->comm_fn) { m->comm_fn = nullptr; m->comm_fn_oop = nullptr; m->comm_user = nullptr; }
+    if (m->comm_fn) { m->comm_fn = nullptr; m->comm_fn_oop = nullptr; m->comm_fn_peers = nullptr; m->comm_user = nullptr; }
     cmx_destroy(m);
   }
   delete g;
@@ -408,6 +419,7 @@ static int group_connect(cmx_group *g, cmx_ctx *leader, const int *devices, int 
       g->duser[r].rank = r;
       g->m[r]->comm_fn = direct_allreduce;
       g->m[r]->comm_fn_oop = direct_oneshot;
+      g->m[r]->comm_fn_peers = direct_peers;
       g->m[r]->comm_user = &g->duser[r];
       g->m[r]->comm_rank = r;
       g->m[r]->comm_size = n_devices;

@@ -908,6 +908,55 @@ void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const
   else hipLaunchKernelGGL(xset_copy_kernel<false>, grid, dim3(256), 0, s, planes, np, W, H, tiles_x, list, n, stage, flags, ntiles);
 }
 
+// The group's one-shot exchange fused with the unpack: every member reads ALL members' packed send buffers (peer pointers; 16-byte loads)
+// and writes the sum -- added in member order: the same bits on every member -- straight into its own planes and occupancy map.  No
+// receive buffer, no separate unpack launch (cmx_group.cpp: direct_peers; cmx_comm.cpp: exchange_tiles).
+__global__ __launch_bounds__(256) void xset_sum_unpack_kernel(XsetPeers in, float *planes, size_t np, int W, int H, int tiles_x, const int *list,
+                                                              int n, unsigned char *flags, int ntiles) {
+  if (blockIdx.y == 2) {
+    const size_t off = (size_t)2 * n * (kTileX * kTileY);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+      float v = in.p[0][off + t];
+      for (int m = 1; m < in.n; m++) v += in.p[m][off + t];
+      flags[t] = v > 0.f ? 1 : 0;
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= n) return;
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int tile = list[i];
+  const int x0 = (tile % tiles_x) * kTileX, y0 = (tile / tiles_x) * kTileY;
+  float *img = planes + (size_t)plane * np;
+  const size_t base = ((size_t)plane * n + i) * (kTileX * kTileY);
+  static_assert(kTileX % 4 == 0 && (kTileX * kTileY) % 1024 == 0, "one float4 per thread per pass");
+  for (int p = threadIdx.x * 4; p < kTileX * kTileY; p += 1024) {
+    float4 acc = *reinterpret_cast<const float4 *>(in.p[0] + base + p);
+    for (int m = 1; m < in.n; m++) {
+      const float4 v = *reinterpret_cast<const float4 *>(in.p[m] + base + p);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int lx = p % kTileX, ly = p / kTileX;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gy < H) {
+      float *dst = img + (size_t)gy * W + gx;
+      if (gx + 3 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) *reinterpret_cast<float4 *>(dst) = acc;
+      else {
+        if (gx < W) dst[0] = acc.x;
+        if (gx + 1 < W) dst[1] = acc.y;
+        if (gx + 2 < W) dst[2] = acc.z;
+        if (gx + 3 < W) dst[3] = acc.w;
+      }
+    }
+  }
+}
+void launch_xset_sum_unpack(const XsetPeers &in, float *planes, size_t np, int W, int H, const int *list, int n, unsigned char *flags,
+                            int ntiles, hipStream_t s) {
+  if (n <= 0 && !flags) return;
+  const int tiles_x = (W + kTileX - 1) / kTileX;
+  const dim3 grid(n > 0 ? n : 1, flags ? 3 : 2);
+  hipLaunchKernelGGL(xset_sum_unpack_kernel, grid, dim3(256), 0, s, in, planes, np, W, H, tiles_x, list, n, flags, ntiles);
+}
+
 size_t image_lds_bytes(int r) {
   const int rawW = kTileX + 2 * r, rawH = kTileY + 2 * r;
   return sizeof(float) * ((size_t)rawW * rawH + (size_t)kTileX * rawH) + sizeof(double) * 8;
@@ -1585,7 +1634,7 @@ __device__ __forceinline__ void border_grad(const float *cx, const float *cy, in
 
 int gather_blocks(int n) {
   int blocks = (n + 255) / 256;
-  const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~130 VGPRs: 3 blocks/CU is its occupancy)
+  const int cap = 768;  // 3 workgroups per CU (be_gather is fp64-ALU bound at ~150 VGPRs: 3 blocks/CU is its occupancy)
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 // front end: one workgroup per kFeGatherPerBlock events up to the cap.  Swept on MI355X with the bearing / dt streams

@@ -37,6 +37,7 @@ CMX_HD Quat q_mul(Quat a, Quat b) {
 }
 // product re-normalised with one reciprocal instead of four divisions (pose-table chain; <= 1 ulp from q_mul)
 CMX_HD Quat q_mul_rcp(Quat a, Quat b) {
+#pragma clang fp contract(fast)  // device pose-table chain only (the host has no FMA to contract into): see spline_eval_pre
   Quat r;
   r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
   r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
@@ -74,6 +75,7 @@ CMX_HD void so3_log(Quat q, double out[3]) {
   out[0] = f * q.x; out[1] = f * q.y; out[2] = f * q.z;
 }
 CMX_HD Mat3 q_to_R(Quat q) {
+#pragma clang fp contract(fast)
   const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
   const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
   const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
@@ -85,6 +87,7 @@ CMX_HD Mat3 q_to_R(Quat q) {
   return R;
 }
 CMX_HD Mat3 m3_mul(const Mat3 &a, const Mat3 &b) {
+#pragma clang fp contract(fast)  // 9 multiplies + 18 FMAs instead of 27 + 18 on the device (the pose table is ~15 of these per batch)
   Mat3 o;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -247,6 +250,10 @@ inline void spline_precompute(const SplineArgs &sp, SplineArgsPre &o) {  // host
 template <int N, bool WANT_J>
 CMX_HD void spline_eval_pre(const SplineArgsPre &sp, const Quat *knots, const PairConsts *pair, long long t_ns, Mat3 &R,
                             Mat3 *Jblocks, int &start_idx) {
+  // Contracted on the device (round 5): one wave per SIMD walks ~1850 dependent fp64 operations per batch -- the kernel is that chain's
+  // latency; FMAs shorten it.  Pinned against the reference's compiled Basalt at 2e-14 (tests/test_gpu_pose_table.py); an FMA rounds once
+  // where mul + add round twice.
+#pragma clang fp contract(fast)
   const long long st = t_ns - sp.start_ns;
   const long long s = st / sp.dt_ns;
   const double u = (double)(st % sp.dt_ns) / (double)sp.dt_ns;

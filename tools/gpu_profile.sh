@@ -14,6 +14,10 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > 
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o pmc -- $BENCH > $OUT/pmc_tcc.log 2>&1
+# instruction issue (round 5: the back-end kernels are priced against the VALU pipe that binds them, bench.py roofline.bound "valu_fp64")
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD -d $OUT/pmc_sq_insts -o pmc -- $BENCH > $OUT/pmc_sq_insts.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $OUT/pmc_sq_active -o pmc -- $BENCH > $OUT/pmc_sq_active.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq_waves -o pmc -- $BENCH > $OUT/pmc_sq_waves.log 2>&1
 # FETCH_SIZE calibration on known byte counts in the kernels' own access widths (tools/microbench/fetch_calib.hip)
 if [ -x $REPO/tools/microbench/fetch_calib ]; then
   timeout 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_calib -o pmc -- $REPO/tools/microbench/fetch_calib > $OUT/pmc_calib.log 2>&1

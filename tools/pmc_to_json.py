@@ -62,7 +62,7 @@ NAMES = {
 def main(path):
     vals = {}
     for line in open(path):
-        m = re.match(r"(.{58})\s+(FETCH_SIZE|WRITE_SIZE)\s+([\d.]+)", line)
+        m = re.match(r"(.{58})\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|SQ_ACTIVE_INST_LDS|SQ_BUSY_CYCLES|SQ_WAVES|SQ_WAVE_CYCLES)\s+([\d.]+)", line)
         if not m:
             continue
         vals.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
@@ -94,8 +94,19 @@ def main(path):
                     stream_raw = min(STREAM_BYTES[key] / 2, fetch)
                     row["stream_bytes_known"] = STREAM_BYTES[key]
                     row["bytes_lower"] = 2 * stream_raw + (fetch - stream_raw) + d["WRITE_SIZE"] * 1024
+                # instruction issue of the same launches (separate PMC passes): wave-level VALU instructions, and the clocks the VALU
+                # pipes were issuing (SQ_ACTIVE_INST_VALU counts in units of 4 clocks, summed over the chip's SIMDs)
+                for cname, oname in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_ACTIVE_INST_VALU", "valu_active_x4clk"),
+                                     ("SQ_ACTIVE_INST_LDS", "lds_active_x4clk"), ("SQ_BUSY_CYCLES", "sq_busy_cycles"), ("SQ_WAVES", "waves"),
+                                     ("SQ_WAVE_CYCLES", "wave_cycles_x4clk")):
+                    if cname in d:
+                        row[oname] = d[cname]
                 out["kernels"][key] = row
                 out[key] = cor
+                if "valu_insts" in row:
+                    out[key + "_valu_insts"] = row["valu_insts"]
+                if "valu_active_x4clk" in row:
+                    out[key + "_valu_active_x4clk"] = row["valu_active_x4clk"]
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
