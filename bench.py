@@ -120,13 +120,15 @@ def load_pmc():
 # What the counters and the same-box A/B diagnostics say binds the dominant kernels (`bound` stays the roofline `frac` is computed
 # against -- HBM, the only roofline this scatter / gather / stream path has; it is not what the launch waits for at these sizes).
 LIMITED_BY = {
-    ("frontend", "gather"): "launch + tail latency: dispatching ~1000 workgroups 4.1 us + last-arriver finalize 4.7 us of 13.5 us; the event "
-                            "loop (24 MB of streams, warps, Jt cells) runs 6.1 us = 3.9 TB/s (profiles/r04_fe_gather_anatomy.txt)",
-    ("backend", "gather"): "fp64 VALU issue + dependent chains at 3 waves/SIMD (163 VGPRs): 322 VALU instructions/event, VALU pipes 63 % "
-                           "busy, no single part removes more than 10 % (profiles/r03_be_splat_bound.txt sections 1, 5)",
-    ("backend", "splat"): "per-iteration dependent chain (stream loads -> pose gather -> projection -> LDS votes) at 3 waves/SIMD; the 1.5x "
-                          "fabric traffic of the pose gather costs no time (profiles/r04_be_splat_pose_traffic.txt)",
-    ("frontend", "splat"): "launch latency of its shape (profiles/r02_splat_timeline.txt)",
+    ("frontend", "gather"): "launch + tail latency: ~4 us of launch latency + 4.7 us last-arriver finalize of 13.9 us, whatever the launch shape "
+                            "(977, 489 or 245 workgroups: 13.6-13.8 us, profiles/r05_fe_shape.txt); the event loop runs 6 us = 3.9 TB/s "
+                            "(profiles/r04_fe_gather_anatomy.txt)",
+    ("backend", "gather"): "fp64 VALU issue (230 VALU instructions/event, pipes 0.57 busy) + the dependent steps of a wave iteration at 3 "
+                           "waves/SIMD (half of a wave's life is a wait); 4 waves, LDS-held coefficients and interleaved polynomial chains "
+                           "measured and rejected (profiles/r05_be_valu.txt)",
+    ("backend", "splat"): "per-iteration dependent chain (stream loads -> pose gather -> projection -> LDS votes): VALU pipes 0.47 busy, HBM 0.60 "
+                          "by the counters; more waves per SIMD buy nothing (profiles/r05_be_valu.txt, r04_be_splat_pose_traffic.txt)",
+    ("frontend", "splat"): "launch latency of its shape (profiles/r02_splat_timeline.txt, r05_fe_shape.txt)",
 }
 
 
