@@ -1045,6 +1045,16 @@ def group_on_one_device(device, w, steps=200):
         cs, gs = ev.eval_each(pts, True)
         ms = (time.perf_counter() - t0) * 1e3 / len(pts)
         res[name] = {"fdf_ms": ms, "events_per_s": len(w.x) / ms * 1e3, "contrast": float(cs[-1])}
+        # what the spin policy costs (CMX_OPT_SPIN_WAIT; 1 = default: evaluations spin on their ticket, idle threads spin 50 us then sleep;
+        # 0 = never spin; 20 = a 20 us budget everywhere): the same loop under each setting
+        pol = {}
+        for val in (0, 20, 1):
+            ev.set_option(_lib.OPT_SPIN_WAIT, val)
+            ev.eval_each(pts[:16], True)
+            t0 = time.perf_counter()
+            ev.eval_each(pts, True)
+            pol[{0: "never_spin", 20: "budget_20us", 1: "default"}[val]] = (time.perf_counter() - t0) * 1e3 / len(pts)
+        res[name]["fdf_ms_by_spin_policy"] = pol
         if devs:
             st, info = ev.stats(), ev.group_info()
             res[name].update({"comm_bytes_last_evaluation": st["comm_bytes"], "exchange_set_tiles": st["exchange_tiles"],
@@ -1191,6 +1201,8 @@ def summary_of(out):
     if isinstance(out.get("group"), dict):
         if "overhead_ms" in out["group"]:
             s["group_2_members_one_device"] = {"overhead_ms": out["group"].get("overhead_ms"),
+                                               "fdf_ms_never_spin_vs_default": [g(out["group"], "group_of_2_on_one_device", "fdf_ms_by_spin_policy", "never_spin"),
+                                                                                g(out["group"], "group_of_2_on_one_device", "fdf_ms_by_spin_policy", "default")],
                                                "per_window_ratio_to_solve_store": g(out["group"], "per_window", "device_store", "sequential", "ratio_to_solve"),
                                                "per_window_ratio_to_solve_host": g(out["group"], "per_window", "host_arrays", "sequential", "ratio_to_solve"),
                                                "set_window_ms_store": g(out["group"], "per_window", "device_store", "set_window_ms"),
