@@ -415,3 +415,14 @@ def test_spin_policy_changes_no_result_and_an_idle_group_gives_its_cores_back(hi
     _same(grp, one, [(d, True)])                                            # woken again
     grp.close()
     one.close()
+
+
+def test_group_exchange_soak_short():
+    """tools/soak_group.py at a size the suite can afford: wandering and jumping parameters, new windows in between, groups of 2 / 3 / 4
+    members on one device, every 7th evaluation against a single context (60 000 evaluations of it ran clean on the round-5 build)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_group.py"), "700"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "soak ok" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
