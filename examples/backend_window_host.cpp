@@ -7,10 +7,15 @@
 // with gsl_multimin_function_fdf-shaped callbacks (global_contrast_f / _df / _fdf,
 // src/backend/global_optim_contrast_gsl_analytical.cpp:17-81) over cmx_frcg_minimize.  No Python, no torch, no Eigen.
 //
-//   run:  examples/backend_window_host window.bin [devices]    (window.bin written by tests/test_gpu_cpp_host.py)
+//   run:  examples/backend_window_host window.bin [devices] [store]   (window.bin written by tests/test_gpu_cpp_host.py)
 //
 // devices (optional, e.g. "0,1,2,3" or "0,0"): the same host code on a GROUP handle (cmx_backend_create_group) -- one
 // process, one thread, one optimiser, the window's batches sharded over the listed devices; nothing else in this file changes.
+// store (optional, the literal word): the events go through the device-resident event store the way the reference keeps them in
+// AngVelEstimator::events_ -- pushed in chunks as they "arrive" (cmx_events_push; with a device list: cmx_events_create_group, one
+// replica per device), the window CUT from it by global index (cmx_backend_set_window_from = PoseGraphOptimizer::getEventSubset,
+// pose_graph_optimizer.cpp:131-165, without the copy; on a group every member cuts its own batch range on its own device), the
+// events before the next window's start dropped afterwards (cmx_events_drop_before = deleteOldEvents, ang_vel_estimator.cpp:149-173).
 //
 // window.bin (little endian): int32 W, H, Wp, Hp, order, K, num_fixed, n_av; int64 n, start_ns, dt_ns, t_next_ns,
 //   t_win_beg_ns, t_win_end_ns; double dt_knots; uint16 x[n], y[n]; int64 t_ns[n]; double lut[W*H*3];
@@ -19,6 +24,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "cmax_hip.h"
@@ -74,7 +80,7 @@ bool read_vec(FILE *fp, std::vector<T> &v, size_t n) {
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s window.bin [devices, e.g. 0,1]\n", argv[0]);
+    fprintf(stderr, "usage: %s window.bin [devices, e.g. 0,1] [store]\n", argv[0]);
     return 2;
   }
   FILE *fp = fopen(argv[1], "rb");
@@ -126,6 +132,23 @@ int main(int argc, char **argv) {
     }
   if (devices.size() > 1) CHECK_RC(cmx_backend_create_group(&opt.cmx, devices.data(), (int)devices.size(), W, H, lut.data(), Wp, Hp, CMX_GROUP_AUTO));
   else CHECK_RC(cmx_backend_create(&opt.cmx, devices.empty() ? 0 : devices[0], W, H, lut.data(), Wp, Hp));
+  const bool use_store = argc > 3 && std::string(argv[3]) == "store";
+  cmx_events *store = nullptr;
+  if (use_store) {
+    const int dev0 = devices.empty() ? 0 : devices[0];
+    if (devices.size() > 1) CHECK_RC(cmx_events_create_group(&store, devices.data(), (int)devices.size(), W, H, (size_t)n + 1024));
+    else CHECK_RC(cmx_events_create(&store, dev0, W, H, (size_t)n + 1024));
+    const int64_t chunk = 7000;  // the stream arrives in packets
+    for (int64_t at = 0; at < n; at += chunk) {
+      const int64_t m = (n - at < chunk) ? n - at : chunk;
+      if (cmx_events_push(store, m, x.data() + at, y.data() + at, t.data() + at) != CMX_OK) {
+        fprintf(stderr, "cmx_events_push: %s\n", cmx_events_last_error(store));
+        return 1;
+      }
+    }
+    CHECK_RC(cmx_backend_set_window_from(opt.cmx, store, cmx_events_begin(store), n, order, K, knots.data(), start_ns, dt_ns, num_fixed,
+                                         t_next_ns, 100, 1, 1.0, CMX_VARIANCE, CMX_KEEP_MAP));
+  } else
   CHECK_RC(cmx_backend_set_window(opt.cmx, n, x.data(), y.data(), t.data(), order, K, knots.data(), start_ns, dt_ns, num_fixed,
                                   t_next_ns, 100, 1, 1.0, CMX_VARIANCE, CMX_KEEP_MAP));  // the global map stays on the GPU
   std::vector<double> v0((size_t)opt.n_params, 0.0), g0((size_t)opt.n_params), drotv((size_t)opt.n_params, 0.0);
@@ -168,6 +191,13 @@ int main(int argc, char **argv) {
   for (double k : fitted) printf(" %.17g", k);
   printf("\nlatest %.17g %.17g %.17g %.17g\nmap %.17g %ld %d\n", q_latest[0], q_latest[1], q_latest[2], q_latest[3], map_sum,
          visited, marked);
+  if (store) {  // deleteOldEvents: everything before the next window's first event
+    int64_t keep_from = 0;
+    while (keep_from < n && t[(size_t)keep_from] < t_next_ns) keep_from++;
+    if (cmx_events_drop_before(store, cmx_events_begin(store) + keep_from) != CMX_OK) return 1;
+    printf("store %lld %lld\n", (long long)cmx_events_begin(store), (long long)cmx_events_end(store));
+    cmx_events_destroy(store);
+  }
   cmx_destroy(opt.cmx);
   return 0;
 }

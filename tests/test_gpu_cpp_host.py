@@ -46,12 +46,14 @@ def test_cpp_host_matches_oracle(oracle, tmp_path):
     assert abs(float(line[-1]) - rep_ref["final_cost"]) < 1e-3 * abs(rep_ref["final_cost"])
 
 
-@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0"])
-def test_cpp_backend_window_host(oracle, tmp_path, devices):
+@pytest.mark.parametrize("devices,store", [(None, False), ("0,0", False), ("0,0,0", False), ("0", True), ("0,0,0", True)])
+def test_cpp_backend_window_host(oracle, tmp_path, devices, store):
     """examples/backend_window_host.cpp: one whole back-end window from C++ -- angular-velocity integration and
     control-pose fit (host fp64), window hand-over with the resident map, GSL-shaped callbacks + FR-CG, trajectory
     update, map upkeep.  devices = "0,0" / "0,0,0": the SAME host code on a group handle (cmx_backend_create_group; two / three
-    members sharing this box's GPU) -- the one-process multi-GPU form the reference's single back-end thread can use."""
+    members sharing this box's GPU) -- the one-process multi-GPU form the reference's single back-end thread can use.
+    store: the events pushed in packets into the device event store (a replica per device of the group), the window cut from it
+    (cmx_backend_set_window_from on the plain or the group handle), old events dropped afterwards -- same results."""
     exe = os.path.join(ROOT, "examples", "backend_window_host")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s", "backend_window_host"])
@@ -72,7 +74,8 @@ def test_cpp_backend_window_host(oracle, tmp_path, devices):
         fh.write(np.ascontiguousarray(w.knots_init, "<f8").tobytes())
         fh.write(av_t.astype("<i8").tobytes())
         fh.write(np.ascontiguousarray(av_w, "<f8").tobytes())
-    out = subprocess.run([exe, str(f)] + ([devices] if devices else []), capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(f)] + ([devices] if devices else []) + (["store"] if store else []), capture_output=True, text=True,
+                         timeout=300)
     assert out.returncode == 0, out.stderr
     vals = {}
     for ln in out.stdout.strip().splitlines():
@@ -105,3 +108,6 @@ def test_cpp_backend_window_host(oracle, tmp_path, devices):
     # the global map received IL_old of the last evaluation; two FOV marks over the 0.1 s stride
     map_sum, visited, marked = float(vals["map"][0]), int(vals["map"][1]), int(vals["map"][2])
     assert map_sum > 0 and visited > 0 and marked == 2
+    if store:  # deleteOldEvents: the store now begins at the next window's first event
+        first_kept = int(np.searchsorted(w.t_ns, w.t_next_win_beg_ns, side="left"))
+        assert [int(v) for v in vals["store"]] == [first_kept, len(w.x)]
