@@ -131,6 +131,8 @@ static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *fla
     XsetPeers peers{};
     const int r = c->comm_fn_peers(c->comm_user, in, ptrs, &peers.n, (void *)c->stream);
     if (r != 0) return fail(c, CMX_ERR_HIP, "the group's one-shot exchange failed with status %d", r);
+    peers.xdev = (peers.n >> 8) & 1;
+    peers.n &= 0xff;
     for (int m = 0; m < peers.n; m++) peers.p[m] = static_cast<const float *>(ptrs[m]);
     launch_xset_sum_unpack(peers, c->d_accum, np, c->Wp, c->Hp, list, n > 0 ? n : 0, flags, ntiles, c->stream);
     HIP_TRY(c, hipGetLastError());

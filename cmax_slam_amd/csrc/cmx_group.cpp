@@ -40,7 +40,12 @@ constexpr int kMaxMembers = 16;
 constexpr double kBarrierTimeoutMs = 20000.0;
 
 // ---- the direct transport's kernels.  ptrs[m] = member m's buffer (same length everywhere); member `me` owns slice `me`.
-struct PeerPtrs { void *p[kMaxMembers]; };
+// xdev: the members sit on more than one device -- every kernel that reads a peer's buffer then opens with a SYSTEM-scope acquire (its
+// own L2 may hold lines of the peer's buffer from the previous collective; the producer's side is the event's release to system scope)
+struct PeerPtrs { void *p[kMaxMembers]; int xdev; };
+__device__ __forceinline__ void peer_acquire(int xdev) {
+  if (xdev) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
 
 // Every access is ONE 16-byte load / store per lane (global_load_dwordx4): across xGMI a 4-byte access per lane is the worst width
 // there is.  Slices start on 16-byte boundaries (direct_launch); the last (count % (16 / sizeof T)) elements go one by one.
@@ -51,6 +56,7 @@ __device__ inline T red(T a, T b) { return MAX ? (b > a ? b : a) : (T)(a + b); }
 
 template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void peer_reduce_scatter_kernel(PeerPtrs pp, int n, int me, size_t beg, size_t end) {
+  peer_acquire(pp.xdev);
   constexpr int L = 16 / sizeof(T);
   T *mine = static_cast<T *>(pp.p[me]);
   const size_t nv = (end - beg) / L;
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(256) void peer_reduce_scatter_kernel(PeerPtrs pp, i
 }
 template <typename T>
 __global__ __launch_bounds__(256) void peer_all_gather_kernel(PeerPtrs pp, int n, int me, size_t per, size_t count) {
+  peer_acquire(pp.xdev);
   constexpr int L = 16 / sizeof(T);
   T *mine = static_cast<T *>(pp.p[me]);
   for (int m = 0; m < n; m++) {
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256) void peer_all_gather_kernel(PeerPtrs pp, int n
 // buffers over the whole range and writes the sum, added in member order (the same bits everywhere), to its OWN receive buffer.
 // Nobody writes a buffer a peer reads: one host barrier, one set of event waits, no gather phase (cmx_group.cpp: direct_oneshot).
 __global__ __launch_bounds__(256) void peer_sum_oneshot_kernel(PeerPtrs in, float *__restrict out, int n, size_t count) {
+  peer_acquire(in.xdev);
   const size_t nv = count / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
     float4 acc = static_cast<const float4 *>(in.p[0])[i];
@@ -138,6 +146,7 @@ struct cmx_group {
   int n = 0;
   int transport = CMX_GROUP_DIRECT;
   cmx_ctx *m[kMaxMembers] = {nullptr};
+  bool cross_device = false;  // members on more than one device (the peer kernels' acquire scope)
   std::vector<std::thread> workers;
   // ---- command word: the leader publishes, the workers run it on their member
   std::atomic<unsigned long long> seq{0};
@@ -191,6 +200,7 @@ bool group_barrier(cmx_group *g) {
 template <typename T>
 void direct_launch(cmx_group *g, int me, size_t count, int op, hipStream_t s, bool gather_phase) {
   PeerPtrs pp{};
+  pp.xdev = g->cross_device ? 1 : 0;
   for (int k = 0; k < g->n; k++) pp.p[k] = g->slot_ptr[k];
   // slices of whole 16-byte groups; member r owns [r*per, (r+1)*per)
   const size_t grp = 16 / sizeof(T);
@@ -244,7 +254,7 @@ int direct_allreduce(void *user, void *buf, size_t count, int dt, int op, void *
 // k+1 is recorded on its stream behind its kernel of collective k -- whoever has waited for the peers' events of collective k+1 knows
 // that every read of its collective-k send buffer is over before it packs collective k+2 into the same buffer.
 // first half: publish, barrier, waits; ptrs[k] = member k's send buffer (cmx_ctx::comm_fn_peers)
-int direct_peers(void *user, const void *in, const void **ptrs, int *n_out, void *hip_stream) {
+int direct_peers(void *user, const void *in, const void **ptrs, int *n_out, void *hip_stream) {  // *n_out: members, | 0x100 when they span devices
   auto *u = static_cast<cmx_group::DirectUser *>(user);
   cmx_group *g = u->g;
   const int me = u->rank, n = g->n;
@@ -257,7 +267,7 @@ int direct_peers(void *user, const void *in, const void **ptrs, int *n_out, void
     ptrs[k] = g->os_in[par][k];
     if (k != me && hipStreamWaitEvent(s, g->ev_os[par][k], 0) != hipSuccess) return 1;
   }
-  *n_out = n;
+  *n_out = n | (g->cross_device ? 0x100 : 0);
   return 0;
 }
 int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hip_stream) {
@@ -265,8 +275,10 @@ int direct_oneshot(void *user, const void *in, void *out, size_t count, void *hi
   int n = 0;
   const int rc = direct_peers(user, in, ptrs, &n, hip_stream);
   if (rc) return rc;
+  n &= 0xff;
   hipStream_t s = (hipStream_t)hip_stream;
   PeerPtrs pp{};
+  pp.xdev = static_cast<cmx_group::DirectUser *>(user)->g->cross_device ? 1 : 0;
   for (int k = 0; k < n; k++) pp.p[k] = const_cast<void *>(ptrs[k]);
   int blocks = (int)((count / 4 + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
@@ -445,6 +457,7 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
   cmx_group *g = new cmx_group();
   g->n = n_devices;
   g->transport = transport;
+  for (int a = 1; a < n_devices; a++) g->cross_device = g->cross_device || devices[a] != devices[0];
   int rc = CMX_OK;
   for (int r = 0; r < n_devices && !rc; r++) {
     rc = cmx_backend_create(&g->m[r], devices[r], W, H, lut, Wp, Hp);

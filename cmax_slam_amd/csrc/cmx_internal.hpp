@@ -308,7 +308,7 @@ void launch_image_moments(const ImgArgs &a, hipStream_t s, hipEvent_t t0 = nullp
 void launch_finalize(const FinalizeArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_xset(const unsigned char *flags, int tiles_x, int tiles_y, const unsigned char *cur_member, int *next_list,
                  unsigned char *next_member, int *miss_list, double *out, unsigned long long seq, hipStream_t s);
-struct XsetPeers { const float *p[16]; int n; };  // the members' packed send buffers of one exchange (cmx_group.cpp's direct transport)
+struct XsetPeers { const float *p[16]; int n; int xdev; };  // xdev: the buffers live on several devices (system-scope acquire first)  // the members' packed send buffers of one exchange (cmx_group.cpp's direct transport)
 void launch_xset_sum_unpack(const XsetPeers &in, float *planes, size_t np, int W, int H, const int *list, int n, unsigned char *flags,
                             int ntiles, hipStream_t s);
 void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const int *list, int n, float *stage, unsigned char *flags,

@@ -913,6 +913,7 @@ void launch_xset_copy(bool unpack, float *planes, size_t np, int W, int H, const
 // receive buffer, no separate unpack launch (cmx_group.cpp: direct_peers; cmx_comm.cpp: exchange_tiles).
 __global__ __launch_bounds__(256) void xset_sum_unpack_kernel(XsetPeers in, float *planes, size_t np, int W, int H, int tiles_x, const int *list,
                                                               int n, unsigned char *flags, int ntiles) {
+  if (in.xdev) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // peers on other devices: this device's L2 may hold their buffers' old lines
   if (blockIdx.y == 2) {
     const size_t off = (size_t)2 * n * (kTileX * kTileY);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
