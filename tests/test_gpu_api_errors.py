@@ -81,3 +81,43 @@ def test_backend_argument_errors(hip):
         be.eval(np.zeros(3))  # wrong parameter count is caught before crossing the ABI
     with pytest.raises(hip.CmaxHipError):
         be.get_plane(99)
+
+
+def test_round5_entry_points_reject_bad_arguments(hip):
+    """cmx_events_create_group / cmx_events_devices / cmx_comm_info / cmx_backend_set_window_from: argument errors come back as status
+    codes with a message, nothing is half-installed."""
+    import ctypes as C
+    from cmax_slam_amd import _lib, synth
+    L = _lib.lib()
+    h = C.c_void_p()
+    dv = (C.c_int * 2)(0, 99)
+    assert L.cmx_events_create_group(C.byref(h), dv, 2, 64, 48, 1000) == _lib.ERR_INVALID_ARG and not h.value      # no such device
+    assert L.cmx_events_create_group(C.byref(h), dv, 0, 64, 48, 1000) == _lib.ERR_INVALID_ARG and not h.value      # empty list
+    assert L.cmx_events_create_group(C.byref(h), None, 1, 64, 48, 1000) == _lib.ERR_INVALID_ARG
+    dv0 = (C.c_int * 3)(0, 0, 0)
+    assert L.cmx_events_create_group(C.byref(h), dv0, 3, 64, 48, 1000) == _lib.OK and h.value
+    out = (C.c_int * 4)()
+    assert L.cmx_events_devices(h, out, 4) == 1 and out[0] == 0               # members sharing a device share its replica
+    assert L.cmx_events_devices(None, out, 4) == 0
+    L.cmx_events_destroy(h)
+
+    w = synth.backend_window(5_000, 64, 48, 55.0, 57.0, 31.5, 23.5, 128, 64, 2, 5, 0, 0.2, seed=5)
+    be = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
+    info = be.comm_info()
+    assert info == {"rank": 0, "nranks": 1, "transport": "none"}
+    assert L.cmx_comm_info(None, None, None, None) == _lib.ERR_INVALID_ARG
+    k = np.ascontiguousarray(w.knots_init, np.float64)
+    rc = L.cmx_backend_set_window_from(be._ctx, None, 0, 10, w.order, w.K, k.ctypes.data_as(_lib.c_dp), int(w.start_ns), int(w.dt_ns), 0,
+                                       int(w.t_next_win_beg_ns), 100, 1, 1.0, 0, None)
+    assert rc == _lib.ERR_INVALID_ARG and b"null event store" in L.cmx_last_error(be._ctx)
+    store = hip.EventStore(w.W + 1, w.H, 10_000)                                  # another sensor
+    store.push(w.x, w.y, w.t_ns)
+    with pytest.raises(hip.CmaxHipError) as e:
+        be.set_window_from(store, 0, len(w.x), w.order, w.knots_init, w.start_ns, w.dt_ns, 0, w.t_next_win_beg_ns)
+    assert e.value.status == _lib.ERR_INVALID_ARG
+    be.K, be.num_fixed = w.K, 0
+    with pytest.raises(hip.CmaxHipError) as e:
+        be.eval(np.zeros(w.P))
+    assert e.value.status == _lib.ERR_STATE                                        # no window was installed
+    store.close()
+    be.close()
