@@ -7,6 +7,7 @@
 // Internal to libcmaxhip.so; gfx950 only.  There is NO CPU fallback: every entry point fails loudly without HIP.
 #pragma once
 #include "../../include/cmax_hip.h"
+#include "../../include/cmax_hip_diag.h"  // the A/B option keys: internal + tests, not the host surface
 
 #include <math.h>
 #include <stdarg.h>

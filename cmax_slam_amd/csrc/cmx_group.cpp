@@ -19,11 +19,15 @@
 // Transports (what an all-reduce between the members is):
 //   CMX_GROUP_RCCL    ncclCommInitAll over the members' devices, one communicator per member, used from its worker
 //                     (RCCL's "one thread per device" mode) -- the default whenever the members sit on different devices;
-//   CMX_GROUP_DIRECT  peer-to-peer kernels, no library: reduce-scatter + all-gather in place over the members' own buffers
-//                     (every slice is summed by exactly one member, in member order: all members hold the same bits),
-//                     ordered by HIP events between the members' streams.  Members on ONE device (what a single-GPU box can
-//                     run: the tests, bench.py's group leg) always use it; across devices it needs peer access (xGMI) and
-//                     has never run on hardware -- opt-in.
+//   CMX_GROUP_DIRECT  peer-to-peer kernels, no library.  The production exchange (a staged tile set below 2 MB) is ONE-SHOT: every
+//                     member packs into one of two alternating send buffers, records one event, meets its peers at one host
+//                     barrier, and its unpack kernel sums ALL members' send buffers (16-byte loads, member order: the same bits
+//                     everywhere) straight into its own planes (direct_peers + cmx_kernels.hip: xset_sum_unpack_kernel).  Whole
+//                     planes (a window's first evaluation, small panoramas) and the u8 / f64 collectives keep reduce-scatter +
+//                     all-gather in place (every slice summed by exactly one member), ordered by HIP events between the members'
+//                     streams.  Members on ONE device (what a single-GPU box can run: the tests, bench.py's group leg,
+//                     tools/soak_group.py) always use it; across devices it needs peer access (xGMI), opens every peer-reading
+//                     kernel with a system-scope acquire, and has never run on hardware -- opt-in.
 #include <condition_variable>
 #include <functional>
 #include <mutex>

@@ -56,11 +56,10 @@ enum {
                           pass over the events gathers from one plane; no derivative planes */
 };
 
-/* cmx_set_option keys.  A host needs at most three of them: CMX_OPT_DETERMINISTIC (bitwise reproducibility), CMX_OPT_SPIN_WAIT (0 to
- * give the waiting core back) and CMX_OPT_GRAD_MODE / CMX_OPT_SPLAT_MODE together to select the reference-shaped data flow.  The
- * others (REUSE_IMAGE, TAIL_FINALIZE, COMPOSITE_IMAGE, FOLD_BATCH, GATED_DF, CHAIN_SOLVE) switch between forms that the library
- * also selects BY ITSELF from the configuration (image size, blur radius, batch size, deterministic mode, communicator attached):
- * they exist so that tests and same-box A/B measurements can reach every form on any input, and default to the fastest one. */
+/* cmx_set_option keys a HOST may need: CMX_OPT_DETERMINISTIC (bitwise reproducibility), CMX_OPT_SPIN_WAIT (how its threads wait) and
+ * CMX_OPT_GRAD_MODE / CMX_OPT_SPLAT_MODE together to select the reference-shaped data flow.  That is the supported surface.  The A/B
+ * switches that tests and same-box measurements use to reach every internal form on any input (forms the library otherwise selects BY
+ * ITSELF from the configuration, defaulting to the fastest) live in include/cmax_hip_diag.h: same cmx_set_option, no stability promise. */
 enum {
   CMX_OPT_GRAD_MODE = 1,  /* CMX_GRAD_ADJOINT (default) | CMX_GRAD_PLANES */
   CMX_OPT_SPLAT_MODE = 2, /* 0 = one global fp32 atomic per vote;
@@ -68,11 +67,6 @@ enum {
                                  tile of their vote, workgroups accumulate in LDS and flush touched pixels; votes that
                                  leave a window (parameters drifted) take the global path, so results stay exact;
                                  applies to the plane-0 splat (cost-only evaluations and CMX_GRAD_ADJOINT) */
-  CMX_OPT_REUSE_IMAGE = 3, /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
-                             the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
-                             df at every accepted point; the reference recomputes everything, :58-70).  A cost-only
-                             evaluation then also runs the adjoint image pass (Jt) instead of the moments-only pass, so the
-                             df that follows launches its gather at once: +3..4 us per f, -12 us per df */
   CMX_OPT_DETERMINISTIC = 5, /* 1: bitwise run-to-run reproducible results (default 0).  With the LDS-privatised splat
                              (CMX_OPT_SPLAT_MODE 1, adjoint gradient or cost-only) every vote that reaches global memory
                              becomes a 64-bit integer add into a 2^-30 fixed-point plane -- integer adds commute -- and
@@ -80,37 +74,6 @@ enum {
                              time order and large panoramas do not use the compacted tile list, so that every
                              floating-point sum has a fixed order.  Costs ~10-20 % per evaluation.  The reference-shaped
                              flow (derivative planes, fp32 atomics) stays order-dependent */
-  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint gradient:
-                             the gather pass / the back end's per-batch pass) runs the finalize step -- contrast, gradient,
-                             result hand-off -- in its last-arriving workgroup (write-through partial sums, tickets sharded
-                             by XCD, sc1 loads) instead of a separate one-workgroup launch behind a kernel boundary.  The
-                             gradient sums of the workgroups reach it through 8 rows of accumulators (device-scope fp64
-                             atomic adds; their order varies run to run, like the vote image's in this mode); with
-                             CMX_OPT_DETERMINISTIC the front end uses a [column][workgroup] table instead and back-end
-                             gradient evaluations keep the separate launch (the 42-column table made the tail slower).
-                             2: tail with the table form everywhere (back-end gradient included).
-                             0: separate finalize launch (the round-1 flow) */
-  /* 7: retired (round 2's opt-in fused gradient pass: measured slower, removed; profiles/r02_pmc_fe_fused_gather.txt) */
-  CMX_OPT_COMPOSITE_IMAGE = 8, /* 1 (default): the image pass of the adjoint gradient applies G^T G as one banded operator per
-                             axis, its 4r+1-term sums accumulated in fp64: three barrier-separated phases per tile instead
-                             of five (radius 4 = the reference's blur_sigma 1 has a register-resident form), and a gradient
-                             that stays within 1e-5 of the exact-arithmetic value of the reference's formula where long fp32
-                             sums do not.  B and the contrast are unchanged to the bit.
-                             0: the four-pass fp32 form */
-  CMX_OPT_FOLD_BATCH = 9, /* 1 (default; back end, adjoint gradient, batches of a multiple of four events, tail finalize on, not
-                             deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
-                             inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
-                             0: separate per-batch kernel */
-  CMX_OPT_CHAIN_SOLVE = 11, /* 1 (default; front end, production path, no communicator): cmx_frontend_solve runs the FR-CG line
-                               search AHEAD of the host -- the optimiser's state machine lives in device memory, the finalize step
-                               of every evaluation advances it and writes the next evaluation point where the next evaluation's
-                               kernels (queued one slot ahead) read it; the host replays the machine on the reported costs /
-                               gradients and takes over on any disagreement, so the result is that of the host-driven solve.
-                               0: host-driven solve (one round trip to the host per evaluation); 2 / 3: test hooks -- the host takes
-                               over after three points / between a cost and its gradient, as it would after a disagreement; 4: the first form of
-                               the slots (a finalize behind the image pass, a flag-gated gradient pass) also where the self-gating
-                               form applies (A/B) */
-  CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
   CMX_OPT_SPIN_WAIT = 4   /* ONE policy for the three places a host thread of this library waits:
                              (a) an evaluation waiting for its last kernel -- spins on a completion ticket that kernel writes to
                                  mapped host memory after the results (a few microseconds sooner than hipStreamSynchronize returns);

@@ -1,0 +1,51 @@
+/* cmax_hip_diag.h -- diagnostic option keys of cmx_set_option (include/cmax_hip.h).
+ *
+ * NOT part of the supported host surface: these keys switch between internal forms of one evaluation that the library selects by
+ * itself from the configuration (image size, blur radius, batch size, deterministic mode, communicator attached), always defaulting
+ * to the fastest.  They exist so that the parity tests and same-box A/B measurements (tools/ab_eval.py, bench.py) can reach every
+ * form on any input; a host integrating the library never sets them, and they may change or disappear between
+ * releases without an ABI revision.  Results never depend on them beyond floating-point summation order. */
+#ifndef CMAX_HIP_DIAG_H
+#define CMAX_HIP_DIAG_H
+#include "cmax_hip.h"
+
+enum {
+  CMX_OPT_REUSE_IMAGE = 3, /* 1 (default): with CMX_GRAD_ADJOINT, a gradient evaluation at exactly the parameters of
+                             the previous evaluation reuses the resident image (GSL's conjugate_fr calls f and then
+                             df at every accepted point; the reference recomputes everything, :58-70).  A cost-only
+                             evaluation then also runs the adjoint image pass (Jt) instead of the moments-only pass, so the
+                             df that follows launches its gather at once: +3..4 us per f, -12 us per df */
+  CMX_OPT_TAIL_FINALIZE = 6, /* 1 (default): the last kernel of an evaluation (cost-only: the blur + moments pass; adjoint gradient:
+                             the gather pass / the back end's per-batch pass) runs the finalize step -- contrast, gradient,
+                             result hand-off -- in its last-arriving workgroup (write-through partial sums, tickets sharded
+                             by XCD, sc1 loads) instead of a separate one-workgroup launch behind a kernel boundary.  The
+                             gradient sums of the workgroups reach it through 8 rows of accumulators (device-scope fp64
+                             atomic adds; their order varies run to run, like the vote image's in this mode); with
+                             CMX_OPT_DETERMINISTIC the front end uses a [column][workgroup] table instead and back-end
+                             gradient evaluations keep the separate launch (the 42-column table made the tail slower).
+                             2: tail with the table form everywhere (back-end gradient included).
+                             0: separate finalize launch (the round-1 flow) */
+  /* 7: retired (round 2's opt-in fused gradient pass: measured slower, removed; profiles/r02_pmc_fe_fused_gather.txt) */
+  CMX_OPT_COMPOSITE_IMAGE = 8, /* 1 (default): the image pass of the adjoint gradient applies G^T G as one banded operator per
+                             axis, its 4r+1-term sums accumulated in fp64: three barrier-separated phases per tile instead
+                             of five (radius 4 = the reference's blur_sigma 1 has a register-resident form), and a gradient
+                             that stays within 1e-5 of the exact-arithmetic value of the reference's formula where long fp32
+                             sums do not.  B and the contrast are unchanged to the bit.
+                             0: the four-pass fp32 form */
+  CMX_OPT_FOLD_BATCH = 9, /* 1 (default; back end, adjoint gradient, batches of a multiple of four events, tail finalize on, not
+                             deterministic): the per-batch pass of the gradient (batch Jacobian applied to the batch's sums) runs
+                             inside the per-event gather kernel, which then also finalizes -- one launch instead of three.
+                             0: separate per-batch kernel */
+  CMX_OPT_CHAIN_SOLVE = 11, /* 1 (default; front end, production path, no communicator): cmx_frontend_solve runs the FR-CG line
+                               search AHEAD of the host -- the optimiser's state machine lives in device memory, the finalize step
+                               of every evaluation advances it and writes the next evaluation point where the next evaluation's
+                               kernels (queued one slot ahead) read it; the host replays the machine on the reported costs /
+                               gradients and takes over on any disagreement, so the result is that of the host-driven solve.
+                               0: host-driven solve (one round trip to the host per evaluation); 2 / 3: test hooks -- the host takes
+                               over after three points / between a cost and its gradient, as it would after a disagreement; 4: the first form of
+                               the slots (a finalize behind the image pass, a flag-gated gradient pass) also where the self-gating
+                               form applies (A/B) */
+  CMX_OPT_GATED_DF = 10   /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
+};
+
+#endif /* CMAX_HIP_DIAG_H */
