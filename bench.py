@@ -1606,14 +1606,14 @@ def main():
             except Exception as e:
                 if rank == 0:
                     out["config5"] = {"error": str(e)}
-        if sharded and rank == 0 and not args.no_extras:
-            n_slabs = len(group_devices) if group_devices else world
-            try:
-                out["one_gpu_same_workload"] = one_gpu_same_workload(local_rank, which, n_slabs, per_gpu, pts, args.steps, args.mode)
-            except Exception as e:
-                out["one_gpu_same_workload"] = {"error": repr(e)}
     if sharded and group_devices is None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # (every rank arrives here together; what follows is rank 0's own work)
+    if family != "frontend" and sharded and rank == 0 and not args.no_extras:
+        n_slabs = len(group_devices) if group_devices else world
+        try:
+            out["one_gpu_same_workload"] = one_gpu_same_workload(local_rank, which, n_slabs, per_gpu, pts, args.steps, args.mode)
+        except Exception as e:
+            out["one_gpu_same_workload"] = {"error": repr(e)}
     if rank == 0:
         out.pop("_last", None)
         if plan["error"]:
