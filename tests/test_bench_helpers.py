@@ -131,3 +131,22 @@ def test_bench_as_the_driver_types_it_ends_in_one_parseable_line_without_a_gpu()
             has_gpu = False
         if not has_gpu:
             assert d["n_gpus"] == 0 and "no HIP device" in d["error"]
+
+
+def test_spawned_process_per_gpu_leg_returns_the_childs_line(tmp_path):
+    """The nested leg of a plain `--gpus N`: bench.py re-launched under torch.distributed.run, its ONE stdout line parsed.  On a box
+    without a GPU the child still ends in a parseable line (n_gpus 0 + error) -- the plumbing is what is tested here."""
+    import argparse
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import pytest
+            pytest.skip("CPU-box test of the launcher plumbing (the GPU box runs the real thing in tests/test_gpu_bench_contract.py)")
+    except ImportError:
+        pass
+    a = argparse.Namespace(steps=3, warmup=1, mode="fast", comm="native", events=1000, no_config5=True, no_parity=True,
+                           detail_out=str(tmp_path / "bench_detail.json"))
+    r = bench.spawn_process_per_gpu(1, a, timeout_s=300)
+    assert "value" in r and r["n_gpus"] == 0 and "no HIP device" in r["error"], r
+    s = bench.summary_of({"process_per_gpu": r, "ms_per_step": 1.0, "value": 1.0, "n_gpus": 1})
+    assert s["process_per_gpu"]["n_gpus"] == 0
