@@ -251,8 +251,8 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     # timing events costs the step 4-8 us (hipExtLaunchKernelGGL's start / stop signals): every 4th step took 0.8-2.2 us off EVERY step
     # of the headline (tools/fixed_overhead.py: 38.4 us untimed, 39.2-41.5 us at every 4th, K = 1000 ... 20)
     if native_loop:  # (untimed) the calibration's read-back left the GPU idle for a millisecond or two: a short timed region would
-        pre = int(os.environ.get("CMX_BENCH_PREROLL", "16"))
-        ev.eval_each(np.vstack([points[i % npts] for i in range(pre)]), True)  # otherwise start on a device that has begun to clock down (K = 20: +1.5 us per step)
+        ev.eval_each(xs_timed[:16], True)  # otherwise start on a device that has begun to clock down (K = 20: +1.5 us per step; 64 ... 1024
+        # untimed evaluations here instead of 16 change nothing: what is left of the K = 20 excess is the two timed launches, below)
     # (a launch that carries timing events costs its step ~16 us at this size: K = 20 with samples on steps 0 / 8 / 16 read 41.3 us per
     #  step, on steps 0 / 10 40.4, on step 0 alone 39.6, K = 200 38.8 -- short regions take two samples, long ones ~12)
     ev.timing_enable([dom], every=int(os.environ.get("CMX_BENCH_EVERY", 0)) or (max(8, steps // 12) if steps >= 48 else max(8, (steps + 1) // 2)))
