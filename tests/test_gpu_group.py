@@ -224,6 +224,13 @@ def test_group_over_several_devices(hip, n_dev, transport):
     assert abs(rg["final_cost"] - r1["final_cost"]) < 2e-3 * abs(r1["final_cost"])
     grp.close()
     one.close()
+    # a panorama whose tile sort needs MORE than the default 64 KB of dynamic LDS (4096 x 2048: 2 x 8192 + 1 bins x 4 B) on EVERY member's
+    # device: the raised limit is a per-device function attribute (it used to be set once per process)
+    w5 = synth.config5_slab(3, 8, 600_000)
+    grp, one = _pair(hip, w5, list(range(n_dev)), transport=transport)
+    _same(grp, one, [(np.zeros(w5.P), True), (rng.normal(0, 0.004, w5.P), True)])
+    grp.close()
+    one.close()
 
 
 # ---------------------------------------------------------------- round 5: the device event store behind a group
