@@ -150,3 +150,22 @@ def test_spawned_process_per_gpu_leg_returns_the_childs_line(tmp_path):
     assert "value" in r and r["n_gpus"] == 0 and "no HIP device" in r["error"], r
     s = bench.summary_of({"process_per_gpu": r, "ms_per_step": 1.0, "value": 1.0, "n_gpus": 1})
     assert s["process_per_gpu"]["n_gpus"] == 0
+
+
+def test_stdout_line_of_the_sharded_and_group_forms():
+    """The N > 1 shapes of the detail (process-per-GPU dry run with config 5 nested; one-process group with its per-window pipeline):
+    the line stays under the budget and carries what a scaling record needs -- comm (nranks_seen), parity vs one GPU, the one-GPU
+    reference of the same workload."""
+    for name, want in (("r05h_bench_sharded_world1_detail.json", ("comm", "parity_vs_1gpu", "config5", "one_gpu_same_workload_events_per_s")),
+                       ("r05h_bench_group00_detail.json", ("comm", "parity_vs_1gpu", "group", "per_window_ratio_to_solve",
+                                                           "one_gpu_same_workload_events_per_s"))):
+        d = json.load(open(os.path.join(bench.ROOT, "profiles", name)))
+        text = bench.compact_line(d)
+        assert len(text.encode()) < 4096, name
+        line = json.loads(text)
+        for k in bench.CONTRACT_KEYS + ("roofline", "summary"):
+            assert k in line, (name, k)
+        for k in want:
+            assert k in line["summary"], (name, k)
+        assert line["summary"]["comm"]["nranks_seen"] in (1, 2) and line["summary"]["parity_vs_1gpu"]["grad_rel_inf"] < 1e-5
+        assert "config 4" in line["config"]["workload"]
