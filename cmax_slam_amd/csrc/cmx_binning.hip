@@ -17,6 +17,7 @@
 
 #include "cmx_internal.hpp"
 #include "cmx_warp.hpp"
+#include "cmx_tilepass.hpp"
 
 namespace cmx {
 
@@ -281,7 +282,7 @@ constexpr int kRankSortMax = 4096;
 constexpr int kSentinelChunk = 256;  // == cmx_internal.hpp's bound in do_binning (max_chunks)
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_start_g, int ntiles, int planes_per_tile, int tiles_x,
                                                             int margin, int M, Chunk *chunks, int *count,
-                                                            unsigned long long *count_host, unsigned binning_id) {
+                                                            unsigned long long *count_host, unsigned binning_id, FusedTables fused) {
   __shared__ int wave_tot[16];
   __shared__ int base_sh;
   __shared__ int ts_sh[kRankSortMax + 2];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
     const int tile = t / planes_per_tile, plane = t % planes_per_tile;
     const int wx0 = sentinel ? -200000000 : (tile % tiles_x) * kBinTile - margin;
     const int wy0 = sentinel ? -200000000 : (tile / tiles_x) * kBinTile - margin;
-    return Chunk{wx0, wy0, beg, end, plane, 0};
+    return Chunk{wx0, wy0, beg, end, plane, sentinel ? -1 : tile};
   };
   if (tid == 0) base_sh = 0;
   __syncthreads();
@@ -371,11 +372,45 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
       chunks[nfull_total + cbase[k] + atomicAdd(&cplace[k], 1)] = make_chunk(t, beg + (len / Mof(t)) * Mof(t), beg + len);
     }
   }
+  // tables of the fused splat + image pass (FusedArgs): how many chunk arrivals complete each tile's 5 x 5 neighbourhood; the
+  // arrival counters and the moment rows start from zero (rows of tiles nobody runs stay zero for as long as this table lives)
+  if (fused.nbr_expected) {  // (front end: one plane per tile; the launcher checks ntiles <= kRankSortMax)
+    int *nch = ts_sh;  // the offsets are not needed any more once every thread has formed its own counts
+    int mine[(kRankSortMax + 1023) / 1024];
+#pragma unroll
+    for (int q = 0; q < (kRankSortMax + 1023) / 1024; q++) {
+      const int t = tid + q * 1024;
+      int len = t < ntiles ? tile_start[t + 1] - tile_start[t] : 0;
+      if (len < 0) len = 0;
+      mine[q] = len / M + (len % M ? 1 : 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (kRankSortMax + 1023) / 1024; q++)
+      if (tid + q * 1024 < ntiles) nch[tid + q * 1024] = mine[q];
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+      const int tx = t % tiles_x, ty = t / tiles_x;
+      int sum = 0;
+      for (int dy = -kFuseNbr; dy <= kFuseNbr; dy++)
+        for (int dx = -kFuseNbr; dx <= kFuseNbr; dx++) {
+          const int ux = tx + dx, uy = ty + dy;
+          if (ux >= 0 && ux < tiles_x && uy >= 0 && uy < fused.tiles_y) sum += nch[uy * tiles_x + ux];
+        }
+      fused.nbr_expected[t] = sum;
+      fused.nbr_cnt[(size_t)t * kFuseCntStride] = 0u;
+      fused.partials[t] = 0.0;
+      fused.partials[ntiles + t] = 0.0;
+    }
+  }
 }
+bool fused_tables_ok(int ntiles, int planes_per_tile) { return planes_per_tile == 1 && ntiles + 2 <= kRankSortMax + 2; }
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s) {
+                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s, const FusedTables *fused) {
+  FusedTables ft{};
+  if (fused && fused_tables_ok(ntiles, planes_per_tile)) ft = *fused;
   hipLaunchKernelGGL(build_chunks_kernel, dim3(1), dim3(1024), 0, s, tile_start, ntiles, planes_per_tile, tiles_x, margin, M,
-                     chunks, count, count_host, binning_id);
+                     chunks, count, count_host, binning_id, ft);
 }
 
 // ---------------------------------------------------------------------------------------------- LDS splats
@@ -442,14 +477,49 @@ constexpr int kUnroll = 2;  // events in flight per thread (swept on MI355X: 2 -
 #endif
 constexpr int kFeSplatNT = CMX_FE_SPLAT_NT;
 static_assert(kBinWindow * kBinWindow % kFeSplatNT == 0, "window cells per thread");
-template <bool FIXED, bool STREAM>
-__global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b) {
-  __shared__ fix_t win[kBinWindow * kBinStride];
+static_assert(sizeof(fix_t) * kBinWindow * kBinStride >= kTpLdsBytes, "the fused tile pass reuses the vote window's LDS");
+constexpr unsigned long long kFuseTimeoutTicks = 200000ull;  // 2 ms of the 100 MHz wall clock: ~200 x the launch's own duration
+// FUSE: the adjoint image pass runs inside this launch, tile by tile, as the tiles' inputs complete (FusedArgs, cmx_tilepass.hpp)
+template <bool FIXED, bool STREAM, bool FUSE>
+__global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b, FusedArgs f) {
+  __shared__ __attribute__((aligned(16))) fix_t win[kBinWindow * kBinStride];
   if (a.skip && *a.skip) return;  // device-driven solve: finished
+  if (FUSE && (int)blockIdx.x >= b.nchunks) {
+    // TILE ROLE: the workgroups behind the chunk table's launch bound each own one 32 x 32 image tile.  They are dispatched after
+    // every chunk workgroup (lower indices), wait -- one polling lane, the other waves parked at the barrier -- until the chunks
+    // that can vote into the tile's neighbourhood have all arrived, and run the tile's image pass.  A wait only ever points at
+    // workgroups dispatched EARLIER that wait for nobody; it is bounded all the same (kFuseTimeoutTicks): a tile that gives up
+    // reports through the fallback counter and the host repeats the evaluation through the separate launches.
+    const int t = (int)blockIdx.x - b.nchunks;
+    const unsigned expected = (unsigned)f.nbr_expected[t];
+    if (f.trace && threadIdx.x == 0) { f.trace[4 * (size_t)blockIdx.x] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = expected ? 2 : 3; }
+    if (expected == 0u || (f.debug & 1)) return;  // no vote can reach this tile: B = Jt = 0 there, zero moments (rows cleared at sort time)
+    __shared__ int ok_sh;
+    auto wait_inputs = [&]() -> bool {
+      if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(f.nbr_cnt + (size_t)t * kFuseCntStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+          if (f.debug & 8) __builtin_amdgcn_s_sleep(32); else if (f.debug & 16) __builtin_amdgcn_s_sleep(127); else __builtin_amdgcn_s_sleep(2);
+          if (wall_clock64() - t0 > kFuseTimeoutTicks) { ok = 0; break; }
+        }
+        if (ok) __hip_atomic_store(f.nbr_cnt + (size_t)t * kFuseCntStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all-zero again for the next launch
+        else atomicOr(b.fallback, kFuseIncomplete);
+        if (f.trace) f.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+        ok_sh = ok;
+      }
+      __syncthreads();
+      return ok_sh != 0 && !(f.debug & 2);
+    };
+    fused_tile_pass<kFeSplatNT>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), wait_inputs);
+    if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[4 * (size_t)blockIdx.x + 2] = wall_clock64(); }
+    return;
+  }
   fe_resolve_omega(a);
   // the launch is sized by an upper bound of the table's length, and so is the table's allocation: the entry is read
   // BEFORE the length is checked, so that the two loads share one memory round trip instead of taking two (~1 us each)
   const Chunk c = b.chunks[blockIdx.x];
+  if (FUSE && f.trace && threadIdx.x == 0) { f.trace[4 * (size_t)blockIdx.x] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = 0; }
   if ((int)blockIdx.x >= *b.nchunks_dev) return;
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
@@ -500,13 +570,23 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
           if (FIXED) vote4_global_fix(b.fixed, a.W, w.xx, w.yy, w.dx, w.dy);
           else vote4_global(a.planes, a.W, w.xx, w.yy, w.dx, w.dy);
           nfall++;
+          // beyond the reach the tiles' arrival counts cover (kFuseReach px around the chunk's tile; window origin = tile - margin)
+          if (!has_win || lx < kBinMargin - kFuseReach || lx + 1 > kBinMargin + kBinTile - 1 + kFuseReach || ly < kBinMargin - kFuseReach ||
+              ly + 1 > kBinMargin + kBinTile - 1 + kFuseReach)
+            nfall |= kFuseUnsafe;
         }
       }
     }
   }
-  if (nfall) atomicAdd(&sfall, nfall);
+  if (nfall) {
+    atomicAdd(&sfall, nfall & kFuseCountMask);
+    if (nfall & kFuseUnsafe) atomicOr(&sfall, kFuseUnsafe);
+  }
   __syncthreads();
-  if (tid == 0 && sfall) atomicAdd(b.fallback, sfall);
+  if (tid == 0 && sfall) {
+    if (sfall & kFuseCountMask) atomicAdd(b.fallback, sfall & kFuseCountMask);
+    if (sfall & kFuseUnsafe) atomicOr(b.fallback, kFuseUnsafe);
+  }
   if (has_win) {
     // all of a thread's window cells are read before the first is flushed: one LDS round trip instead of sixteen
     // (the rolled loop waited for every read in turn: ~0.9 of the kernel's ~9 us, profiles/r02_splat_timeline.txt)
@@ -528,21 +608,39 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
       }
     }
   }
+  if (FUSE) {
+    // This chunk's votes are on their way to the plane as agent-scope atomics: drain them, then arrive on the (up to) 25 tiles
+    // whose image pass reads pixels this chunk can have touched -- 25 lanes, 25 fire-and-forget atomics.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's atomics have been performed
+    constexpr int kSide = 2 * kFuseNbr + 1;
+    if (c.tile >= 0 && tid < kSide * kSide && !(f.debug & 4)) {
+      const int tx = c.tile % f.tiles_x + (tid % kSide - kFuseNbr), ty = c.tile / f.tiles_x + (tid / kSide - kFuseNbr);
+      if (tx >= 0 && tx < f.tiles_x && ty >= 0 && ty < f.tiles_y)
+        __hip_atomic_fetch_add(f.nbr_cnt + (size_t)(ty * f.tiles_x + tx) * kFuseCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (f.trace && tid == 0) { f.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = 1; }
+  }
 }
-template <bool FIXED, bool STREAM>
-static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b);
-  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM>), dim3(b.nchunks), dim3(kFeSplatNT), 0, s, a, b);
+template <bool FIXED, bool STREAM, bool FUSE>
+static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+  const dim3 grid(b.nchunks + (FUSE ? f.tiles_x * f.tiles_y : 0));  // chunk workgroups, then one workgroup per image tile
+  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, f);
+  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, a, b, f);
 }
-void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1, const FusedArgs *fused) {
   if (b.nchunks <= 0) return;
   const bool stream = b.sb && b.sdt;
-  if (b.fixed) {
-    if (stream) launch_fe_splat_lds_t<true, true>(a, b, s, t0, t1);
-    else launch_fe_splat_lds_t<true, false>(a, b, s, t0, t1);
+  const FusedArgs none{};
+  if (fused && !b.fixed) {  // (never with the deterministic mode's fixed-point planes)
+    if (stream) launch_fe_splat_lds_t<false, true, true>(a, b, *fused, s, t0, t1);
+    else launch_fe_splat_lds_t<false, false, true>(a, b, *fused, s, t0, t1);
+  } else if (b.fixed) {
+    if (stream) launch_fe_splat_lds_t<true, true, false>(a, b, none, s, t0, t1);
+    else launch_fe_splat_lds_t<true, false, false>(a, b, none, s, t0, t1);
   } else {
-    if (stream) launch_fe_splat_lds_t<false, true>(a, b, s, t0, t1);
-    else launch_fe_splat_lds_t<false, false>(a, b, s, t0, t1);
+    if (stream) launch_fe_splat_lds_t<false, true, false>(a, b, none, s, t0, t1);
+    else launch_fe_splat_lds_t<false, false, false>(a, b, none, s, t0, t1);
   }
 }
 

@@ -234,7 +234,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
         c->nchunks_exact = true;
       }
     }
-    if (c->n_packed > 0) c->last_fallback_frac = ba[kFallbackSlot] / (double)c->n_packed;  // drives the re-sort of the next slot queued
+    if (c->n_packed > 0) c->last_fallback_frac = fallback_count(ba[kFallbackSlot]) / (double)c->n_packed;  // drives the re-sort of the next slot queued
     c->fallback_pending = false;
     if (t.self_gating) {  // one block: contrast, gradient (when the launch computed it), decisions, next point
       const int ext = t.nout_a - kChainExtra;

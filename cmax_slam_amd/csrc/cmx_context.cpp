@@ -323,6 +323,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_tile_start);
   hipFree(c->d_chunks);
   hipFree(c->d_fallback);
+  hipFree(c->d_fnbr_expected); hipFree(c->d_fnbr_cnt); hipFree(c->d_fpartials); hipFree(c->d_fuse_trace);
   hipFree(c->d_itilde);
   hipFree(c->d_cx);
   hipFree(c->d_cy);
@@ -396,6 +397,11 @@ static int set_option_one(cmx_ctx *c, int key, int value) {
       c->chain_solve = value != 0;
       c->chain_test = value == 2 ? 1 : (value == 3 ? 2 : 0);
       c->chain_self_gating = value != 4;
+      return CMX_OK;
+    case CMX_OPT_FUSED_IMAGE:
+      c->fused_image = value != 0;
+      c->bin_valid = false;  // the fused pass's tables are built with the chunk table
+      c->x_valid = false;
       return CMX_OK;
     case CMX_OPT_COMPOSITE_IMAGE:
       c->composite_image = value != 0;
@@ -556,6 +562,8 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[14] = (double)c->chain_slots;
   stats[15] = (double)c->chain_takeovers;
   stats[16] = (double)c->chain_warm_starts;
+  stats[CMX_STAT_FUSED_EVALS] = (double)c->fused_evals;
+  stats[CMX_STAT_FUSED_REDOS] = (double)c->fused_redos;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

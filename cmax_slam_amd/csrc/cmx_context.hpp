@@ -33,6 +33,10 @@ constexpr long long kMaxEvents = 1LL << 30;  // kernels index events with 32-bit
 // Re-sort the events by destination tile once more than this share of the votes left their LDS windows: a vote on the
 // global-atomic path costs the 1M-event splat ~3.7 us per percent (9.5 % -> 44 us instead of 9.5), a re-sort ~60 us once
 constexpr double kRebinFallbackFrac = 0.03;
+// the fallback word of a result block (kFallbackSlot): count of global-path votes in the low 30 bits, kFuseUnsafe / kFuseIncomplete above
+inline unsigned fallback_word(double slot) { return slot >= 0.0 && slot < 4294967296.0 ? (unsigned)slot : 0u; }
+inline double fallback_count(double slot) { return (double)(fallback_word(slot) & cmx::kFuseCountMask); }
+inline unsigned fallback_flags(double slot) { return fallback_word(slot) & ~cmx::kFuseCountMask; }
 
 struct TimedSpan { int cls; hipEvent_t a, b; };
 typedef struct ncclComm *ncclComm_t;  // as <rccl/rccl.h> declares it; only cmx_comm.cpp includes that header
@@ -177,6 +181,22 @@ struct cmx_ctx {
   unsigned binning_id = 0;
   bool nchunks_exact = false;  // nchunks has been replaced by the table's true length (read back after the first evaluation)
   unsigned *d_fallback = nullptr;
+  // tile-dataflow fusion of the adjoint image pass into the front-end LDS splat (FusedArgs, cmx_internal.hpp; CMX_OPT_FUSED_IMAGE)
+  bool fused_image = true;
+  int *d_fnbr_expected = nullptr;     // per sort tile: chunk arrivals that complete its 3 x 3 neighbourhood (built with the chunk table)
+  unsigned *d_fnbr_cnt = nullptr;     // arrival counters, all-zero between launches
+  double *d_fpartials = nullptr;      // [2][tiles] moment rows of the fused pass
+  size_t fnbr_cap = 0, fcnt_cap = 0, fpartials_cap = 0;
+  unsigned fused_bin_id = 0;          // binning the three tables above were built for (0: none)
+  int fused_tiles_x = 0, fused_tiles_y = 0;
+  bool fused_done = false;            // the pending evaluation's splat carried the image pass: Jt and d_fpartials are (being) written
+  bool adj_fused = false;             // the moment rows of the last adjoint image pass are d_fpartials (else d_partials)
+  unsigned votes_bin_id = 0;          // binning under which d_accum's votes were made by an LDS splat (0: some other way)
+  unsigned last_fallback_flags = 0;   // kFuseUnsafe / kFuseIncomplete of the last collected evaluation
+  bool force_rebin = false;           // a fused evaluation reported votes outside their windows: sort again before the next splat
+  int64_t fused_evals = 0, fused_redos = 0;
+  unsigned long long *d_fuse_trace = nullptr;  // diagnostics (env CMX_FUSE_TRACE = output file): see FusedArgs::trace
+  size_t fuse_trace_cap = 0, fuse_trace_n = 0;
   int64_t rebin_count = 0;
   double last_fallback_frac = 0;
   bool last_used_lds = false;
@@ -393,7 +413,7 @@ bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
 bool spin_for_ticket(const double *h_block, unsigned long long want, int nout, int budget_us = -1);
-int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes);  // cmx_frontend.cpp
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse = false);  // cmx_frontend.cpp
 // cmx_chain.cpp: run the solve on the device as far as it goes.  `hs` = the host's machine, begun (sm_begin) with x = start;
 // on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
 // host-driven from hs (configuration not eligible, or the device's next point was not bitwise the host's)

@@ -1,5 +1,8 @@
 // cmx_frontend.cpp -- cmx_frontend_*: the drop-in for local_contrast_{f,df,fdf}
 // (src/frontend/local_optim_contrast_gsl.cpp:20-70 -> local_image_warped_events.cpp:10-170 -> local_focus_funcs.cpp:82-120).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "cmx_context.hpp"
 
 int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *lut) {
@@ -96,19 +99,34 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
   return fe_set_packet_impl(c, n, x, y, t_ns, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma, contrast_measure);
 }
 
-int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
+// The adjoint image pass can ride inside the splat launch (FusedArgs, cmx_internal.hpp): gradient evaluations of the production
+// path at the reference's blur (sigma 1 -> radius 4, register-resident operator rows), context-owned ping-pong planes, nothing
+// between splat and blur (no communicator), no bitwise-reproducibility promise to keep.
+static bool fe_fuse_ok(const cmx_ctx *c, int nplanes, bool use_lds, bool allow_fuse) {
+  return allow_fuse && c->fused_image && use_lds && nplanes == 1 && c->last_adjoint && adjoint_ok(c) && c->composite_image &&
+         c->radius == 4 && c->d_Mx && c->d_My && c->Mx_radius == 4 && !c->deterministic && !c->sharded() && !c->accum_external &&
+         !c->chain_active && c->pingpong_planes > 0 && c->fused_bin_id != 0 && c->fused_bin_id == c->binning_id;
+}
+
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse) {
   yield_to_urgent(c);
   c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
   const size_t np = (size_t)c->W * c->H;
+  // what the buffer the previous evaluation voted into looks like (it becomes this evaluation's ping-pong partner)
+  const unsigned prev_votes_bin = c->votes_bin_id;
+  const bool prev_in_reach = c->last_used_lds && c->last_fallback_flags == 0u && !c->fallback_pending;  // (no vote beyond kFuseReach)
+  const float *prev_accum = c->d_accum;
   int rc = begin_accum(c, nplanes, np, nplanes == 1 && adjoint_ok(c) && c->splat_mode == 1);
   if (rc) return rc;
   FeSplatArgs a = fe_args(c, omega);
   for (int k = 0; k < 3; k++) c->last_x[k] = omega[k];
   const bool use_lds = c->splat_mode == 1 && nplanes == 1 && c->n_packed > 0;
-  if (use_lds && (!c->bin_valid || c->last_fallback_frac > kRebinFallbackFrac)) {
+  if (use_lds && (!c->bin_valid || c->force_rebin || c->last_fallback_frac > kRebinFallbackFrac)) {
     rc = do_binning(c, &a, nullptr);
     if (rc) return rc;
   }
+  c->fused_done = false;
+  c->votes_bin_id = use_lds ? c->binning_id : 0u;
   {
     Span sp(c, CMX_T_SPLAT, /*exact=*/true);
     c->last_used_lds = use_lds;
@@ -120,7 +138,44 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
         if (rc) return rc;
         b.fixed = c->d_fixed;
       }
-      launch_fe_splat_lds(a, b, c->stream, sp.t0(), sp.t1());
+      FusedArgs f{};
+      const bool fuse = fe_fuse_ok(c, nplanes, use_lds, allow_fuse);
+      if (fuse) {
+        float *jt_before = c->d_itilde;
+        rc = ensure(c, c->d_itilde, c->itilde_cap, np);
+        if (rc) return rc;
+        if (c->d_itilde != jt_before) HIP_TRY(c, hipMemsetAsync(c->d_itilde, 0, c->itilde_cap * sizeof(float), c->stream));
+        f.tiles_x = c->fused_tiles_x;
+        f.tiles_y = c->fused_tiles_y;
+        f.nbr_expected = c->d_fnbr_expected;
+        f.nbr_cnt = c->d_fnbr_cnt;
+        memcpy(f.taps, c->taps, sizeof(f.taps));
+        f.Mx = c->d_Mx;
+        f.My = c->d_My;
+        f.jt = c->d_itilde;
+        f.partials = c->d_fpartials;
+        if (c->d_accum_alt && !c->alt_clean) {
+          // ping-pong: the tiles' passes clear the partner.  They cover every pixel the partner's votes can have reached only if
+          // those votes were made under THIS chunk table and stayed within reach of their tiles; otherwise one memset clears it.
+          const bool covered = c->d_accum_alt == prev_accum && prev_votes_bin == c->binning_id && prev_in_reach;
+          if (covered) f.zero_ptr = c->d_accum_alt;
+          else HIP_TRY(c, hipMemsetAsync(c->d_accum_alt, 0, (size_t)c->pingpong_planes * np * sizeof(float), c->stream));
+          c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs
+          c->alt_flagged = false;
+        }
+        if (const char *dbg = getenv("CMX_FUSE_DEBUG")) f.debug = atoi(dbg);
+        if (getenv("CMX_FUSE_TRACE")) {  // diagnostics: per-workgroup wall-clock stamps of this launch (tools/fuse_trace.py)
+          const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y;
+          rc = ensure(c, c->d_fuse_trace, c->fuse_trace_cap, 4 * nwg);
+          if (rc) return rc;
+          HIP_TRY(c, hipMemsetAsync(c->d_fuse_trace, 0, 4 * nwg * sizeof(unsigned long long), c->stream));
+          f.trace = c->d_fuse_trace;
+          c->fuse_trace_n = nwg;
+        }
+        c->fused_done = true;
+        c->fused_evals++;
+      }
+      launch_fe_splat_lds(a, b, c->stream, sp.t0(), sp.t1(), fuse ? &f : nullptr);
     } else {
       launch_fe_splat(a, nplanes > 1, c->stream, sp.t0(), sp.t1());
     }
@@ -131,7 +186,12 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes) {
   c->last_P = nplanes - 1;
   c->accumulated = true;
   c->x_valid = true;
-  c->jt_valid = false;
+  c->jt_valid = c->fused_done;  // (the fused pass leaves Jt and its moment rows exactly as a speculative image pass would)
+  if (c->fused_done) {
+    c->adj_fused = true;
+    c->adj_direct = true;
+    c->adj_tile_count = nullptr;
+  }
   c->gated_pending = false;  // (a gated gradient pass still in flight belongs to the previous point: nobody will ask for it)
   return CMX_OK;
 }
@@ -157,15 +217,18 @@ int cmx_frontend_prepare(cmx_ctx *c, const double omega_hint[3]) {
   return CMX_OK;
 }
 
-int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) {
+// allow_fuse: the caller runs the gather of this very point next and nothing else touches the planes in between (cmx_frontend_eval);
+// the split-phase entry point never fuses -- its caller may exchange the planes with other ranks before the blur
+static int fe_accumulate_checked(cmx_ctx *c, const double omega[3], int want_grad, bool allow_fuse) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
   if (!omega) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
   int rc = bind_device(c);
   if (rc) return rc;
   c->last_adjoint = want_grad && adjoint_ok(c);
-  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1);
+  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1, allow_fuse);
 }
+int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) { return fe_accumulate_checked(c, omega, want_grad, false); }
 
 int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
@@ -180,7 +243,40 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
     c->gate_mode = 0;  // a hint not consumed by a cost-only evaluation does not outlive the next evaluation of any kind
     rc = collect_gated(c, 3, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
     if (rc || served) return rc;
+    const bool fused = c->fused_done;
     rc = run_adjoint(c, 3);
+    if (!rc && fused) {
+      // the fused image pass is exact only while every vote lands within reach of its chunk's tile (the tiles' arrival counts cover
+      // kFuseReach = 56 px around it; votes beyond that, or a tile that gave up waiting, raise a flag in the fallback word): such
+      // an evaluation is repeated after a fresh sort at these very parameters -- every vote is then inside its own tile -- and,
+      // should that not do, through the separate launches, which are exact for any parameters
+      for (int attempt = 0;; attempt++) {
+        rc = sync_and_collect(c, true);
+        if (rc) return rc;
+        if (const char *path = getenv("CMX_FUSE_TRACE")) {
+          if (c->d_fuse_trace && c->fuse_trace_n) {
+            std::vector<unsigned long long> h(4 * c->fuse_trace_n);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(h.data(), c->d_fuse_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
+          }
+        }
+        const unsigned flags = fallback_flags(c->h_result[kFallbackSlot]);
+        if (!flags || !c->fused_done) break;
+        c->fused_redos++;
+        c->force_rebin = true;
+        if (flags & kFuseIncomplete)  // a tile gave up waiting: late arrivals are still on its counter
+          HIP_TRY(c, hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream));
+        double om[3] = {c->last_x[0], c->last_x[1], c->last_x[2]};
+        rc = fe_accumulate(c, om, 1, /*allow_fuse=*/attempt == 0 && !(flags & kFuseIncomplete));
+        if (rc) return rc;
+        rc = run_adjoint(c, 3);
+        if (rc) return rc;
+      }
+      *contrast = c->h_result[0];
+      for (int k = 0; k < 3; k++) grad[k] = c->h_result[2 + k];
+      return CMX_OK;
+    }
   } else if (!grad && speculative_jt_ok(c)) {
     rc = finish_cost_only_speculative(c, 3);
     if (rc) return rc;
@@ -208,7 +304,7 @@ int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, doubl
     if (sharded) return finish_sharded(c, KIND_FE, false, contrast, grad);
     return cmx_frontend_finish(c, contrast, grad);
   }
-  int rc = cmx_frontend_accumulate(c, omega, grad != nullptr);
+  int rc = fe_accumulate_checked(c, omega, grad != nullptr, /*allow_fuse=*/!sharded);
   if (rc) return rc;
   if (sharded) return finish_sharded(c, KIND_FE, true, contrast, grad);
   return cmx_frontend_finish(c, contrast, grad);

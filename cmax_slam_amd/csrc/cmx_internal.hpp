@@ -260,8 +260,46 @@ constexpr int kBinWindow = kBinTile + 2 * kBinMargin;
 constexpr int kBinStride = 67;   // LDS row stride of a window (floats): odd, with stride+-1 poor in factors of 2, so votes along
                                  // vertical / diagonal edges spread over the 32 LDS banks instead of piling onto one
 
-struct Chunk { int wx0, wy0, beg, end, plane, pad; };  // LDS window origin (pixels), sorted-event range, target plane
-                                                        // (back end: 0 = IL_old, 1 = IL_new); wx0 < -1e8: no window
+struct Chunk { int wx0, wy0, beg, end, plane, tile; };  // LDS window origin (pixels), sorted-event range, target plane
+                                                         // (back end: 0 = IL_old, 1 = IL_new); wx0 < -1e8: no window;
+                                                         // tile: the chunk's sort tile (-1: the no-window sentinel)
+
+// Tile-dataflow fusion of the adjoint image pass into the front-end LDS splat (round 6; fe_splat_lds_kernel<.., FUSE>,
+// cmx_tilepass.hpp).  The image tiles of the fused pass ARE the 32 x 32 sort tiles.  A chunk's votes stay inside its window
+// (tile + 16 px) or, on the global path, within kFuseReach = 56 px of its tile, and the pass of tile T reads the raw image on
+// T + 2r = 8 px: everything T needs comes from the chunks of T's 5 x 5 tile neighbourhood.  Every chunk workgroup, once its
+// window has been flushed, arrives on the counters of the (up to) 25 tiles around its own.  The launch carries one more workgroup per image tile behind the chunk workgroups: it waits for
+// its tile's count and runs B = G I (moments), Jt = G^T G I for that tile -- no kernel boundary between the splat and the image
+// pass, no second launch, and the 300 tile passes of a 640 x 480 image run side by side the moment the last chunks land
+// (the first form, "the completing arrival runs the pass", put up to nine passes in a row on the late finishers: splat + image
+// 50 us instead of 16, profiles/r06_fused_ab.txt).  Votes beyond kFuseReach are not covered by the counts: an evaluation that
+// reports any (kFuseUnsafe) is repeated by the host after a fresh sort (cmx_frontend.cpp).
+constexpr int kFuseCntStride = 32;  // words between two tiles' arrival counters: one 128-byte line each -- 300 polling lanes on ten
+                                    // shared lines serialised at the memory side and held up the chunks' own atomics (chunk phase
+                                    // 7 -> 13 us, profiles/r06_fused_ab.txt)
+// Votes on the global-atomic path (outside the chunk's 64 x 64 LDS window) are still covered by the tiles' arrival counts as long
+// as they land within kFuseReach pixels of the chunk's own tile: the chunk arrives on the 5 x 5 tiles around its own, and a tile's
+// pass reads tile + 2r = 8 px -- 2 * 32 - 8 = 56 px of reach (3.8 rad/s of omega at the far end of a 50 ms packet).  A vote beyond
+// that raises kFuseUnsafe in the fallback word; a tile workgroup that gave up waiting raises kFuseIncomplete.  The low 30 bits stay
+// the count of global-path votes (the 3 % re-sort rule of the LDS splat).
+constexpr int kFuseNbr = 2;  // tiles on every side of a chunk's tile it arrives on
+constexpr int kFuseReach = kFuseNbr * 32 - 8;
+constexpr unsigned kFuseUnsafe = 0x80000000u, kFuseIncomplete = 0x40000000u, kFuseCountMask = 0x3fffffffu;
+struct FusedArgs {
+  int tiles_x, tiles_y;         // sort-tile grid (kBinTile pixels)
+  const int *nbr_expected;      // [tiles]: chunks in the tile's 5 x 5 neighbourhood (0: no vote can reach it: nobody runs it)
+  unsigned *nbr_cnt;            // [tiles * kFuseCntStride]: arrivals so far; all-zero between launches (the tile's workgroup stores 0)
+  float taps[9];                // radius 4 only
+  const float *Mx, *My;         // banded G^T G per axis (cmx_context.cpp upload_gt1)
+  float *jt;                    // out: G^T G I
+  float *zero_ptr;              // the OTHER accumulation buffer: a tile's pass clears its own tile there (ping-pong); may be null
+  double *partials;             // [2][tiles]: per-tile sum B, sum B^2 (rows of inactive tiles stay zero: written at sort time)
+  double *macc;                 // device-driven solve: moment accumulator rows (ChainDev::macc) instead of `partials`; else null
+  unsigned long long *trace;    // diagnostics (env CMX_FUSE_TRACE): [workgroup][4] wall-clock stamps -- start, inputs complete / chunk
+                                // flushed, end, role; null = off
+  int debug;                    // diagnostics (env CMX_FUSE_DEBUG, timing experiments only -- results are WRONG when set): 1 tile
+                                // workgroups leave at once, 2 they wait but skip the pass, 4 chunks do not arrive (with 1)
+};
 
 struct BinnedEvents {
   const uint32_t *sxy;     // packed events in sorted order
@@ -275,6 +313,7 @@ struct BinnedEvents {
   const double *sb;        // front end, optional: bearing (x, y) of each sorted event (16 B, z == 1) ...
   const double *sdt;       // ... and its batch's dt: coalesced streams instead of two divergent table gathers per event
   unsigned long long *fixed;  // deterministic mode: 2^-30 fixed-point planes every global vote is added to (else nullptr)
+  int sort_tiles_x, sort_tiles_y;  // front end: the sort-tile grid (global-path votes are classified by reach, see kFuseReach)
 };
 
 // binning: key = destination tile under the current parameters (ntiles = "not accepted right now")
@@ -293,7 +332,8 @@ void launch_count_sort(const FeSplatArgs *fe, const BeSplatArgs *be, int tiles_x
                        double *sb, double *sdt, hipStream_t s);
 // t0 / t1 (optional): events bracketing exactly the kernel(s) of the launch (hipExtLaunchKernelGGL start / stop events,
 // the timestamps rocprofv3 reports) for the live roofline measurement of bench.py
-void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr,
+                         const FusedArgs *fused = nullptr);  // fused: the image pass runs inside this launch (see FusedArgs)
 void launch_be_splat_lds(const BeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // deterministic mode: fixed-point planes -> fp32 planes (non-zero entries only; `planes` is all-zero before), fixed := 0
 // bearing (x, y) of every event in time order (back-end gather stream)
@@ -337,8 +377,12 @@ int sobel_blocks(int W, int H);
 
 // back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
 // chunk table built on the device from the tile offsets (no host round trip): tile_start[ntiles+2] -> chunks, *count
+// fused (front end, optional): nbr_expected / nbr_cnt / partials of FusedArgs are (re)initialised for this table
+struct FusedTables { int tiles_y; int *nbr_expected; unsigned *nbr_cnt; double *partials; };
+bool fused_tables_ok(int ntiles, int planes_per_tile);  // the chunk-table kernel can build them for this tile grid
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
-                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s);
+                         int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s,
+                         const FusedTables *fused = nullptr);
 void launch_be_batch_times(const long long *t, long long n, int B, int nb, long long start_ns, long long dt_ns, int order, int K,
                            long long *bt, long long *err, hipStream_t s);
 void launch_be_pack_from_store(const uint32_t *raw, const long long *t, long long n, int B, int rate, int per_batch,

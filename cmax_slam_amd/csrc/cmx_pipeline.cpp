@@ -157,8 +157,25 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       launch_tile_lower_bound(c->d_keys_s, n, ntiles + 2, c->d_tile_start, c->stream);
     }
     // the chunk table is built where the offsets are: no read-back, no host loop, no synchronisation
+    FusedTables ft{};
+    c->fused_bin_id = 0;
+    if (fe && c->fused_image && fused_tables_ok(ntiles, planes_per_tile)) {  // tables of the fused splat + image pass (FusedArgs)
+      rc = ensure(c, c->d_fnbr_expected, c->fnbr_cap, (size_t)ntiles);
+      if (rc) return rc;
+      rc = ensure(c, c->d_fnbr_cnt, c->fcnt_cap, (size_t)ntiles * kFuseCntStride);
+      if (rc) return rc;
+      rc = ensure(c, c->d_fpartials, c->fpartials_cap, (size_t)2 * ntiles);
+      if (rc) return rc;
+      ft.tiles_y = tiles_y;
+      ft.nbr_expected = c->d_fnbr_expected;
+      ft.nbr_cnt = c->d_fnbr_cnt;
+      ft.partials = c->d_fpartials;
+      c->fused_bin_id = c->binning_id;
+      c->fused_tiles_x = tiles_x;
+      c->fused_tiles_y = tiles_y;
+    }
     launch_build_chunks(c->d_tile_start, ntiles, planes_per_tile, tiles_x, kBinMargin, M, c->d_chunks, c->d_nchunks, c->d_nchunks_host,
-                        c->binning_id, c->stream);
+                        c->binning_id, c->stream, ft.nbr_expected ? &ft : nullptr);
     HIP_TRY(c, hipGetLastError());
     c->nchunks = max_chunks;
     c->nchunks_exact = false;
@@ -168,6 +185,7 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
     c->nchunks_exact = true;
   }
   c->bin_valid = true;
+  c->force_rebin = false;
   c->rebin_count++;
   c->last_fallback_frac = 0;
   return CMX_OK;
@@ -189,6 +207,8 @@ BinnedEvents binned(const cmx_ctx *c) {
   b.nchunks = c->nchunks;
   b.nchunks_dev = c->d_nchunks;
   b.fallback = c->d_fallback;
+  b.sort_tiles_x = (c->imgW + kBinTile - 1) / kBinTile;
+  b.sort_tiles_y = (c->imgH + kBinTile - 1) / kBinTile;
   if (c->streams_valid) { b.sb = c->d_sb; b.sdt = c->kind == KIND_FE ? c->d_sdt : nullptr; }
   return b;
 }
@@ -496,12 +516,14 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     return fail(c, CMX_ERR_INVALID_ARG, "external gradient buffer too small: %zu < %d doubles", c->gsum_cap, P2);
   }
   a.partials = c->d_partials;
+  if (!have_image) c->adj_fused = false;  // the separate image pass below writes d_partials
+  const bool fused_rows = have_image && c->adj_fused && phase != 2;  // moment rows of a pass that ran inside the splat launch
   FinalizeArgs f{};
   f.P = 0;
-  f.nblk = a.nblk;
+  f.nblk = fused_rows ? c->fused_tiles_x * c->fused_tiles_y : a.nblk;
   f.measure = c->measure;
   f.npix = (double)np;
-  f.partials = c->d_partials;
+  f.partials = fused_rows ? c->d_fpartials : c->d_partials;
   f.sums = c->d_sums;
   f.result = phase == 4 ? c->d_result2 : result_ptr(c);
   if (c->chain_active) {  // device-driven solve: this finalize advances the machine; results go to the slot's blocks of the ring
@@ -577,7 +599,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
     c->spec_images++;
     return CMX_OK;
   }
-  if (have_image && phase == 0) c->spec_hits++;
+  if (have_image && phase == 0 && !c->fused_done) c->spec_hits++;
   const bool gated = phase == 4;
   bool tailed = false;  // the gather launch carries the finalize
   {
@@ -720,7 +742,10 @@ int sync_and_collect(cmx_ctx *c, bool ends_in_finalize) {
     if (nch >= 0 && nch <= c->nchunks) c->nchunks = nch;
     c->nchunks_exact = true;
   }
-  if (c->fallback_pending && c->n_packed > 0) c->last_fallback_frac = c->h_result[kFallbackSlot] / (double)c->n_packed;
+  if (c->fallback_pending && c->n_packed > 0) {
+    c->last_fallback_frac = fallback_count(c->h_result[kFallbackSlot]) / (double)c->n_packed;
+    c->last_fallback_flags = fallback_flags(c->h_result[kFallbackSlot]);
+  }
   c->fallback_pending = false;
   // timing spans are resolved lazily (cmx_timing_get) so that timed evaluations wait exactly like untimed ones
   if (c->spans.size() > 4096) {
@@ -894,7 +919,7 @@ static int eval_many(cmx_ctx *c, int kind, int m, const double *xs, double *cont
     if (grads) for (int k = 0; k < n; k++) grads[(size_t)i * n + k] = r[2 + k];
   }
   if (m > 0 && c->n_packed > 0 && c->last_used_lds)
-    c->last_fallback_frac = c->h_many[(size_t)(m - 1) * kBlock + kFallbackSlot] / (double)c->n_packed;
+    c->last_fallback_frac = fallback_count(c->h_many[(size_t)(m - 1) * kBlock + kFallbackSlot]) / (double)c->n_packed;
   c->fallback_pending = false;
   return CMX_OK;
 }

@@ -443,21 +443,39 @@ enum { CMX_T_SPLAT = 0, CMX_T_IMAGE = 1, CMX_T_POSE = 2, CMX_T_GATHER = 3, CMX_T
 /* CMX_T_FINAL: the separate finalize launch (absent when CMX_OPT_TAIL_FINALIZE folds it into the last kernel);
  * CMX_T_BATCH: the back end's per-batch pass of the gradient gather.  Every class except CMX_T_ZERO / CMX_T_COMM is timed
  * through events carried by its (main) kernel: the dispatch's own begin / end timestamps, what rocprofv3 reports. */
-/* stats (CMX_N_STATS doubles): [0] = number of (re)binnings so far, [1] = fraction of votes that left their LDS window in the last
- * evaluation, [2] = workgroup chunks, [3] = packed (sub-sampled) events, [4] = image-reuse hits, [5] = host synchronisations
- * issued between the splat and the last kernel of sharded evaluations so far (stays 0), [6] = sharded evaluations whose
- * exchange set missed flagged tiles and were completed by a second exchange, [7] = tiles in the current exchange set
- * (-1: none known, whole planes), [8] = bytes the last sharded evaluation exchanged (all collectives, this rank's buffers), [11] = gated gradient passes queued (cmx_hint_next_df), [12] = gradient evaluations served by one, [9] = cost-only evaluations that ran
- * the adjoint image pass speculatively, [10] = gradient evaluations that found it ready, [13] = device-driven solves started
- * (CMX_OPT_CHAIN_SOLVE), [14] = evaluation slots they queued, [15] = solves the host took over after a disagreement, [16] = device-driven
- * solves that started warm (no initial copy, nothing cleared: the solve before them on this context ended normally) */
-#define CMX_N_STATS 17
+/* cmx_get_stats: counters of a context, one double each, indexed by this enum (ABI 6: the indices have names; 0..16 keep the
+ * values they had as bare numbers). */
+enum {
+  CMX_STAT_REBINS = 0,              /* destination-tile sorts so far */
+  CMX_STAT_FALLBACK_FRAC = 1,       /* fraction of votes that left their LDS window in the last evaluation */
+  CMX_STAT_CHUNKS = 2,              /* workgroup chunks of the current sort */
+  CMX_STAT_EVENTS = 3,              /* packed (sub-sampled) events */
+  CMX_STAT_REUSE_HITS = 4,          /* gradient evaluations that reused the resident image of the previous cost evaluation */
+  CMX_STAT_SHARDED_HOST_SYNCS = 5,  /* host synchronisations between the splat and the last kernel of sharded evaluations (stays 0) */
+  CMX_STAT_EXCHANGE_MISSES = 6,     /* sharded evaluations whose exchange set missed flagged tiles (completed by a second exchange) */
+  CMX_STAT_EXCHANGE_TILES = 7,      /* tiles in the current exchange set (-1: none known, whole planes) */
+  CMX_STAT_COMM_BYTES = 8,          /* bytes the last sharded evaluation exchanged (all collectives, this rank's buffers) */
+  CMX_STAT_SPEC_IMAGES = 9,         /* cost-only evaluations that ran the adjoint image pass speculatively */
+  CMX_STAT_SPEC_HITS = 10,          /* gradient evaluations that found it ready */
+  CMX_STAT_GATED_LAUNCHES = 11,     /* gated gradient passes queued (cmx_hint_next_df) */
+  CMX_STAT_GATED_HITS = 12,         /* gradient evaluations served by one */
+  CMX_STAT_CHAIN_SOLVES = 13,       /* device-driven solves started */
+  CMX_STAT_CHAIN_SLOTS = 14,        /* evaluation slots they queued */
+  CMX_STAT_CHAIN_TAKEOVERS = 15,    /* solves the host took over (disagreement, or votes outside their windows in a fused slot) */
+  CMX_STAT_CHAIN_WARM_STARTS = 16,  /* device-driven solves that started warm (nothing copied or cleared in front of them) */
+  CMX_STAT_FUSED_EVALS = 17,        /* evaluations whose image pass ran inside the splat launch (two launches instead of three) */
+  CMX_STAT_FUSED_REDOS = 18,        /* ... of which were repeated through the separate launches (votes outside their windows) */
+  CMX_N_STATS = 19
+};
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes
  * (3: cmx_get_stats takes the buffer length; cmx_frontend_prepare / cmx_backend_prepare added;
  *  4: groups, cmx_backend_get_pose_table, stream priority / CU mask;
- *  5: cmx_comm_info; the event store behind a group (cmx_events_create_group, cmx_backend_set_window_from on a group)) */
-#define CMX_ABI_VERSION 5
+ *  5: cmx_comm_info; the event store behind a group (cmx_events_create_group, cmx_backend_set_window_from on a group);
+ *     CMX_OPT_SPIN_WAIT values >= 2 are a spin budget in microseconds for all three waiters (before: "spin"), negative values are
+ *     rejected (before: accepted as non-zero);
+ *  6: named cmx_get_stats indices, two more of them) */
+#define CMX_ABI_VERSION 6
 int cmx_abi_version(void);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
 int cmx_timing_get(cmx_ctx *ctx, double ms[CMX_T_COUNT], int64_t launches[CMX_T_COUNT]);

@@ -45,7 +45,12 @@ enum {
                                over after three points / between a cost and its gradient, as it would after a disagreement; 4: the first form of
                                the slots (a finalize behind the image pass, a flag-gated gradient pass) also where the self-gating
                                form applies (A/B) */
-  CMX_OPT_GATED_DF = 10   /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
+  CMX_OPT_GATED_DF = 10,  /* 1 (default): act on cmx_hint_next_df (below).  0: ignore the hints */
+  CMX_OPT_FUSED_IMAGE = 12 /* 1 (default; front end, production path, blur_sigma 1, no communicator, not deterministic): the adjoint
+                               image pass runs INSIDE the splat launch, tile by tile, as the chunk workgroups that can vote into a
+                               tile's neighbourhood complete (tile-dataflow fusion): a gradient evaluation
+                               is two launches instead of three.  An evaluation whose votes left their LDS windows is repeated
+                               through the separate launches.  0: splat, image pass and gather as three launches */
 };
 
 #endif /* CMAX_HIP_DIAG_H */

@@ -1,0 +1,160 @@
+"""-m gpu: tile-dataflow fusion of the adjoint image pass into the front-end splat (CMX_OPT_FUSED_IMAGE, round 6).
+
+A gradient evaluation of the production path is two launches (splat + image pass, gather) instead of three.  The fused form
+must give the separate launches' numbers (same per-pixel arithmetic; only the grouping of the fp64 moment sums differs) and the
+oracle's (local_image_warped_events.cpp:10-170, local_focus_funcs.cpp:26-44) within north_star's 1e-5, for any parameters --
+including jumps that throw votes out of their LDS windows (the evaluation is then repeated through the separate launches)."""
+import numpy as np
+import pytest
+
+from cmax_slam_amd import _lib, synth
+from util import RTOL, rel_scalar, rel_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _fe(hip, p, fused, measure=0, sigma=None):
+    fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
+    fe.set_option(_lib.OPT_FUSED_IMAGE, 1 if fused else 0)
+    fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma if sigma is None else sigma, measure)
+    return fe
+
+
+@pytest.fixture(scope="module")
+def small():
+    return synth.frontend_packet(60_013, 240, 180, 200.0, 200.0, 119.5, 89.5, seed=21)
+
+
+@pytest.mark.parametrize("measure", [0, 1])
+def test_fused_equals_separate_launches_and_oracle(hip, oracle, small, measure):
+    p = small
+    a, b = _fe(hip, p, True, measure), _fe(hip, p, False, measure)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, measure)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    rng = np.random.default_rng(5)
+    om = np.array([0.55, -0.85, 0.35])
+    for it in range(12):
+        ca, ga = a.eval(om)
+        cb, gb = b.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(ca, cb) < 1e-7 and rel_vec(ga, gb) < 1e-6, (it, ca, cb, ga, gb)
+        assert rel_scalar(ca, cr) < RTOL and rel_vec(ga, gr) < RTOL, (it, ca, cr, ga, gr)
+        om = om + rng.normal(0, 0.03, 3)  # a line search's steps: a pixel or two
+    sa, sb = a.stats(), b.stats()
+    assert sa["fused_evals"] == 12 and sa["fused_redos"] == 0, sa
+    assert sb["fused_evals"] == 0, sb
+
+
+def test_cost_only_and_reuse_around_fused_evaluations(hip, oracle, small):
+    """f, then df at the same point (conjugate_fr's pattern), then fdf elsewhere: every mix of the fused gradient
+    evaluation with the cost-only path and the image reuse gives the oracle's numbers."""
+    p = small
+    fe = _fe(hip, p, True)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    pts = [(0.5, -0.8, 0.3), (0.52, -0.83, 0.31), (0.6, -0.9, 0.4)]
+    for om in pts:
+        cr, gr = ref.eval(om)
+        f, df = fe.contrast_fdf(om)                               # a new point: fused
+        assert rel_scalar(-f, cr) < RTOL and rel_vec(-df, gr) < RTOL
+        f2, df2 = fe.contrast_fdf(om)                             # the same point again: the resident image is reused
+        assert rel_scalar(-f2, cr) < RTOL and rel_vec(-df2, gr) < RTOL
+        om2 = (om[0] + 0.01, om[1], om[2] - 0.01)
+        cr2, gr2 = ref.eval(om2)
+        assert rel_scalar(-fe.contrast_f(om2), cr2) < RTOL        # cost-only (separate launches, Jt kept)
+        assert rel_vec(-fe.contrast_df(om2), gr2) < RTOL          # served from the resident image / the gated pass
+    s = fe.stats()
+    assert s["fused_evals"] == 3 and s["fused_redos"] == 0, s
+
+
+def test_jump_out_of_the_windows_is_repeated_and_resorted(hip, oracle, small):
+    """A jump of omega far beyond the 16-pixel window margin: the fused evaluation reports votes on the global path, is
+    repeated through the separate launches (exact for any parameters) and the events are sorted again."""
+    p = small
+    fe = _fe(hip, p, True)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    seq = [(0.0, 0.0, 0.0), (6.0, -5.0, 9.0), (6.0, -5.0, 9.0), (6.02, -5.0, 9.0), (-4.0, 3.0, -8.0), (0.0, 0.0, 0.0)]
+    for om in seq:
+        c, g = fe.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL, (om, c, cr, g, gr)
+    s = fe.stats()
+    assert s["fused_redos"] >= 2 and s["rebins"] >= 3, s
+
+
+def test_moves_beyond_the_window_but_within_reach_need_no_repeat(hip, oracle, small):
+    """A line search's range (omega from 0 to the packet's true rate and back: up to ~18 px of motion): votes leave their 16-px LDS
+    margin and take the global path, but stay within the 56 px the tiles' arrival counts cover -- no evaluation is repeated."""
+    p = small
+    fe = _fe(hip, p, True)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for s_ in (0.0, 1.0, 0.3, 2.5, 0.0, -1.5):
+        om = np.array([0.6, -0.9, 0.4]) * s_ * 3.0
+        c, g = fe.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL, (om, c, cr, g, gr)
+    s = fe.stats()
+    assert s["fused_evals"] == 6 and s["fused_redos"] == 0, s
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (100, 70), (346, 260), (33, 35)])
+def test_partial_tiles_and_small_images(hip, oracle, W, H):
+    """Image sides that are not multiples of the 32-pixel tile, images of a few tiles: border folding of the banded operator,
+    reflected halos and partially filled tiles."""
+    p = synth.frontend_packet(20_011, W, H, 0.9 * W, 0.9 * W, (W - 1) / 2, (H - 1) / 2, seed=W + H)
+    a, b = _fe(hip, p, True), _fe(hip, p, False)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in [(0.2, -0.4, 0.3), (0.25, -0.42, 0.28), (-0.6, 0.5, 1.0)]:
+        ca, ga = a.eval(om)
+        cb, gb = b.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(ca, cb) < 1e-7 and rel_vec(ga, gb) < 1e-6
+        assert rel_scalar(ca, cr) < RTOL and rel_vec(ga, gr) < RTOL
+
+
+def test_other_blur_radii_keep_the_separate_launches(hip, oracle, small):
+    p = small
+    for sigma in (0.0, 0.5, 2.0):
+        fe = _fe(hip, p, True, sigma=sigma)
+        ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, sigma, 0)
+        ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+        c, g = fe.eval((0.4, 0.1, -0.7))
+        cr, gr = ref.eval((0.4, 0.1, -0.7))
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL
+        assert fe.stats()["fused_evals"] == 0
+
+
+def test_config2_full_size_fused(hip, oracle):
+    """BASELINE config 2 (1M events, 640x480) through the two-launch evaluation, at a sequence of points."""
+    p = synth.frontend_packet(1_000_000, 640, 480, 588.10, 593.99, 339.83, 242.43, seed=20240316)
+    fe = _fe(hip, p, True)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in [(0.6, -0.9, 0.4), (0.55, -0.95, 0.42), (0.62, -0.88, 0.37)]:
+        c, g = fe.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL, (om, c, cr, g, gr)
+    s = fe.stats()
+    assert s["fused_evals"] == 3 and s["fused_redos"] == 0, s
+
+
+def test_many_fused_evaluations_leave_the_counters_clean(hip, small):
+    """400 evaluations back to back on one context, two more contexts interleaved: the arrival counters reset themselves, the
+    ping-pong partner is cleared by the tiles' passes, nothing drifts."""
+    p = small
+    fe, other = _fe(hip, p, True), _fe(hip, p, True)
+    plain = _fe(hip, p, False)
+    rng = np.random.default_rng(9)
+    om = np.array([0.5, -0.8, 0.3])
+    for it in range(400):
+        c, g = fe.eval(om)
+        if it % 50 == 0:
+            cb, gb = plain.eval(om)
+            assert rel_scalar(c, cb) < 1e-7 and rel_vec(g, gb) < 1e-6, it
+            other.eval(om + 0.01)
+        om = om + rng.normal(0, 0.01, 3)
+    s = fe.stats()
+    assert s["fused_evals"] == 400 and s["fused_redos"] == 0 and s["rebins"] == 1, s

@@ -34,11 +34,13 @@ def test_frontend_prepare_never_changes_results(hip, oracle, hint):
     c_ref, g_ref = ref.eval(om)
     c, g = fe.eval(om)
     assert rel_scalar(c, c_ref) < RTOL and rel_vec(g, g_ref) < RTOL
-    # a hint near the evaluation point: the first evaluation found the sort ready; a hint far away (an absurd 9 rad/s): the votes
-    # left their windows, results stay exact and the NEXT evaluation re-sorts
+    # a hint near the evaluation point: the first evaluation found the sort ready; a hint far away (an absurd 9 rad/s): votes land
+    # beyond the reach of their tiles -- the two-launch evaluation (round 6: image pass inside the splat launch) notices, sorts
+    # again at the evaluation point and repeats itself; results stay exact
     far = max(abs(h) for h in hint) > 5
-    assert fe.stats()["rebins"] == 1
-    assert (fe.stats()["fallback_frac"] > 0.03) == far
+    st = fe.stats()
+    assert st["rebins"] == (2 if far else 1) and st["fused_redos"] == (1 if far else 0), st
+    assert st["fallback_frac"] <= 0.03
     c2, g2 = fe.eval(om * 1.01)
     assert fe.stats()["rebins"] == (2 if far else 1)
     c2_ref, g2_ref = ref.eval(om * 1.01)
@@ -118,7 +120,7 @@ def test_tiny_image_sigma_change_keeps_the_operator_tables_consistent(hip, oracl
 
 def test_stats_take_their_length(hip):
     import ctypes as C
-    assert _lib.lib().cmx_abi_version() == 5
+    assert _lib.lib().cmx_abi_version() == 6
     p = synth.frontend_packet(1_000, 64, 48, 60.0, 60.0, 31.5, 23.5, seed=1)
     fe = _fe(hip, p)
     fe.eval(np.zeros(3))

@@ -1,0 +1,52 @@
+"""Timeline of ONE fused splat + image launch (CMX_OPT_FUSED_IMAGE): per-workgroup wall-clock stamps written by the kernel when the
+environment variable CMX_FUSE_TRACE names an output file.  Usage on the GPU box:  python tools/fuse_trace.py [events]
+Prints, in microseconds from the first workgroup's start: when chunk workgroups start / finish, when tile workgroups start, see
+their inputs complete and finish."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("CMAX_HIP_NO_TORCH", "1")
+path = "/tmp/fuse_trace.bin"
+from cmax_slam_amd import _lib, evaluator, synth  # noqa: E402
+
+
+def pct(v, name):
+    v = np.sort(v)
+    print("  %-34s n=%4d  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f" % (name, len(v), v[0], v[len(v) // 10], v[len(v) // 2], v[(9 * len(v)) // 10], v[-1]))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    p = synth.config2(n)
+    ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
+    ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
+    x0 = np.array([0.3, -0.5, 0.2])
+    for _ in range(30):
+        ev.eval(x0 + 1e-4 * np.random.randn(3), True)
+    os.environ["CMX_FUSE_TRACE"] = path
+    for rep in range(2):
+        ev.eval(x0 + 1e-4 * np.random.randn(3), True)
+        t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
+        role = t[:, 3]
+        live = t[:, 0] > 0
+        t0 = t[live, 0].min()
+        us = lambda col, m: (t[m, col] - t0) / 100.0  # noqa: E731  (100 MHz wall clock)
+        ch, tl, idle = live & (role == 1), live & (role == 2), live & (role == 3)
+        print("launch %d: %d chunk workgroups, %d tile workgroups (+ %d of empty tiles), %d workgroups beyond the table" % (rep, ch.sum(), tl.sum(), idle.sum(), (live & (role == 0)).sum()))
+        pct(us(0, ch), "chunk start")
+        pct(us(1, ch), "chunk flushed + arrived")
+        if tl.sum() and (t[tl, 2] > 0).all():
+            pct(us(0, tl), "tile start")
+            pct(us(1, tl), "tile inputs complete (poll ok)")
+            pct(us(2, tl), "tile end")
+            pct(us(2, tl) - us(1, tl), "tile pass duration")
+            pct(us(1, tl) - us(1, ch).max(), "poll ok - last chunk arrival")
+    ev.close()
+
+
+if __name__ == "__main__":
+    main()
