@@ -23,7 +23,7 @@ constexpr int kAhead = 2;        // slots kept queued ahead of the one whose res
 constexpr int kRingSlots = 8;    // ring of result blocks (2 per slot); > kAhead + 1
 constexpr int kBlock = 4096;     // doubles per result block (the layout of the one-evaluation result buffer)
 
-struct SlotTickets { unsigned long long a = 0, g = 0; int nout_a = 0, nout_g = 0; bool gated = false, self_gating = false; };
+struct SlotTickets { unsigned long long a = 0, g = 0; int nout_a = 0, nout_g = 0; bool gated = false, self_gating = false, fused = false; };
 
 int ensure_chain_buffers(cmx_ctx *c) {
   if (c->d_chain) return CMX_OK;
@@ -85,7 +85,11 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   const double *x = first ? c->chain_x0 : zero;
   const unsigned par = (c->chain_seq + (unsigned)slot) & 1u;  // moment rows this slot adds to (cleared by the slot before it)
   c->last_adjoint = true;
-  int rc = fe_accumulate(c, x, 1);  // splat (omega from device memory; re-sorts first when due)
+  // splat (omega from device memory; re-sorts first when due).  Round 6: the image pass rides inside this launch when the fused
+  // form applies (FusedArgs) -- its tiles' moments go to the same accumulator rows, and the slot is two launches instead of three
+  c->fuse_macc = &c->d_chain->macc[par][0][0];
+  int rc = fe_accumulate(c, x, 1, /*allow_fuse=*/true);
+  c->fuse_macc = nullptr;
   if (rc) return rc;
   if (!c->streams_valid || !c->bin_valid) return fail(c, CMX_ERR_STATE, "self-gating slot without the tile-ordered streams");
   float *jt_before = c->d_itilde;
@@ -104,14 +108,14 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   a.tiles_x = image_adjoint_tiles_x(W);
   a.nblk = image_adjoint_tiles(W, H);
   a.tiles_y = (H + kTileY - 1) / kTileY;
-  if (c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
+  if (!c->fused_done && c->pingpong_planes > 0 && c->d_accum_alt && !c->alt_clean) {
     a.zero_ptr = c->d_accum_alt;
     a.zero_planes = c->pingpong_planes;
     c->alt_clean = true;
   }
   a.skip = first ? nullptr : &c->d_chain->done;
   a.macc = &c->d_chain->macc[par][0][0];
-  launch_image_adjoint(ia, c->stream);
+  if (!c->fused_done) launch_image_adjoint(ia, c->stream);
   // ---- the self-gating launch: cost finalize + machine step, and the gradient pass when the machine's test says so
   FeGatherArgs g{};
   g.ev = fe_args(c, x);
@@ -149,6 +153,7 @@ int queue_slot_self_gating(cmx_ctx *c, int slot, SlotTickets *t) {
   t->a = f.ticket;
   t->nout_a = f.nout_pad + kChainExtra;
   t->self_gating = true;
+  t->fused = c->fused_done;
   t->gated = true;
   c->jt_valid = false;
   c->chain_slots++;
@@ -204,7 +209,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
   bool all_self_gating = true;
   SlotTickets tick[kRingSlots];
   int queued = 0, consumed = 0;
-  bool diverged = false, unsupported = false;
+  bool diverged = false, unsupported = false, fuse_incomplete = false;
   c->chain_active = true;
   c->chain_solves++;
   double g[3];
@@ -236,6 +241,18 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     }
     if (c->n_packed > 0) c->last_fallback_frac = fallback_count(ba[kFallbackSlot]) / (double)c->n_packed;  // drives the re-sort of the next slot queued
     c->fallback_pending = false;
+    if (const unsigned flags = t.fused ? fallback_flags(ba[kFallbackSlot]) : 0u) {
+      // a fused slot whose votes went beyond the reach its tiles' arrival counts cover (or a tile that gave up waiting): its numbers --
+      // and what the device's machine made of them -- are not this point's.  Nothing of the block is fed to the host's machine: it
+      // takes over from its own state, re-evaluates the point through the ordinary path (which sorts again first).
+      c->last_fallback_flags = flags;
+      c->force_rebin = true;
+      c->fused_redos++;
+      fuse_incomplete = (flags & kFuseIncomplete) != 0;
+      diverged = true;
+      break;
+    }
+    c->last_fallback_flags = 0u;
     if (t.self_gating) {  // one block: contrast, gradient (when the launch computed it), decisions, next point
       const int ext = t.nout_a - kChainExtra;
       if (((int)ba[ext + 2] & 2) != 0) { diverged = true; break; }  // the launch's workgroups and the machine disagreed: nothing fed
@@ -285,6 +302,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     (void)hipStreamSynchronize(c->stream);
     if (c->d_tail_counters) (void)hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream);
     if (c->d_gacc) (void)hipMemsetAsync(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double), c->stream);
+    if (fuse_incomplete && c->d_fnbr_cnt) (void)hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream);
     if (diverged) c->chain_takeovers++;
   }
   c->x_valid = false;

@@ -190,6 +190,8 @@ struct cmx_ctx {
   unsigned fused_bin_id = 0;          // binning the three tables above were built for (0: none)
   int fused_tiles_x = 0, fused_tiles_y = 0;
   bool fused_done = false;            // the pending evaluation's splat carried the image pass: Jt and d_fpartials are (being) written
+  double *fuse_macc = nullptr;        // set by a self-gating slot of the device-driven solve around its fe_accumulate: the fused pass adds
+                                      // the tiles' moments to these accumulator rows (ChainDev::macc) instead of writing d_fpartials
   bool adj_fused = false;             // the moment rows of the last adjoint image pass are d_fpartials (else d_partials)
   unsigned votes_bin_id = 0;          // binning under which d_accum's votes were made by an LDS splat (0: some other way)
   unsigned last_fallback_flags = 0;   // kFuseUnsafe / kFuseIncomplete of the last collected evaluation

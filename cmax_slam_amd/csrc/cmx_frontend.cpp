@@ -105,7 +105,7 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
 static bool fe_fuse_ok(const cmx_ctx *c, int nplanes, bool use_lds, bool allow_fuse) {
   return allow_fuse && c->fused_image && use_lds && nplanes == 1 && c->last_adjoint && adjoint_ok(c) && c->composite_image &&
          c->radius == 4 && c->d_Mx && c->d_My && c->Mx_radius == 4 && !c->deterministic && !c->sharded() && !c->accum_external &&
-         !c->chain_active && c->pingpong_planes > 0 && c->fused_bin_id != 0 && c->fused_bin_id == c->binning_id;
+         (!c->chain_active || c->fuse_macc) && c->pingpong_planes > 0 && c->fused_bin_id != 0 && c->fused_bin_id == c->binning_id;
 }
 
 int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse) {
@@ -154,10 +154,14 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
         f.My = c->d_My;
         f.jt = c->d_itilde;
         f.partials = c->d_fpartials;
+        f.macc = c->chain_active ? c->fuse_macc : nullptr;
         if (c->d_accum_alt && !c->alt_clean) {
           // ping-pong: the tiles' passes clear the partner.  They cover every pixel the partner's votes can have reached only if
           // those votes were made under THIS chunk table and stayed within reach of their tiles; otherwise one memset clears it.
-          const bool covered = c->d_accum_alt == prev_accum && prev_votes_bin == c->binning_id && prev_in_reach;
+          // (slots of a device-driven solve are queued AHEAD of their predecessors' results: they assume reach -- a slot that reports
+          //  otherwise ends the chain, cmx_chain.cpp, and both buffers are cleared before the next evaluation)
+          const bool covered = c->d_accum_alt == prev_accum && prev_votes_bin == c->binning_id &&
+                               (prev_in_reach || (c->chain_active && c->last_used_lds && c->last_fallback_flags == 0u));
           if (covered) f.zero_ptr = c->d_accum_alt;
           else HIP_TRY(c, hipMemsetAsync(c->d_accum_alt, 0, (size_t)c->pingpong_planes * np * sizeof(float), c->stream));
           c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs

@@ -203,7 +203,8 @@ def test_warm_started_solves_between_other_uses_of_the_context(hip, oracle):
     assert fe.stats()["chain_warm_starts"] == warm + 1 and fe.stats()["chain_takeovers"] == 1
 
 
-def test_flat_start_beside_a_busy_context_keeps_the_accumulators_clean(hip, oracle):
+@pytest.mark.parametrize("fused", [0, 1])
+def test_flat_start_beside_a_busy_context_keeps_the_accumulators_clean(hip, oracle, fused):
     """in a self-gating slot whose outcome is 'cost only', workgroup 0 runs the finalize and the machine's step
     while other workgroups of the SAME launch may not have started; they used to read the gate from the machine that step had just
     rewritten -- a late workgroup could then take the gradient path, add to the accumulator rows and bump the arrival tickets
@@ -233,6 +234,7 @@ def test_flat_start_beside_a_busy_context_keeps_the_accumulators_clean(hip, orac
     th.start()
     try:
         fe = _fe(hip, p, 1)
+        fe.set_option(_lib.OPT_FUSED_IMAGE, fused)  # round 6: slots of two launches (image pass inside the splat launch) / of three
         for k in range(6):
             flat = fe.setupProblemAndOptimize(np.zeros(3))
             assert flat[1]["n_f"] >= 10 and np.abs(flat[0]).max() < 1e-2
@@ -242,7 +244,10 @@ def test_flat_start_beside_a_busy_context_keeps_the_accumulators_clean(hip, orac
             good = fe.setupProblemAndOptimize(x_chk)
             _close(good, host_good)
         st = fe.stats()
-        assert st["chain_solves"] == 12 and st["chain_takeovers"] == 0, st
+        # no take-over by a workgroup-vs-machine disagreement.  With fused slots the solves from 0.3 omega_true (a 57-pixel journey
+        # at the ends of this 120 ms packet, beyond the 56 px the tiles' arrival counts cover) hand over to the host when a slot
+        # reports votes out of reach -- every take-over must be one of those
+        assert st["chain_solves"] == 12 and st["chain_takeovers"] <= (st["fused_redos"] if fused else 0), st
     finally:
         stop.set()
         th.join()

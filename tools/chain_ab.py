@@ -13,9 +13,16 @@ from cmax_slam_amd import _lib, evaluator, synth  # noqa: E402
 
 
 def run(p, n_solves, label):
-    for chain in (0, 4, 1, 0, 4, 1):
+    fused_env = os.environ.get("CHAIN_AB_FUSED")  # "0,1": A/B of CMX_OPT_FUSED_IMAGE inside the device-driven solve
+    variants = [(c, None) for c in (0, 4, 1, 0, 4, 1)] if not fused_env else [(1, int(f)) for f in fused_env.split(",")] * 2
+    for chain, fused in variants:
         fe = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
         fe.set_option(_lib.OPT_CHAIN_SOLVE, chain)
+        if fused is not None:
+            fe.set_option(_lib.OPT_FUSED_IMAGE, fused)
+            label_ = "%s fused=%d" % (label, fused)
+        else:
+            label_ = label
         fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
         for _ in range(5):
             fe.setupProblemAndOptimize(np.zeros(3))
@@ -24,9 +31,9 @@ def run(p, n_solves, label):
             x, rep = fe.setupProblemAndOptimize(np.zeros(3))
         el = (time.perf_counter() - t0) / n_solves
         st = fe.stats()
-        print("%s chain=%d: %.4f ms per solve, %d iterations, %d f + %d df, %.0f iters/s, final %.6f, slots/solve %.1f takeovers %d"
-              % (label, chain, el * 1e3, rep["iterations"], rep["n_f"], rep["n_df"], rep["iterations"] / el, rep["final_cost"],
-                 st["chain_slots"] / max(st["chain_solves"], 1), st["chain_takeovers"]), flush=True)
+        print("%s chain=%d: %.4f ms per solve, %d iterations, %d f + %d df, %.0f iters/s, final %.6f, slots/solve %.1f takeovers %d rebins %d fused %d redos %d"
+              % (label_, chain, el * 1e3, rep["iterations"], rep["n_f"], rep["n_df"], rep["iterations"] / el, rep["final_cost"],
+                 st["chain_slots"] / max(st["chain_solves"], 1), st["chain_takeovers"], st["rebins"], st["fused_evals"], st["fused_redos"]), flush=True)
         fe.close()
 
 
