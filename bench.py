@@ -1430,7 +1430,7 @@ def line(m, world, args, name, n_total, img, comm_used, mode_desc):
         "per_gpu_value": m["value"] / world,
     }
     for k in ("cost_only", "pipelined", "kernel_ms", "kernels", "roofline", "whole_evaluation", "comm", "rebins", "fallback_frac_last", "contrast",
-              "timed_loop"):
+              "timed_loop", "launches_per_evaluation", "fused_image_pass"):
         if k in m:
             out[k] = m[k]
     return out

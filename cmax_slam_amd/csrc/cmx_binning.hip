@@ -397,10 +397,13 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
           const int ux = tx + dx, uy = ty + dy;
           if (ux >= 0 && ux < tiles_x && uy >= 0 && uy < fused.tiles_y) sum += nch[uy * tiles_x + ux];
         }
-      fused.nbr_expected[t] = sum;
-      fused.nbr_cnt[(size_t)t * kFuseCntStride] = 0u;
-      fused.partials[t] = 0.0;
-      fused.partials[ntiles + t] = 0.0;
+      for (int h = 0; h < kFuseStrips; h++) {
+        const int u = t * kFuseStrips + h;
+        fused.nbr_expected[u] = sum;
+        fused.nbr_cnt[(size_t)u * kFuseCntStride] = 0u;
+        fused.partials[u] = 0.0;
+        fused.partials[ntiles * kFuseStrips + u] = 0.0;
+      }
     }
   }
 }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
     // reports through the fallback counter and the host repeats the evaluation through the separate launches.
     const int t = (int)blockIdx.x - b.nchunks;
     const unsigned expected = (unsigned)f.nbr_expected[t];
-    if (f.trace && threadIdx.x == 0) { f.trace[4 * (size_t)blockIdx.x] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = expected ? 2 : 3; }
+    if (f.trace && threadIdx.x == 0) { f.trace[8 * (size_t)blockIdx.x] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = expected ? 2 : 3; }
     if (expected == 0u || (f.debug & 1)) return;  // no vote can reach this tile: B = Jt = 0 there, zero moments (rows cleared at sort time)
     __shared__ int ok_sh;
     auto wait_inputs = [&]() -> bool {
@@ -505,21 +508,27 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
         }
         if (ok) __hip_atomic_store(f.nbr_cnt + (size_t)t * kFuseCntStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all-zero again for the next launch
         else atomicOr(b.fallback, kFuseIncomplete);
-        if (f.trace) f.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+        if (f.trace) f.trace[8 * (size_t)blockIdx.x + 1] = wall_clock64();
         ok_sh = ok;
       }
       __syncthreads();
       return ok_sh != 0 && !(f.debug & 2);
     };
     fused_tile_pass<kFeSplatNT>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), wait_inputs);
-    if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[4 * (size_t)blockIdx.x + 2] = wall_clock64(); }
+    if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[8 * (size_t)blockIdx.x + 2] = wall_clock64(); }
+    if (f.debug & 32) {  // diagnostics: the same pass once more, its code and operands warm (stamp [7])
+      __syncthreads();
+      auto no_wait = [&]() -> bool { __syncthreads(); return true; };
+      fused_tile_pass<kFeSplatNT>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), no_wait);
+      if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[8 * (size_t)blockIdx.x + 7] = wall_clock64(); }
+    }
     return;
   }
   fe_resolve_omega(a);
   // the launch is sized by an upper bound of the table's length, and so is the table's allocation: the entry is read
   // BEFORE the length is checked, so that the two loads share one memory round trip instead of taking two (~1 us each)
   const Chunk c = b.chunks[blockIdx.x];
-  if (FUSE && f.trace && threadIdx.x == 0) { f.trace[4 * (size_t)blockIdx.x] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = 0; }
+  if (FUSE && f.trace && threadIdx.x == 0) { f.trace[8 * (size_t)blockIdx.x] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = 0; }
   if ((int)blockIdx.x >= *b.nchunks_dev) return;
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
@@ -609,22 +618,24 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
     }
   }
   if (FUSE) {
-    // This chunk's votes are on their way to the plane as agent-scope atomics: drain them, then arrive on the (up to) 25 tiles
-    // whose image pass reads pixels this chunk can have touched -- 25 lanes, 25 fire-and-forget atomics.
+    // This chunk's votes are on their way to the plane as agent-scope atomics: drain them, then arrive on the strips of the (up to)
+    // 25 tiles whose image pass reads pixels this chunk can have touched -- one lane, one fire-and-forget atomic each.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave's atomics have been performed
     constexpr int kSide = 2 * kFuseNbr + 1;
-    if (c.tile >= 0 && tid < kSide * kSide && !(f.debug & 4)) {
-      const int tx = c.tile % f.tiles_x + (tid % kSide - kFuseNbr), ty = c.tile / f.tiles_x + (tid / kSide - kFuseNbr);
+    if (c.tile >= 0 && tid < kSide * kSide * kFuseStrips && !(f.debug & 4)) {
+      const int q = tid / kFuseStrips, h = tid % kFuseStrips;
+      const int tx = c.tile % f.tiles_x + (q % kSide - kFuseNbr), ty = c.tile / f.tiles_x + (q / kSide - kFuseNbr);
       if (tx >= 0 && tx < f.tiles_x && ty >= 0 && ty < f.tiles_y)
-        __hip_atomic_fetch_add(f.nbr_cnt + (size_t)(ty * f.tiles_x + tx) * kFuseCntStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(f.nbr_cnt + (size_t)((ty * f.tiles_x + tx) * kFuseStrips + h) * kFuseCntStride, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (f.trace && tid == 0) { f.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64(); f.trace[4 * (size_t)blockIdx.x + 3] = 1; }
+    if (f.trace && tid == 0) { f.trace[8 * (size_t)blockIdx.x + 1] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = 1; }
   }
 }
 template <bool FIXED, bool STREAM, bool FUSE>
 static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  const dim3 grid(b.nchunks + (FUSE ? f.tiles_x * f.tiles_y : 0));  // chunk workgroups, then one workgroup per image tile
+  const dim3 grid(b.nchunks + (FUSE ? f.tiles_x * f.tiles_y * kFuseStrips : 0));  // chunk workgroups, then one workgroup per image strip
   if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, f);
   else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, a, b, f);
 }

@@ -169,10 +169,10 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
         }
         if (const char *dbg = getenv("CMX_FUSE_DEBUG")) f.debug = atoi(dbg);
         if (getenv("CMX_FUSE_TRACE")) {  // diagnostics: per-workgroup wall-clock stamps of this launch (tools/fuse_trace.py)
-          const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y;
-          rc = ensure(c, c->d_fuse_trace, c->fuse_trace_cap, 4 * nwg);
+          const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y * kFuseStrips;
+          rc = ensure(c, c->d_fuse_trace, c->fuse_trace_cap, 8 * nwg);
           if (rc) return rc;
-          HIP_TRY(c, hipMemsetAsync(c->d_fuse_trace, 0, 4 * nwg * sizeof(unsigned long long), c->stream));
+          HIP_TRY(c, hipMemsetAsync(c->d_fuse_trace, 0, 8 * nwg * sizeof(unsigned long long), c->stream));
           f.trace = c->d_fuse_trace;
           c->fuse_trace_n = nwg;
         }
@@ -259,7 +259,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
         if (rc) return rc;
         if (const char *path = getenv("CMX_FUSE_TRACE")) {
           if (c->d_fuse_trace && c->fuse_trace_n) {
-            std::vector<unsigned long long> h(4 * c->fuse_trace_n);
+            std::vector<unsigned long long> h(8 * c->fuse_trace_n);
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, hipMemcpy(h.data(), c->d_fuse_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }

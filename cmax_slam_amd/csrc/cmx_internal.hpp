@@ -283,20 +283,24 @@ constexpr int kFuseCntStride = 32;  // words between two tiles' arrival counters
 // that raises kFuseUnsafe in the fallback word; a tile workgroup that gave up waiting raises kFuseIncomplete.  The low 30 bits stay
 // the count of global-path votes (the 3 % re-sort rule of the LDS splat).
 constexpr int kFuseNbr = 2;  // tiles on every side of a chunk's tile it arrives on
+constexpr int kFuseStrips = 1;  // image-pass workgroups per 32 x 32 tile (strips of 32 x 32 / kFuseStrips lines, each with its own arrival
+                                // counter and moment row).  2 measured: no gain -- the 300 passes are bound by the CUs' fp64-conversion / LDS
+                                // throughput, not by one pass's latency (profiles/r06_fused_ab.txt)
 constexpr int kFuseReach = kFuseNbr * 32 - 8;
 constexpr unsigned kFuseUnsafe = 0x80000000u, kFuseIncomplete = 0x40000000u, kFuseCountMask = 0x3fffffffu;
 struct FusedArgs {
   int tiles_x, tiles_y;         // sort-tile grid (kBinTile pixels)
-  const int *nbr_expected;      // [tiles]: chunks in the tile's 5 x 5 neighbourhood (0: no vote can reach it: nobody runs it)
-  unsigned *nbr_cnt;            // [tiles * kFuseCntStride]: arrivals so far; all-zero between launches (the tile's workgroup stores 0)
+  const int *nbr_expected;      // [tiles * kFuseStrips]: chunks in the tile's 5 x 5 neighbourhood (0: no vote can reach it: nobody runs it)
+  unsigned *nbr_cnt;            // [tiles * kFuseStrips * kFuseCntStride]: arrivals so far; all-zero between launches (the strip's
+                                // workgroup stores 0)
   float taps[9];                // radius 4 only
   const float *Mx, *My;         // banded G^T G per axis (cmx_context.cpp upload_gt1)
   float *jt;                    // out: G^T G I
   float *zero_ptr;              // the OTHER accumulation buffer: a tile's pass clears its own tile there (ping-pong); may be null
-  double *partials;             // [2][tiles]: per-tile sum B, sum B^2 (rows of inactive tiles stay zero: written at sort time)
+  double *partials;             // [2][tiles * kFuseStrips]: per-strip sum B, sum B^2 (rows of inactive tiles stay zero: written at sort time)
   double *macc;                 // device-driven solve: moment accumulator rows (ChainDev::macc) instead of `partials`; else null
-  unsigned long long *trace;    // diagnostics (env CMX_FUSE_TRACE): [workgroup][4] wall-clock stamps -- start, inputs complete / chunk
-                                // flushed, end, role; null = off
+  unsigned long long *trace;    // diagnostics (env CMX_FUSE_TRACE): [workgroup][8] wall-clock stamps -- start, inputs complete / chunk
+                                // flushed, end, role, then the tile pass's phases (raw loaded, row pass done, column pass done); null = off
   int debug;                    // diagnostics (env CMX_FUSE_DEBUG, timing experiments only -- results are WRONG when set): 1 tile
                                 // workgroups leave at once, 2 they wait but skip the pass, 4 chunks do not arrive (with 1)
 };

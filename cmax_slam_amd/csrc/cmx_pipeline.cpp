@@ -160,11 +160,11 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
     FusedTables ft{};
     c->fused_bin_id = 0;
     if (fe && c->fused_image && fused_tables_ok(ntiles, planes_per_tile)) {  // tables of the fused splat + image pass (FusedArgs)
-      rc = ensure(c, c->d_fnbr_expected, c->fnbr_cap, (size_t)ntiles);
+      rc = ensure(c, c->d_fnbr_expected, c->fnbr_cap, (size_t)ntiles * kFuseStrips);
       if (rc) return rc;
-      rc = ensure(c, c->d_fnbr_cnt, c->fcnt_cap, (size_t)ntiles * kFuseCntStride);
+      rc = ensure(c, c->d_fnbr_cnt, c->fcnt_cap, (size_t)ntiles * kFuseStrips * kFuseCntStride);
       if (rc) return rc;
-      rc = ensure(c, c->d_fpartials, c->fpartials_cap, (size_t)2 * ntiles);
+      rc = ensure(c, c->d_fpartials, c->fpartials_cap, (size_t)2 * ntiles * kFuseStrips);
       if (rc) return rc;
       ft.tiles_y = tiles_y;
       ft.nbr_expected = c->d_fnbr_expected;
@@ -520,7 +520,7 @@ int run_adjoint(cmx_ctx *c, int P, int phase) {
   const bool fused_rows = have_image && c->adj_fused && phase != 2;  // moment rows of a pass that ran inside the splat launch
   FinalizeArgs f{};
   f.P = 0;
-  f.nblk = fused_rows ? c->fused_tiles_x * c->fused_tiles_y : a.nblk;
+  f.nblk = fused_rows ? c->fused_tiles_x * c->fused_tiles_y * kFuseStrips : a.nblk;
   f.measure = c->measure;
   f.npix = (double)np;
   f.partials = fused_rows ? c->d_fpartials : c->d_partials;

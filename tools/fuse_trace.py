@@ -25,18 +25,22 @@ def main():
     ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
     ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
     x0 = np.array([0.3, -0.5, 0.2])
+    if len(sys.argv) > 2:  # sort at omega = 0, evaluate at argv[2] x the packet's true rate (a cold-start solve's range)
+        ev.eval(np.zeros(3), True)
+        x0 = float(sys.argv[2]) * np.array(p.omega_true, dtype=float)
     for _ in range(30):
         ev.eval(x0 + 1e-4 * np.random.randn(3), True)
     os.environ["CMX_FUSE_TRACE"] = path
     for rep in range(2):
         ev.eval(x0 + 1e-4 * np.random.randn(3), True)
-        t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
+        t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
         role = t[:, 3]
         live = t[:, 0] > 0
         t0 = t[live, 0].min()
         us = lambda col, m: (t[m, col] - t0) / 100.0  # noqa: E731  (100 MHz wall clock)
         ch, tl, idle = live & (role == 1), live & (role == 2), live & (role == 3)
-        print("launch %d: %d chunk workgroups, %d tile workgroups (+ %d of empty tiles), %d workgroups beyond the table" % (rep, ch.sum(), tl.sum(), idle.sum(), (live & (role == 0)).sum()))
+        print("rebins %d fallback_frac %.5f" % (ev.stats()["rebins"], ev.stats()["fallback_frac"]))
+        print("launch %d: %d chunk workgroups, %d strip workgroups (+ %d of empty tiles), %d workgroups beyond the table" % (rep, ch.sum(), tl.sum(), idle.sum(), (live & (role == 0)).sum()))
         pct(us(0, ch), "chunk start")
         pct(us(1, ch), "chunk flushed + arrived")
         if tl.sum() and (t[tl, 2] > 0).all():
@@ -44,6 +48,12 @@ def main():
             pct(us(1, tl), "tile inputs complete (poll ok)")
             pct(us(2, tl), "tile end")
             pct(us(2, tl) - us(1, tl), "tile pass duration")
+            pct(us(4, tl) - us(1, tl), "  raw pixels loaded (sc1)")
+            pct(us(5, tl) - us(4, tl), "  LDS write + row pass")
+            pct(us(6, tl) - us(5, tl), "  column pass (Jt stores issued)")
+            pct(us(2, tl) - us(6, tl), "  moments + stores drained")
+            if (t[tl, 7] > 0).all():
+                pct(us(7, tl) - us(2, tl), "  the whole pass AGAIN (warm code)")
             pct(us(1, tl) - us(1, ch).max(), "poll ok - last chunk arrival")
     ev.close()
 
