@@ -18,6 +18,7 @@
 #include "cmx_internal.hpp"
 #include "cmx_warp.hpp"
 #include "cmx_tilepass.hpp"
+#include "cmx_fusedgather.hpp"
 
 namespace cmx {
 
@@ -375,6 +376,8 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
   // tables of the fused splat + image pass (FusedArgs): how many chunk arrivals complete each tile's 5 x 5 neighbourhood; the
   // arrival counters and the moment rows start from zero (rows of tiles nobody runs stay zero for as long as this table lives)
   if (fused.nbr_expected) {  // (front end: one plane per tile; the launcher checks ntiles <= kRankSortMax)
+    __shared__ int nact_sh;
+    if (tid == 0) nact_sh = 0;
     int *nch = ts_sh;  // the offsets are not needed any more once every thread has formed its own counts
     int mine[(kRankSortMax + 1023) / 1024];
 #pragma unroll
@@ -404,6 +407,12 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const int *tile_star
         fused.partials[u] = 0.0;
         fused.partials[ntiles * kFuseStrips + u] = 0.0;
       }
+      if (sum > 0) atomicAdd(&nact_sh, kFuseStrips);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (fused.n_active) *fused.n_active = nact_sh;
+      if (fused.tiles_done) *fused.tiles_done = 0u;
     }
   }
 }
@@ -482,11 +491,17 @@ constexpr int kFeSplatNT = CMX_FE_SPLAT_NT;
 static_assert(kBinWindow * kBinWindow % kFeSplatNT == 0, "window cells per thread");
 static_assert(sizeof(fix_t) * kBinWindow * kBinStride >= kTpLdsBytes, "the fused tile pass reuses the vote window's LDS");
 constexpr unsigned long long kFuseTimeoutTicks = 200000ull;  // 2 ms of the 100 MHz wall clock: ~200 x the launch's own duration
-// FUSE: the adjoint image pass runs inside this launch, tile by tile, as the tiles' inputs complete (FusedArgs, cmx_tilepass.hpp)
-template <bool FIXED, bool STREAM, bool FUSE>
-__global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b, FusedArgs f) {
+// FUSE 1: the adjoint image pass runs inside this launch, tile by tile, as the tiles' inputs complete (FusedArgs, cmx_tilepass.hpp)
+// FUSE 2: ... and so do the gradient gather and the finalize step (cmx_fusedgather.hpp): one launch per evaluation
+template <bool FIXED, bool STREAM, int FUSE>
+__device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f) {
   __shared__ __attribute__((aligned(16))) fix_t win[kBinWindow * kBinStride];
   if (a.skip && *a.skip) return;  // device-driven solve: finished
+  if (FUSE == 2 && (int)blockIdx.x >= b.nchunks + f.tiles_x * f.tiles_y * kFuseStrips) {  // GATHER ROLE
+    __shared__ FgSmem fg_sm;
+    fused_gather_role<kFeSplatNT>(a, b, f, (int)blockIdx.x - b.nchunks - f.tiles_x * f.tiles_y * kFuseStrips, fg_sm);
+    return;
+  }
   if (FUSE && (int)blockIdx.x >= b.nchunks) {
     // TILE ROLE: the workgroups behind the chunk table's launch bound each own one 32 x 32 image tile.  They are dispatched after
     // every chunk workgroup (lower indices), wait -- one polling lane, the other waves parked at the barrier -- until the chunks
@@ -514,14 +529,16 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
       __syncthreads();
       return ok_sh != 0 && !(f.debug & 2);
     };
-    fused_tile_pass<kFeSplatNT>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), wait_inputs);
-    if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[8 * (size_t)blockIdx.x + 2] = wall_clock64(); }
-    if (f.debug & 32) {  // diagnostics: the same pass once more, its code and operands warm (stamp [7])
+    fused_tile_pass<kFeSplatNT, FUSE == 2>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), wait_inputs);
+    if (FUSE == 2) {  // publish: every wave's write-through stores have left, then the strip's stamp and the launch's strip count
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      auto no_wait = [&]() -> bool { __syncthreads(); return true; };
-      fused_tile_pass<kFeSplatNT>(f, a.planes, a.W, a.H, t, reinterpret_cast<unsigned char *>(win), no_wait);
-      if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[8 * (size_t)blockIdx.x + 7] = wall_clock64(); }
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(f.tile_done + (size_t)t * kFuseCntStride, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(f.tiles_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    if (f.trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f.trace[8 * (size_t)blockIdx.x + 2] = wall_clock64(); }
     return;
   }
   fe_resolve_omega(a);
@@ -633,25 +650,45 @@ __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a,
     if (f.trace && tid == 0) { f.trace[8 * (size_t)blockIdx.x + 1] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = 1; }
   }
 }
-template <bool FIXED, bool STREAM, bool FUSE>
+template <bool FIXED, bool STREAM, int FUSE>
+__global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b, FusedArgs f) {
+  fe_splat_lds_body<FIXED, STREAM, FUSE>(a, b, f);
+}
+// the one-launch form (FUSE = 2): at least six waves per SIMD = three 512-thread workgroups per CU -- the chunk and strip workgroups of
+// a 1M-event launch (413 + 300) must all be resident at once, and the gather role's registers would otherwise take the kernel to 93
+// VGPRs = two workgroups per CU
+template <bool STREAM>
+__global__ __launch_bounds__(kFeSplatNT) __attribute__((amdgpu_waves_per_eu(6, 8))) void fe_splat_lds_one_kernel(FeSplatArgs a, BinnedEvents b,
+                                                                                                                FusedArgs f) {
+  fe_splat_lds_body<false, STREAM, 2>(a, b, f);
+}
+template <bool FIXED, bool STREAM, int FUSE>
 static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
-  const dim3 grid(b.nchunks + (FUSE ? f.tiles_x * f.tiles_y * kFuseStrips : 0));  // chunk workgroups, then one workgroup per image strip
-  if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, f);
-  else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, a, b, f);
+  // chunk workgroups, then one workgroup per image strip, then (one-launch evaluation) the gather workgroups
+  const dim3 grid(b.nchunks + (FUSE ? f.tiles_x * f.tiles_y * kFuseStrips : 0) + (FUSE == 2 ? f.gather_blocks : 0));
+  if constexpr (FUSE == 2) {
+    if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_one_kernel<STREAM>), grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, f);
+    else hipLaunchKernelGGL((fe_splat_lds_one_kernel<STREAM>), grid, dim3(kFeSplatNT), 0, s, a, b, f);
+  } else {
+    if (t0 || t1) hipExtLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, f);
+    else hipLaunchKernelGGL((fe_splat_lds_kernel<FIXED, STREAM, FUSE>), grid, dim3(kFeSplatNT), 0, s, a, b, f);
+  }
 }
 void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_t s, hipEvent_t t0, hipEvent_t t1, const FusedArgs *fused) {
   if (b.nchunks <= 0) return;
   const bool stream = b.sb && b.sdt;
   const FusedArgs none{};
-  if (fused && !b.fixed) {  // (never with the deterministic mode's fixed-point planes)
-    if (stream) launch_fe_splat_lds_t<false, true, true>(a, b, *fused, s, t0, t1);
-    else launch_fe_splat_lds_t<false, false, true>(a, b, *fused, s, t0, t1);
+  if (fused && !b.fixed && fused->gather_blocks > 0 && stream) {  // one launch per evaluation (needs the tile-ordered streams)
+    launch_fe_splat_lds_t<false, true, 2>(a, b, *fused, s, t0, t1);
+  } else if (fused && !b.fixed) {  // (never with the deterministic mode's fixed-point planes)
+    if (stream) launch_fe_splat_lds_t<false, true, 1>(a, b, *fused, s, t0, t1);
+    else launch_fe_splat_lds_t<false, false, 1>(a, b, *fused, s, t0, t1);
   } else if (b.fixed) {
-    if (stream) launch_fe_splat_lds_t<true, true, false>(a, b, none, s, t0, t1);
-    else launch_fe_splat_lds_t<true, false, false>(a, b, none, s, t0, t1);
+    if (stream) launch_fe_splat_lds_t<true, true, 0>(a, b, none, s, t0, t1);
+    else launch_fe_splat_lds_t<true, false, 0>(a, b, none, s, t0, t1);
   } else {
-    if (stream) launch_fe_splat_lds_t<false, true, false>(a, b, none, s, t0, t1);
-    else launch_fe_splat_lds_t<false, false, false>(a, b, none, s, t0, t1);
+    if (stream) launch_fe_splat_lds_t<false, true, 0>(a, b, none, s, t0, t1);
+    else launch_fe_splat_lds_t<false, false, 0>(a, b, none, s, t0, t1);
   }
 }
 

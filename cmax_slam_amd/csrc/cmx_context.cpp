@@ -324,6 +324,7 @@ void cmx_destroy(cmx_ctx *c) {
   hipFree(c->d_chunks);
   hipFree(c->d_fallback);
   hipFree(c->d_fnbr_expected); hipFree(c->d_fnbr_cnt); hipFree(c->d_fpartials); hipFree(c->d_fuse_trace);
+  hipFree(c->d_ftile_done); hipFree(c->d_ftiles_done); hipFree(c->d_fn_active);
   hipFree(c->d_itilde);
   hipFree(c->d_cx);
   hipFree(c->d_cy);
@@ -400,6 +401,7 @@ static int set_option_one(cmx_ctx *c, int key, int value) {
       return CMX_OK;
     case CMX_OPT_FUSED_IMAGE:
       c->fused_image = value != 0;
+      c->fused_full = value == 2;  // 2: gather + finalize inside the same launch as well (A/B: measured slower, see cmax_hip_diag.h)
       c->bin_valid = false;  // the fused pass's tables are built with the chunk table
       c->x_valid = false;
       return CMX_OK;
@@ -564,6 +566,7 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[16] = (double)c->chain_warm_starts;
   stats[CMX_STAT_FUSED_EVALS] = (double)c->fused_evals;
   stats[CMX_STAT_FUSED_REDOS] = (double)c->fused_redos;
+  stats[CMX_STAT_ONE_LAUNCH_EVALS] = (double)c->fused_full_evals;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

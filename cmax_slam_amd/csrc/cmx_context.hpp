@@ -187,6 +187,15 @@ struct cmx_ctx {
   unsigned *d_fnbr_cnt = nullptr;     // arrival counters, all-zero between launches
   double *d_fpartials = nullptr;      // [2][tiles] moment rows of the fused pass
   size_t fnbr_cap = 0, fcnt_cap = 0, fpartials_cap = 0;
+  unsigned *d_ftile_done = nullptr;   // one-launch evaluation: per-strip stamps (== fuse_seq of the launch that computed the strip)
+  unsigned *d_ftiles_done = nullptr;  // ... strips finished in the running launch (reset by its finalizing workgroup)
+  int *d_fn_active = nullptr;         // ... strips that run under the current chunk table
+  size_t fdone_cap = 0;
+  unsigned fuse_seq = 0;
+  bool fused_full = false;            // CMX_OPT_FUSED_IMAGE 2 (opt-in, measured slower: profiles/r06_fused_ab.txt): gather + finalize ride
+                                      // in the splat launch as well
+  bool fused_full_done = false;       // the pending evaluation is ONE launch: its finalize carries the ticket, nothing is left to queue
+  int64_t fused_full_evals = 0;
   unsigned fused_bin_id = 0;          // binning the three tables above were built for (0: none)
   int fused_tiles_x = 0, fused_tiles_y = 0;
   bool fused_done = false;            // the pending evaluation's splat carried the image pass: Jt and d_fpartials are (being) written
@@ -415,7 +424,7 @@ bool speculative_jt_ok(const cmx_ctx *c);
 int sync_and_collect(cmx_ctx *c, bool ends_in_finalize = false);
 bool can_reuse(const cmx_ctx *c, const double *x, int n, bool want_grad);
 bool spin_for_ticket(const double *h_block, unsigned long long want, int nout, int budget_us = -1);
-int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse = false);  // cmx_frontend.cpp
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse = false, bool allow_full = false);  // cmx_frontend.cpp
 // cmx_chain.cpp: run the solve on the device as far as it goes.  `hs` = the host's machine, begun (sm_begin) with x = start;
 // on return it holds the state after every evaluation the device reported.  *completed = false: the caller continues
 // host-driven from hs (configuration not eligible, or the device's next point was not bitwise the host's)

@@ -108,7 +108,14 @@ static bool fe_fuse_ok(const cmx_ctx *c, int nplanes, bool use_lds, bool allow_f
          (!c->chain_active || c->fuse_macc) && c->pingpong_planes > 0 && c->fused_bin_id != 0 && c->fused_bin_id == c->binning_id;
 }
 
-int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse) {
+// ... and the gather + finalize as well (FUSE = 2): a plain gradient evaluation of the production path whose finalize would have been
+// the gather's tail anyway
+static bool fe_full_ok(const cmx_ctx *c) {
+  return c->fused_full && c->streams_valid && c->d_cx && c->d_cy && c->d_gacc && c->d_tail_counters && c->tail_finalize == 1 &&
+         c->ticket_wait && c->measure != CMX_GRADIENT_MAGNITUDE && !c->chain_active && c->d_ftile_done && c->n_packed > 0;
+}
+
+int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse, bool allow_full) {
   yield_to_urgent(c);
   c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
   const size_t np = (size_t)c->W * c->H;
@@ -126,6 +133,7 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
     if (rc) return rc;
   }
   c->fused_done = false;
+  c->fused_full_done = false;
   c->votes_bin_id = use_lds ? c->binning_id : 0u;
   {
     Span sp(c, CMX_T_SPLAT, /*exact=*/true);
@@ -167,9 +175,33 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
           c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs
           c->alt_flagged = false;
         }
+        if (allow_full && fe_full_ok(c)) {  // ONE launch: gather workgroups and the finalize step behind the strips
+          const int NT = 512, n = c->n_packed;
+          int per = ((n + 399) / 400 + NT - 1) / NT * NT;
+          per = per < NT ? NT : (per > 4 * NT ? 4 * NT : per);
+          f.gather_per_block = per;
+          f.gather_blocks = (n + per - 1) / per;
+          if (++c->fuse_seq == 0u) c->fuse_seq = 1u;
+          f.seq = c->fuse_seq;
+          f.tile_done = c->d_ftile_done;
+          f.tiles_done = c->d_ftiles_done;
+          f.n_active = c->d_fn_active;
+          f.cx = c->d_cx;
+          f.cy = c->d_cy;
+          f.gacc = c->d_gacc;
+          f.gacc_stride = kGaccStride;
+          f.tail_counters = c->d_tail_counters;
+          f.result = result_ptr(c);
+          f.ticket = ++c->ticket_issued;
+          c->ticket_nout = 5;
+          f.npix = (double)np;
+          f.measure = c->measure;
+          c->fused_full_done = true;
+          c->fused_full_evals++;
+        }
         if (const char *dbg = getenv("CMX_FUSE_DEBUG")) f.debug = atoi(dbg);
         if (getenv("CMX_FUSE_TRACE")) {  // diagnostics: per-workgroup wall-clock stamps of this launch (tools/fuse_trace.py)
-          const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y * kFuseStrips;
+          const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y * kFuseStrips + (size_t)f.gather_blocks;
           rc = ensure(c, c->d_fuse_trace, c->fuse_trace_cap, 8 * nwg);
           if (rc) return rc;
           HIP_TRY(c, hipMemsetAsync(c->d_fuse_trace, 0, 8 * nwg * sizeof(unsigned long long), c->stream));
@@ -223,14 +255,14 @@ int cmx_frontend_prepare(cmx_ctx *c, const double omega_hint[3]) {
 
 // allow_fuse: the caller runs the gather of this very point next and nothing else touches the planes in between (cmx_frontend_eval);
 // the split-phase entry point never fuses -- its caller may exchange the planes with other ranks before the blur
-static int fe_accumulate_checked(cmx_ctx *c, const double omega[3], int want_grad, bool allow_fuse) {
+static int fe_accumulate_checked(cmx_ctx *c, const double omega[3], int want_grad, bool allow_fuse, bool allow_full = false) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   if (!c->have_data) return fail(c, CMX_ERR_STATE, "cmx_frontend_set_packet has not succeeded");
   if (!omega) return fail(c, CMX_ERR_INVALID_ARG, "null omega");
   int rc = bind_device(c);
   if (rc) return rc;
   c->last_adjoint = want_grad && adjoint_ok(c);
-  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1, allow_fuse);
+  return fe_accumulate(c, omega, (want_grad && !c->last_adjoint) ? 4 : 1, allow_fuse, allow_full);
 }
 int cmx_frontend_accumulate(cmx_ctx *c, const double omega[3], int want_grad) { return fe_accumulate_checked(c, omega, want_grad, false); }
 
@@ -248,7 +280,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
     rc = collect_gated(c, 3, contrast, grad, &served);  // the gradient pass may already be in flight (cmx_hint_next_df)
     if (rc || served) return rc;
     const bool fused = c->fused_done;
-    rc = run_adjoint(c, 3);
+    if (!c->fused_full_done) rc = run_adjoint(c, 3);  // (one-launch evaluation: gather and finalize are already in flight)
     if (!rc && fused) {
       // the fused image pass is exact only while every vote lands within reach of its chunk's tile (the tiles' arrival counts cover
       // kFuseReach = 56 px around it; votes beyond that, or a tile that gave up waiting, raise a flag in the fallback word): such
@@ -272,10 +304,13 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
         if (flags & kFuseIncomplete)  // a tile gave up waiting: late arrivals are still on its counter
           HIP_TRY(c, hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream));
         double om[3] = {c->last_x[0], c->last_x[1], c->last_x[2]};
-        rc = fe_accumulate(c, om, 1, /*allow_fuse=*/attempt == 0 && !(flags & kFuseIncomplete));
+        const bool again_fused = attempt == 0 && !(flags & kFuseIncomplete);
+        rc = fe_accumulate(c, om, 1, /*allow_fuse=*/again_fused, /*allow_full=*/again_fused);
         if (rc) return rc;
-        rc = run_adjoint(c, 3);
-        if (rc) return rc;
+        if (!c->fused_full_done) {
+          rc = run_adjoint(c, 3);
+          if (rc) return rc;
+        }
       }
       *contrast = c->h_result[0];
       for (int k = 0; k < 3; k++) grad[k] = c->h_result[2 + k];
@@ -308,7 +343,7 @@ int cmx_frontend_eval(cmx_ctx *c, const double omega[3], double *contrast, doubl
     if (sharded) return finish_sharded(c, KIND_FE, false, contrast, grad);
     return cmx_frontend_finish(c, contrast, grad);
   }
-  int rc = fe_accumulate_checked(c, omega, grad != nullptr, /*allow_fuse=*/!sharded);
+  int rc = fe_accumulate_checked(c, omega, grad != nullptr, /*allow_fuse=*/!sharded, /*allow_full=*/!sharded && grad != nullptr);
   if (rc) return rc;
   if (sharded) return finish_sharded(c, KIND_FE, true, contrast, grad);
   return cmx_frontend_finish(c, contrast, grad);

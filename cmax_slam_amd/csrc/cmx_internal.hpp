@@ -303,6 +303,28 @@ struct FusedArgs {
                                 // flushed, end, role, then the tile pass's phases (raw loaded, row pass done, column pass done); null = off
   int debug;                    // diagnostics (env CMX_FUSE_DEBUG, timing experiments only -- results are WRONG when set): 1 tile
                                 // workgroups leave at once, 2 they wait but skip the pass, 4 chunks do not arrive (with 1)
+  // ---- ONE-LAUNCH evaluation (fe_splat_lds_kernel<.., FUSE = 2>): the gradient gather and the finalize step ride in the same
+  // launch as well.  Behind the strip workgroups come `gather_blocks` GATHER workgroups: each loads and warps its slice of the
+  // tile-sorted events while the splat is still running (streams, fp64 warp, Jacobian rows: nothing of that depends on Jt), marks
+  // the tiles its vote cells lie in, waits for exactly those tiles' passes (tile_done[t] == seq), reads the 4 Jt cells per event
+  // (agent-scope loads: the strip workgroups store Jt write-through), adds its six sums to the accumulator rows and arrives; the
+  // last arriver waits for every strip (tiles_done == *n_active) and runs the finalize: contrast, gradient, fallback word,
+  // checksum + ticket to the mapped result block.  Every wait points at workgroups with LOWER indices that wait for nobody
+  // further up, and is bounded (kFuseIncomplete).
+  int gather_blocks;            // 0: two-launch form (FUSE = 1)
+  int gather_per_block;         // events per gather workgroup (a multiple of the workgroup size; at most 4 per thread)
+  unsigned seq;                 // this launch's stamp in tile_done[]
+  unsigned *tile_done;          // [tiles * kFuseStrips * kFuseCntStride]: == seq once the strip's Jt and moment row have been stored
+  unsigned *tiles_done;         // strips finished in this launch; reset by the finalizing workgroup
+  const int *n_active;          // strips that run (nbr_expected > 0), written with the chunk table
+  const float *cx, *cy;         // G^T 1 factors (border band of the mu term)
+  double *gacc;                 // kTailShards accumulator rows (FinalizeArgs::gacc), all-zero between launches
+  int gacc_stride;
+  unsigned *tail_counters;      // last-arriver tickets of the gather workgroups (TailArgs::counters)
+  double *result;               // mapped host result block
+  unsigned long long ticket;
+  double npix;
+  int measure;
 };
 
 struct BinnedEvents {
@@ -382,7 +404,7 @@ int sobel_blocks(int W, int H);
 // back-end window cut from the device-resident event store: sub-sampling restarts per batch, old/new flag from the timestamps
 // chunk table built on the device from the tile offsets (no host round trip): tile_start[ntiles+2] -> chunks, *count
 // fused (front end, optional): nbr_expected / nbr_cnt / partials of FusedArgs are (re)initialised for this table
-struct FusedTables { int tiles_y; int *nbr_expected; unsigned *nbr_cnt; double *partials; };
+struct FusedTables { int tiles_y; int *nbr_expected; unsigned *nbr_cnt; double *partials; int *n_active; unsigned *tiles_done; };
 bool fused_tables_ok(int ntiles, int planes_per_tile);  // the chunk-table kernel can build them for this tile grid
 void launch_build_chunks(const int *tile_start, int ntiles, int planes_per_tile, int tiles_x, int margin, int M, Chunk *chunks,
                          int *count, unsigned long long *count_host, unsigned binning_id, hipStream_t s,

@@ -166,6 +166,17 @@ int do_binning(cmx_ctx *c, const FeSplatArgs *fe, const BeSplatArgs *be) {
       if (rc) return rc;
       rc = ensure(c, c->d_fpartials, c->fpartials_cap, (size_t)2 * ntiles * kFuseStrips);
       if (rc) return rc;
+      if (!c->d_ftiles_done) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_ftiles_done, sizeof(unsigned)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_fn_active, sizeof(int)));
+      }
+      if ((size_t)ntiles * kFuseStrips * kFuseCntStride > c->fdone_cap || !c->d_ftile_done) {
+        rc = ensure(c, c->d_ftile_done, c->fdone_cap, (size_t)ntiles * kFuseStrips * kFuseCntStride);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_ftile_done, 0, c->fdone_cap * sizeof(unsigned), c->stream));  // (no launch has stamp 0)
+      }
+      ft.n_active = c->d_fn_active;
+      ft.tiles_done = c->d_ftiles_done;
       ft.tiles_y = tiles_y;
       ft.nbr_expected = c->d_fnbr_expected;
       ft.nbr_cnt = c->d_fnbr_cnt;

@@ -64,7 +64,9 @@ __device__ __forceinline__ void tp_ld_sc1_n(const float *const (&p)[5], float (&
 // wait_inputs(): called by every thread once everything that does NOT depend on the tile's votes has been requested (operator
 // rows, taps) -- it returns (in every thread, behind a workgroup barrier) whether the votes are complete; false: nothing is computed.
 // The caller issues a barrier before it reuses `lds`.
-template <int NT, typename WaitFn>
+// PUB: the pass's outputs (Jt, the moment row) are read by OTHER workgroups of the same launch (the one-launch evaluation's gather
+// role and finalize): stored write-through (agent scope), the caller publishes the strip's done flag behind them.
+template <int NT, bool PUB, typename WaitFn>
 __device__ __forceinline__ void fused_tile_pass(const FusedArgs &f, const float *plane, int W, int H, int strip, unsigned char *lds,
                                                 WaitFn wait_inputs) {
   constexpr int R = kTpR, T = kTpT, TH = kTpH, AW = kTpAW, AH = kTpAH, GH = kTpGH, NTAP = kTpTap, NRAW = kTpRawPerThread;
@@ -170,7 +172,9 @@ __device__ __forceinline__ void fused_tile_pass(const FusedArgs &f, const float 
 #pragma unroll
       for (int i = 4; i < NTAP; i++) jc[i & 3] = __builtin_fma(my[i], Q[i * T], jc[i & 3]);
       const double j = (jc[0] + jc[1]) + (jc[2] + jc[3]);
-      f.jt[(size_t)gy * W + gx] = (float)j;
+      if (PUB) __hip_atomic_store(reinterpret_cast<unsigned *>(f.jt + (size_t)gy * W + gx), __float_as_uint((float)j), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+      else f.jt[(size_t)gy * W + gx] = (float)j;
     }
   }
   if (f.trace && tid == 0) f.trace[8 * (size_t)blockIdx.x + 6] = wall_clock64();
@@ -194,8 +198,15 @@ __device__ __forceinline__ void fused_tile_pass(const FusedArgs &f, const float 
         if (t1 != 0.0) __hip_atomic_fetch_add(row + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         const int nstrips = f.tiles_x * f.tiles_y * kFuseStrips;
-        f.partials[strip] = t0;
-        f.partials[nstrips + strip] = t1;
+        if (PUB) {
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.partials + strip), (unsigned long long)__double_as_longlong(t0),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.partials + nstrips + strip), (unsigned long long)__double_as_longlong(t1),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          f.partials[strip] = t0;
+          f.partials[nstrips + strip] = t1;
+        }
       }
     }
   }

@@ -464,8 +464,9 @@ enum {
   CMX_STAT_CHAIN_TAKEOVERS = 15,    /* solves the host took over (disagreement, or votes outside their windows in a fused slot) */
   CMX_STAT_CHAIN_WARM_STARTS = 16,  /* device-driven solves that started warm (nothing copied or cleared in front of them) */
   CMX_STAT_FUSED_EVALS = 17,        /* evaluations whose image pass ran inside the splat launch (two launches instead of three) */
-  CMX_STAT_FUSED_REDOS = 18,        /* ... of which were repeated through the separate launches (votes outside their windows) */
-  CMX_N_STATS = 19
+  CMX_STAT_FUSED_REDOS = 18,        /* ... of which were repeated (votes beyond the reach of their tiles' arrival counts) */
+  CMX_STAT_ONE_LAUNCH_EVALS = 19,   /* ... of which ran splat, image pass, gather and finalize as ONE launch */
+  CMX_N_STATS = 20
 };
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes

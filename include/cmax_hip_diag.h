@@ -49,8 +49,14 @@ enum {
   CMX_OPT_FUSED_IMAGE = 12 /* 1 (default; front end, production path, blur_sigma 1, no communicator, not deterministic): the adjoint
                                image pass runs INSIDE the splat launch, tile by tile, as the chunk workgroups that can vote into a
                                tile's neighbourhood complete (tile-dataflow fusion): a gradient evaluation
-                               is two launches instead of three.  An evaluation whose votes left their LDS windows is repeated
-                               through the separate launches.  0: splat, image pass and gather as three launches */
+                               is two launches instead of three, and so is a slot of the device-driven solve.  An evaluation with
+                               votes beyond the reach the tiles' arrival counts cover is repeated after a fresh sort.
+                               2: ONE launch per gradient evaluation -- the gradient gather (its workgroups warp their events while
+                               the splat is still running and wait for the tiles their votes touch) and the finalize step ride in
+                               the same launch as well.  Built, parity-tested and measured SLOWER than 1 (0.048 vs 0.0365 ms per
+                               1M-event evaluation: the three roles compete for the same CUs and the gather's workgroups do not
+                               all fit beside the strips; profiles/r06_fused_ab.txt) -- kept as an A/B switch.
+                               0: splat, image pass and gather as three launches */
 };
 
 #endif /* CMAX_HIP_DIAG_H */

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _fe(hip, p, fused, measure=0, sigma=None):
     fe = hip.FrontendEvaluator(p.W, p.H, p.lut)
-    fe.set_option(_lib.OPT_FUSED_IMAGE, 1 if fused else 0)
+    fe.set_option(_lib.OPT_FUSED_IMAGE, int(fused))  # 0: three launches, 1 (default): two, 2: one (A/B form)
     fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma if sigma is None else sigma, measure)
     return fe
 
@@ -158,3 +158,22 @@ def test_many_fused_evaluations_leave_the_counters_clean(hip, small):
         om = om + rng.normal(0, 0.01, 3)
     s = fe.stats()
     assert s["fused_evals"] == 400 and s["fused_redos"] == 0 and s["rebins"] == 1, s
+
+
+@pytest.mark.parametrize("measure", [0, 1])
+def test_one_launch_form_matches_too(hip, oracle, small, measure):
+    """CMX_OPT_FUSED_IMAGE = 2 (kept as an A/B switch: measured slower): gather and finalize inside the splat launch as well.  Same
+    numbers as the other two forms and the oracle's, incl. after a jump beyond the tiles' reach and on a partial-tile image."""
+    for p in (small, synth.frontend_packet(20_011, 100, 70, 90.0, 90.0, 49.5, 34.5, seed=170)):
+        a, b = _fe(hip, p, 2, measure), _fe(hip, p, 0, measure)
+        ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, measure)
+        ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+        for om in [(0.5, -0.8, 0.3), (0.52, -0.83, 0.31), (6.0, -5.0, 9.0), (6.0, -5.01, 9.0), (0.0, 0.0, 0.0)]:
+            ca, ga = a.eval(om)
+            cb, gb = b.eval(om)
+            cr, gr = ref.eval(om)
+            assert rel_scalar(ca, cb) < 1e-7 and rel_vec(ga, gb) < 1e-6, (om, ca, cb, ga, gb)
+            assert rel_scalar(ca, cr) < RTOL and rel_vec(ga, gr) < RTOL, (om, ca, cr, ga, gr)
+        s = a.stats()
+        assert s["one_launch_evals"] >= 5, s
+        assert rel_scalar(-a.contrast_f((0.1, 0.2, 0.3)), ref.eval((0.1, 0.2, 0.3))[0]) < RTOL  # the other paths still work behind it

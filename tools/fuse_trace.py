@@ -39,7 +39,9 @@ def main():
         t0 = t[live, 0].min()
         us = lambda col, m: (t[m, col] - t0) / 100.0  # noqa: E731  (100 MHz wall clock)
         ch, tl, idle = live & (role == 1), live & (role == 2), live & (role == 3)
+        ga = live & (role == 4)
         print("rebins %d fallback_frac %.5f" % (ev.stats()["rebins"], ev.stats()["fallback_frac"]))
+        print("workgroups %d, by role:" % len(t), {int(r): int((role == r).sum()) for r in np.unique(role)}, "one-launch evaluations:", ev.stats()["one_launch_evals"])
         print("launch %d: %d chunk workgroups, %d strip workgroups (+ %d of empty tiles), %d workgroups beyond the table" % (rep, ch.sum(), tl.sum(), idle.sum(), (live & (role == 0)).sum()))
         pct(us(0, ch), "chunk start")
         pct(us(1, ch), "chunk flushed + arrived")
@@ -55,6 +57,15 @@ def main():
             if (t[tl, 7] > 0).all():
                 pct(us(7, tl) - us(2, tl), "  the whole pass AGAIN (warm code)")
             pct(us(1, tl) - us(1, ch).max(), "poll ok - last chunk arrival")
+        if ga.sum():
+            pct(us(0, ga), "gather start")
+            pct(us(1, ga), "gather: events warped")
+            pct(us(2, ga), "gather: its tiles are done")
+            pct(us(4, ga), "gather: Jt cells read, summed")
+            pct(us(5, ga), "gather: arrived")
+            fin = ga & (t[:, 6] > 0)
+            if fin.sum():
+                pct(us(6, fin), "finalize done (last arriver)")
     ev.close()
 
 
