@@ -20,6 +20,7 @@ SCHED_BACKGROUND, SCHED_NORMAL, SCHED_URGENT = -1, 0, 1
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 OPT_GRAD_MODE, OPT_SPLAT_MODE, OPT_REUSE_IMAGE, OPT_SPIN_WAIT, OPT_DETERMINISTIC, OPT_TAIL_FINALIZE = 1, 2, 3, 4, 5, 6
 OPT_COMPOSITE_IMAGE, OPT_FOLD_BATCH, OPT_GATED_DF, OPT_CHAIN_SOLVE, OPT_FUSED_IMAGE = 8, 9, 10, 11, 12
+DIAG_FORCE_CROSS_DEVICE = 1  # cmx_diag_set key (include/cmax_hip_diag.h)
 PLANE_IL_OLD, PLANE_IL_NEW, PLANE_IWE, PLANE_DERIV0 = 0, 1, 2, 16
 T_SPLAT, T_IMAGE, T_POSE, T_GATHER, T_ZERO, T_COMM, T_FINAL, T_BATCH, T_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 T_NAMES = ("splat", "image", "pose", "gather", "zero", "comm", "final", "batch")
@@ -41,6 +42,7 @@ SYMBOLS = {
     "cmx_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
     "cmx_set_stream_priority": (C.c_int, [ctx_p, C.c_int]),
     "cmx_set_cu_mask": (C.c_int, [ctx_p, C.POINTER(C.c_uint32), C.c_int]),
+    "cmx_diag_set": (C.c_int, [C.c_int, C.c_int]),
     "cmx_set_sched_class": (C.c_int, [ctx_p, C.c_int]),
     "cmx_backend_create_group": (C.c_int, [C.POINTER(ctx_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_int,
                                            C.c_int]),

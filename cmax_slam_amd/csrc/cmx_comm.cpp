@@ -112,8 +112,13 @@ static int exchange_tiles(cmx_ctx *c, const int *list, int n, unsigned char *fla
   const bool oop = c->comm_fn_oop || (c->comm && !c->comm_fn);
   // out-of-place transports: the buffers are sized ONCE for the largest set this panorama can produce (every tile of both planes + the
   // map) -- a peer of the one-shot transport may still be reading the previous collective's send buffer, which must never be freed under it
-  const size_t cap = oop ? 2 * np + (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY) : need;
-  int rc = ensure(c, c->d_xstage, c->xstage_cap, cap > need ? cap : need);
+  // (`need` counts whole padded 64 x 16 tiles -- with Wp % 64 or Hp % 16 != 0 a large set exceeds 2 * Wp * Hp; the true
+  //  maximum is every tile of both planes, padded, plus the map.  An out-of-place buffer is never regrown: a list that exceeds the
+  //  map's own tile count is a caller error, not a reason to free memory a peer may be reading.)
+  const size_t tiles_all = (size_t)((c->Wp + kTileX - 1) / kTileX) * ((c->Hp + kTileY - 1) / kTileY);
+  const size_t cap = oop ? 2 * tiles_all * kTileX * kTileY + tiles_all : need;
+  if (oop && need > cap) return fail(c, CMX_ERR_STATE, "exchange set of %d tiles exceeds the panorama's %zu", n, tiles_all);
+  int rc = ensure(c, c->d_xstage, c->xstage_cap, cap);
   if (!rc && oop) rc = ensure(c, c->d_xstage_b, c->xstage_b_cap, cap);
   if (!rc && oop && !c->comm_fn_peers) rc = ensure(c, c->d_xstage_out, c->xstage_out_cap, cap);
   if (rc) return rc;

@@ -123,8 +123,10 @@ int cmx_events_drop_before(cmx_events *e, int64_t global_index) {
     }
     // the contexts that cut packets / windows from the store use their own non-blocking streams: the compaction is complete
     // on every replica before the buffers are flipped
+    //  device-wide: cmx_*_set_*_from leaves an asynchronous copy OUT of the current buffer pending on the consumer's own
+    // stream -- after two drops without an evaluation in between the second compaction would write the buffer that copy still reads
     for (cmx_events::Replica &r : e->rep)
-      if (hipSetDevice(r.device) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) return efail(e, CMX_ERR_HIP, "compaction failed");
+      if (hipSetDevice(r.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return efail(e, CMX_ERR_HIP, "compaction failed");
     (void)hipSetDevice(e->device);
   }
   e->h_t.erase(e->h_t.begin(), e->h_t.begin() + (ptrdiff_t)k);

@@ -42,6 +42,7 @@ namespace {
 
 constexpr int kMaxMembers = 16;
 constexpr double kBarrierTimeoutMs = 20000.0;
+constexpr double kGroupCallTimeoutMs = 120000.0;  // the calling thread's bound on ONE fanned-out call (group_all)
 
 // ---- the direct transport's kernels.  ptrs[m] = member m's buffer (same length everywhere); member `me` owns slice `me`.
 // xdev: the members sit on more than one device -- every kernel that reads a peer's buffer then opens with a SYSTEM-scope acquire (its
@@ -362,15 +363,36 @@ int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn) {
   int rc0 = fn(g->m[0], 0);
   g->rc[0] = rc0;
   if (rc0) g->abort_flag.store(1, std::memory_order_relaxed);
-  while (g->remaining.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  // the workers' calls are bounded (a member waits at most kBarrierTimeoutMs in a barrier, a handful of barriers per call): the caller
+  // is too.  A member that has not returned by then is a hung device -- the handle refuses further calls (only cmx_destroy stays valid).
+  const double wait0 = now_us();
+  for (unsigned spins = 0; g->remaining.load(std::memory_order_acquire) > 0; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 4095u) == 4095u && now_us() - wait0 > kGroupCallTimeoutMs * 1e3) {
+      g->abort_flag.store(1, std::memory_order_relaxed);
+      g->ready = false;
+      g->setup_err = "a member did not return from a call within " + std::to_string((int)(kGroupCallTimeoutMs / 1000)) + " s";
+      return fail(leader, CMX_ERR_HIP, "group call timed out: %d member(s) still running after %.0f s; the handle is unusable",
+                  g->remaining.load(std::memory_order_acquire), kGroupCallTimeoutMs / 1000);
+    }
+  }
   g->cmd = nullptr;
   g->last_fanout_us = now_us() - t0;
-  for (int r = 0; r < g->n; r++)
-    if (g->rc[r]) {
-      if (r != 0) leader->err = "member " + std::to_string(r) + " (device " + std::to_string(g->m[r]->device) + "): " + g->m[r]->err;
-      return g->rc[r];
-    }
-  return CMX_OK;
+  int first_bad = -1;
+  for (int r = 0; r < g->n && first_bad < 0; r++)
+    if (g->rc[r]) first_bad = r;
+  if (first_bad < 0) return CMX_OK;
+  // A failed call may have left the members out of step: the one-shot exchange takes its buffer / event parity from per-member
+  // counters, and a member that failed before its exchange did not advance its own while its peers did.  Every member is
+  // back (nothing of theirs runs host-side); drain their streams and restart the parities from zero.
+  for (int r = 0; r < g->n; r++) {
+    if (hipSetDevice(g->m[r]->device) == hipSuccess && g->m[r]->stream) (void)hipStreamSynchronize(g->m[r]->stream);
+    g->os_seq[r] = 0;
+  }
+  (void)hipSetDevice(g->m[0]->device);
+  const int r = first_bad;
+  if (r != 0) leader->err = "member " + std::to_string(r) + " (device " + std::to_string(g->m[r]->device) + "): " + g->m[r]->err;
+  return g->rc[r];
 }
 
 static void group_teardown(cmx_group *g) {
@@ -447,6 +469,13 @@ static int group_connect(cmx_group *g, cmx_ctx *leader, const int *devices, int 
   return CMX_OK;
 }
 
+static std::atomic<int> g_diag_force_cross_device{0};
+int cmx_diag_set(int key, int value) {
+  if (key != CMX_DIAG_FORCE_CROSS_DEVICE) return CMX_ERR_INVALID_ARG;
+  g_diag_force_cross_device.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  return CMX_OK;
+}
+
 int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, int W, int H, const double *lut, int Wp, int Hp,
                              int transport) {
   if (!out) return CMX_ERR_INVALID_ARG;
@@ -462,6 +491,7 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
   g->n = n_devices;
   g->transport = transport;
   for (int a = 1; a < n_devices; a++) g->cross_device = g->cross_device || devices[a] != devices[0];
+  if (g_diag_force_cross_device.load(std::memory_order_relaxed)) g->cross_device = true;  // (cmax_hip_diag.h: a one-GPU box runs the xdev paths)
   int rc = CMX_OK;
   for (int r = 0; r < n_devices && !rc; r++) {
     rc = cmx_backend_create(&g->m[r], devices[r], W, H, lut, Wp, Hp);

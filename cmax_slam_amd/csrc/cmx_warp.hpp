@@ -103,15 +103,16 @@ struct BeWarp {
 // Z1: the bearing's z is the constant 1 (tile- / time-ordered bearing streams hold (x, y) only): R[2], R[5], R[8] are added, not multiplied.
 template <bool Z1>
 __device__ __forceinline__ void be_rotate(const double *R, double b0, double b1, double b2, double &x, double &y, double &z) {
-#pragma clang fp contract(fast)
+  // explicit FMAs in ONE association for both forms: with b2 == 1.0 the general form rounds R2 * b2 exactly, so
+  // fma(R1, b1, R2 * b2) is the Z1 form's fma(R1, b1, R2) bit for bit -- whatever the compiler's contraction pass would have chosen
   if (Z1) {
-    x = R[0] * b0 + (R[1] * b1 + R[2]);
-    y = R[3] * b0 + (R[4] * b1 + R[5]);
-    z = R[6] * b0 + (R[7] * b1 + R[8]);
+    x = __builtin_fma(R[0], b0, __builtin_fma(R[1], b1, R[2]));
+    y = __builtin_fma(R[3], b0, __builtin_fma(R[4], b1, R[5]));
+    z = __builtin_fma(R[6], b0, __builtin_fma(R[7], b1, R[8]));
   } else {
-    x = R[0] * b0 + (R[1] * b1 + R[2] * b2);
-    y = R[3] * b0 + (R[4] * b1 + R[5] * b2);
-    z = R[6] * b0 + (R[7] * b1 + R[8] * b2);
+    x = __builtin_fma(R[0], b0, __builtin_fma(R[1], b1, R[2] * b2));
+    y = __builtin_fma(R[3], b0, __builtin_fma(R[4], b1, R[5] * b2));
+    z = __builtin_fma(R[6], b0, __builtin_fma(R[7], b1, R[8] * b2));
   }
 }
 

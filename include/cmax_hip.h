@@ -96,22 +96,9 @@ int cmx_set_option(cmx_ctx *ctx, int key, int value);
 /* run the context's work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
 int cmx_set_stream(cmx_ctx *ctx, void *hip_stream);
 /* Two paths on one GPU.  The reference runs the front end (a packet every 10 ms, src/node.cpp:22) beside the back-end thread's
- * window solves (src/cmax_slam.cpp:92); on one GPU the two contexts' kernels share the compute units.  Both calls replace the
- * context's OWN stream (they wait for its queued work first; not with cmx_set_stream's caller-owned stream):
- *   cmx_set_stream_priority  level > 0: the device's highest stream priority, 0: normal, < 0: lowest;
- *   cmx_set_cu_mask          the stream's kernels run on the compute units whose bit is set (hipExtStreamCreateWithCUMask;
- *                            n_words x 32 bits; which physical unit a bit selects is the driver's mapping); n_words == 0: all
- *                            compute units, normal priority.
- * Measured on MI355X (profiles/r04_fe_beside_be.txt): with both contexts evaluating back to back the default -- dynamic sharing --
- * costs the front end x1.9 and the back end x1.23; priorities change nothing (the back end's launches are one resident round of
- * workgroups that fill the register files; a queue's priority does not pre-empt them); disjoint masks isolate the two (beside =
- * solo x1.04-1.09) at the price of a static split -- e.g. front end 51.8 us (x1.34) / back end x1.82 with half of every XCD each.
- * A masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags; every other stream of this library is
- * hipStreamNonBlocking): the per-packet / per-window / per-evaluation paths issue nothing on the null stream, but the rare
- * synchronous calls that do (cmx_backend_get_map / _set_map, context creation, the device-driven solve's early-stop word) are then
- * ordered against a masked context's queue like any null-stream work.  Results never depend on either call. */
-int cmx_set_stream_priority(cmx_ctx *ctx, int level);
-int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
+ * window solves (src/cmax_slam.cpp:92); on one GPU the two contexts' kernels share the compute units.  (Stream priorities and CU masks
+ * were measured not to deliver the asked-for pair of slow-downs, profiles/r04_fe_beside_be.txt: the two entry points live in
+ * cmax_hip_diag.h since ABI 6.) */
 /* What DOES give the front end its latency back without a static split: cooperative scheduling between the contexts of one
  * process that share a device, at evaluation granularity.  A context of class CMX_SCHED_BACKGROUND (the back end) holds its
  * NEXT evaluation -- between two evaluations of a solve there is nothing of it on the GPU -- while a context of class

@@ -59,4 +59,44 @@ enum {
                                0: splat, image pass and gather as three launches */
 };
 
+#if defined(__cplusplus)
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* Static scheduling mechanisms, kept for A/B measurements (moved here from cmax_hip.h in ABI 6: they do not deliver).  Both calls
+ * replace the context's OWN stream (they wait for its queued work first; not with cmx_set_stream's caller-owned stream):
+ *   cmx_set_stream_priority  level > 0: the device's highest stream priority, 0: normal, < 0: lowest;
+ *   cmx_set_cu_mask          the stream's kernels run on the compute units whose bit is set (hipExtStreamCreateWithCUMask;
+ *                            n_words x 32 bits; which physical unit a bit selects is the driver's mapping); n_words == 0: all
+ *                            compute units, normal priority.
+ * Measured on MI355X (profiles/r04_fe_beside_be.txt): with both contexts evaluating back to back the default -- dynamic sharing --
+ * costs the front end x1.9 and the back end x1.23; priorities change nothing (the back end's launches are one resident round of
+ * workgroups that fill the register files; a queue's priority does not pre-empt them); disjoint masks isolate the two (beside =
+ * solo x1.04-1.09) at the price of a static split -- e.g. front end 51.8 us (x1.34) / back end x1.82 with half of every XCD each.
+ * What does work is cmx_set_sched_class (cmax_hip.h).
+ * A masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags; every other stream of this library is
+ * hipStreamNonBlocking): the per-packet / per-window / per-evaluation paths issue nothing on the null stream, but the rare
+ * synchronous calls that do (cmx_backend_get_map / _set_map, context creation, the device-driven solve's early-stop word) are then
+ * ordered against a masked context's queue like any null-stream work.  Results never depend on either call. */
+int cmx_set_stream_priority(cmx_ctx *ctx, int level);
+int cmx_set_cu_mask(cmx_ctx *ctx, const uint32_t *mask, int n_words);
+
+/* Process-wide test switches (read when a context / group is created).
+ *   CMX_DIAG_FORCE_CROSS_DEVICE  1: a group whose members share ONE device is set up as if they sat on several -- the peer kernels
+ *                                take their system-scope acquire (xdev) variants and the exchange's events release to system scope --
+ *                                so that a one-GPU box executes the code paths of a multi-GPU group.  Results
+ *                                are unchanged; the collectives get slower. */
+enum { CMX_DIAG_FORCE_CROSS_DEVICE = 1 };
+int cmx_diag_set(int key, int value);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#if defined(__cplusplus)
+}
+#endif
+
 #endif /* CMAX_HIP_DIAG_H */

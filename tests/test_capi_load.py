@@ -19,7 +19,8 @@ def L():
 
 def test_every_declared_symbol_is_exported(L):
     from cmax_slam_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "cmax_hip.h")).read()
+    # the host surface + the diagnostic header (A/B option keys, the two static scheduling calls, process-wide test switches)
+    hdr = open(os.path.join(ROOT, "include", "cmax_hip.h")).read() + open(os.path.join(ROOT, "include", "cmax_hip_diag.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(cmx_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 25

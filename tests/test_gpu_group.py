@@ -433,3 +433,57 @@ def test_group_exchange_soak_short():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_group.py"), "700"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "soak ok" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+@pytest.fixture
+def forced_cross_device(hip):
+    """cmax_hip_diag.h, CMX_DIAG_FORCE_CROSS_DEVICE: groups created inside take the multi-device code paths on ONE device."""
+    L = _lib.lib()
+    assert L.cmx_diag_set(_lib.DIAG_FORCE_CROSS_DEVICE, 1) == 0
+    yield
+    assert L.cmx_diag_set(_lib.DIAG_FORCE_CROSS_DEVICE, 0) == 0
+    assert L.cmx_diag_set(99, 1) != 0  # unknown keys are refused
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_cross_device_code_paths_on_one_device(hip, forced_cross_device, members):
+    """no box with two visible devices exists (profiles/r06_partition_probe.txt: one render node, SPX, sysfs
+    read-only), so the group's cross-device forms run HERE: with the switch on, a same-device group takes the system-scope-acquire
+    (xdev) variants of every peer kernel -- whole-plane reduce-scatter + all-gather on the first evaluation, the one-shot
+    exchange fused into the unpack afterwards, the miss exchange after a jump -- and its events release to system scope.  Same
+    numbers as the single context (and as the same group without the switch, which the other tests hold against the oracle)."""
+    w = synth.config4_slab(1, 8, 1_500_000)
+    grp, one = _pair(hip, w, [0] * members, transport=_lib.GROUP_DIRECT)
+    rng = np.random.default_rng(70 + members)
+    small = rng.normal(0, 0.004, w.P)
+    jump = np.tile([0.5, 0.0, 0.0], w.P // 3)
+    seq = [(np.zeros(w.P), True), (small, False), (small, True), (rng.normal(0, 0.004, w.P), True), (jump, True), (np.zeros(w.P), True)]
+    _same(grp, one, seq)
+    s = grp.stats()
+    assert s["exchange_misses"] >= 1 and s["sharded_host_syncs"] == 0, s
+    # a solve through the handle, and a second window (whole planes again on its first evaluation)
+    x, rep = grp.setupProblemAndOptimize()
+    x1, rep1 = one.setupProblemAndOptimize()
+    assert abs(rep["final_cost"] - rep1["final_cost"]) < 1e-3 * abs(rep1["final_cost"]), (rep, rep1)
+    for ev in (grp, one):
+        _set(ev, w, n=600_000)
+    _same(grp, one, [(np.zeros(w.P), True), (small, True)])
+    assert rel_img(grp.get_plane(_lib.PLANE_IWE), one.get_plane(_lib.PLANE_IWE)) < RTOL
+    grp.close()
+    one.close()
+
+
+def test_cross_device_code_paths_small_planes_whole_plane_exchange(hip, oracle, forced_cross_device):
+    """planes below 1 MB always travel whole (reduce-scatter + all-gather kernels, 16-byte peer accesses): the xdev variants of those
+    two kernels against the oracle"""
+    w = synth.backend_window(30_001, 240, 180, 200.0, 200.0, 119.5, 89.5, 512, 256, 4, 8, 2, 0.25, seed=171)
+    grp = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0, 0], transport=_lib.GROUP_DIRECT)
+    _set(grp, w)
+    ref = oracle.Backend(w.W, w.H, w.lut, w.Wp, w.Hp, w.order)
+    ref.set_window(w.x, w.y, w.t_ns, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns)
+    rng = np.random.default_rng(3)
+    for d in (np.zeros(w.P), rng.normal(0, 0.01, w.P)):
+        c, g = grp.eval(d, True)
+        cr, gr = ref.eval(d)
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL
+    grp.close()

@@ -16,6 +16,9 @@ from cmax_slam_amd import _lib, evaluator, synth  # noqa: E402
 
 def main():
     n_eval = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    if len(sys.argv) > 2 and sys.argv[2] == "xdev":  # the multi-device code paths on this one device (cmax_hip_diag.h)
+        assert _lib.lib().cmx_diag_set(_lib.DIAG_FORCE_CROSS_DEVICE, 1) == 0
+        print("CMX_DIAG_FORCE_CROSS_DEVICE on: system-scope acquire variants of the peer kernels, release-to-system events", flush=True)
     w = synth.config4_slab(2, 8, 600_000)
     rng = np.random.default_rng(11)
     one = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp)
