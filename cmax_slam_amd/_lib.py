@@ -43,6 +43,7 @@ SYMBOLS = {
     "cmx_set_stream_priority": (C.c_int, [ctx_p, C.c_int]),
     "cmx_set_cu_mask": (C.c_int, [ctx_p, C.POINTER(C.c_uint32), C.c_int]),
     "cmx_diag_set": (C.c_int, [C.c_int, C.c_int]),
+    "cmx_group_transport_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), c_dp, c_dp]),
     "cmx_set_sched_class": (C.c_int, [ctx_p, C.c_int]),
     "cmx_backend_create_group": (C.c_int, [C.POINTER(ctx_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_int,
                                            C.c_int]),

@@ -191,6 +191,13 @@ static int exchange_planes(cmx_ctx *c) {
 
 }  // namespace
 
+// One staged exchange of `count` floats through whatever transport the context has attached -- what a group's transport calibration
+// times (cmx_group.cpp group_calibrate); the caller alternates `in` between two buffers like exchange_tiles does.
+int comm_probe_exchange(cmx_ctx *c, float *in, float *out, size_t count) {
+  float *res = nullptr;
+  return comm_allreduce_staged(c, in, out, count, &res);
+}
+
 void comm_release(cmx_ctx *c) {
   if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
   c->comm = nullptr;

@@ -359,6 +359,7 @@ int ensure(cmx_ctx *c, T *&ptr, size_t &cap, size_t need) {
 
 // ---- cmx_context.cpp
 int bind_device(cmx_ctx *c);
+int comm_probe_exchange(cmx_ctx *c, float *in, float *out, size_t count);  // cmx_comm.cpp
 long long time_batch_ns(long long t_first, long long t_last);
 double time_to_sec(long long t_ns);
 int upload_gt1(cmx_ctx *c);

@@ -181,6 +181,10 @@ struct cmx_group {
   std::vector<double> out_g[kMaxMembers];
   int64_t evals = 0;
   double last_fanout_us = 0;  // host time of the last fan-out: command published -> every member returned
+  // ---- CMX_GROUP_AUTO: both transports set up where both are possible, the faster one (measured on this group's own message) kept
+  ncclComm_t rccl_comms[kMaxMembers] = {nullptr};
+  bool have_rccl = false, have_direct = false, calibrated = false;
+  double calib_us[3] = {-1.0, -1.0, -1.0};  // per exchange of kCalibFloats floats, indexed by CMX_GROUP_* (-1: not available / not measured)
 };
 
 namespace {
@@ -416,55 +420,136 @@ static void group_teardown(cmx_group *g) {
     if (!m) continue;
     m->group = nullptr;
     if (m->comm_fn) { m->comm_fn = nullptr; m->comm_fn_oop = nullptr; m->comm_fn_peers = nullptr; m->comm_user = nullptr; }
+    if (g->rccl_comms[r]) m->comm = g->rccl_comms[r];  // (set up but not selected: the member's destroy releases it all the same)
     cmx_destroy(m);
   }
   delete g;
 }
 void group_destroy(cmx_ctx *leader) { group_teardown(leader->group); }
 
-// transport set-up + worker threads of a group whose members exist; on failure the group stays "not ready" (group_all refuses)
-static int group_connect(cmx_group *g, cmx_ctx *leader, const int *devices, int n_devices, int transport, bool same_device) {
-  if (transport == CMX_GROUP_RCCL) {
-    if (same_device) return fail(leader, CMX_ERR_INVALID_ARG, "RCCL cannot place two ranks on one device: use CMX_GROUP_DIRECT");
-    if (!rccl_group().ok) return fail(leader, CMX_ERR_HIP, "librccl.so.1 could not be loaded (ncclCommInitAll)");
-    ncclComm_t comms[kMaxMembers] = {nullptr};
-    const ncclResult_t r = rccl_group().CommInitAll(comms, n_devices, devices);
-    if (r != ncclSuccess) return fail(leader, CMX_ERR_HIP, "ncclCommInitAll failed: %s", rccl_group().GetErrorString(r));
-    for (int k = 0; k < n_devices; k++) { g->m[k]->comm = comms[k]; g->m[k]->comm_rank = k; g->m[k]->comm_size = n_devices; }
-  } else {
-    for (int a = 0; a < n_devices; a++) {  // peer access between the members' devices (a no-op on one device)
-      HIP_TRY(leader, hipSetDevice(devices[a]));
-      for (int b = 0; b < n_devices; b++) {
-        if (devices[a] == devices[b]) continue;
-        int can = 0;
-        HIP_TRY(leader, hipDeviceCanAccessPeer(&can, devices[a], devices[b]));
-        if (!can) return fail(leader, CMX_ERR_HIP, "device %d cannot access device %d: the direct transport needs peer access", devices[a], devices[b]);
-        const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(leader, CMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed", devices[a], devices[b]);
-        (void)hipGetLastError();
-      }
-    }
-    for (int r = 0; r < n_devices; r++) {
-      HIP_TRY(leader, hipSetDevice(devices[r]));
-      // system-scope release at the record: what a peer DEVICE reads behind the wait must be in memory, not in this device's L2
-      const unsigned flags = hipEventDisableTiming | hipEventReleaseToSystem;
-      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ready[r], flags));
-      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_rs[r], flags));
-      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ag[r], flags));
-      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[0][r], flags));
-      HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[1][r], flags));
-      g->duser[r].g = g;
-      g->duser[r].rank = r;
-      g->m[r]->comm_fn = direct_allreduce;
-      g->m[r]->comm_fn_oop = direct_oneshot;
-      g->m[r]->comm_fn_peers = direct_peers;
-      g->m[r]->comm_user = &g->duser[r];
-      g->m[r]->comm_rank = r;
-      g->m[r]->comm_size = n_devices;
+// ---- transport set-up.  CMX_GROUP_RCCL / CMX_GROUP_DIRECT set up the one asked for; CMX_GROUP_AUTO sets up every transport the
+// devices allow and keeps the one that moves THIS group's message fastest (group_calibrate).
+static int setup_rccl(cmx_group *g, cmx_ctx *leader, const int *devices, int n_devices) {
+  if (!rccl_group().ok) return fail(leader, CMX_ERR_HIP, "librccl.so.1 could not be loaded (ncclCommInitAll)");
+  const ncclResult_t r = rccl_group().CommInitAll(g->rccl_comms, n_devices, devices);
+  if (r != ncclSuccess) return fail(leader, CMX_ERR_HIP, "ncclCommInitAll failed: %s", rccl_group().GetErrorString(r));
+  g->have_rccl = true;
+  return CMX_OK;
+}
+static int setup_direct(cmx_group *g, cmx_ctx *leader, const int *devices, int n_devices) {
+  for (int a = 0; a < n_devices; a++) {  // peer access between the members' devices (a no-op on one device)
+    HIP_TRY(leader, hipSetDevice(devices[a]));
+    for (int b = 0; b < n_devices; b++) {
+      if (devices[a] == devices[b]) continue;
+      int can = 0;
+      HIP_TRY(leader, hipDeviceCanAccessPeer(&can, devices[a], devices[b]));
+      if (!can) return fail(leader, CMX_ERR_HIP, "device %d cannot access device %d: the direct transport needs peer access", devices[a], devices[b]);
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(leader, CMX_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed", devices[a], devices[b]);
+      (void)hipGetLastError();
     }
   }
+  for (int r = 0; r < n_devices; r++) {
+    HIP_TRY(leader, hipSetDevice(devices[r]));
+    // system-scope release at the record: what a peer DEVICE reads behind the wait must be in memory, not in this device's L2
+    const unsigned flags = hipEventDisableTiming | hipEventReleaseToSystem;
+    HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ready[r], flags));
+    HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_rs[r], flags));
+    HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_ag[r], flags));
+    HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[0][r], flags));
+    HIP_TRY(leader, hipEventCreateWithFlags(&g->ev_os[1][r], flags));
+    g->duser[r].g = g;
+    g->duser[r].rank = r;
+  }
+  g->have_direct = true;
+  return CMX_OK;
+}
+// point every member at one of the transports that have been set up
+static void select_transport(cmx_group *g, int transport) {
+  for (int r = 0; r < g->n; r++) {
+    cmx_ctx *m = g->m[r];
+    m->comm_rank = r;
+    m->comm_size = g->n;
+    if (transport == CMX_GROUP_RCCL) {
+      m->comm = g->rccl_comms[r];
+      m->comm_fn = nullptr; m->comm_fn_oop = nullptr; m->comm_fn_peers = nullptr; m->comm_user = nullptr;
+    } else {
+      m->comm = nullptr;
+      m->comm_fn = direct_allreduce; m->comm_fn_oop = direct_oneshot; m->comm_fn_peers = direct_peers; m->comm_user = &g->duser[r];
+    }
+  }
+  g->transport = transport;
+}
+// Time the staged exchange of a message the size of a production tile set (config 4: ~1 MB) through every transport that is set up:
+// kCalibWarm + kCalibReps exchanges each, every member on its own thread exactly as an evaluation issues them, wall clock of the
+// calling thread around the fan-out (stream-synchronised at the end).  A transport that fails its probe is dropped.
+constexpr size_t kCalibFloats = 256 * 1024;
+constexpr int kCalibWarm = 3, kCalibReps = 20;
+static int group_calibrate(cmx_group *g, cmx_ctx *leader) {
+  float *buf[kMaxMembers][3] = {{nullptr}};
+  int rc = group_all(leader, [&](cmx_ctx *m, int r) {
+    int rc2 = bind_device(m);
+    for (int k = 0; k < 3 && !rc2; k++) {
+      if (hipMalloc((void **)&buf[r][k], kCalibFloats * sizeof(float)) != hipSuccess) rc2 = fail(m, CMX_ERR_HIP, "calibration buffer");
+      else if (hipMemsetAsync(buf[r][k], 0, kCalibFloats * sizeof(float), m->stream) != hipSuccess) rc2 = fail(m, CMX_ERR_HIP, "calibration buffer");
+    }
+    return rc2;
+  });
+  for (int t = CMX_GROUP_RCCL; t <= CMX_GROUP_DIRECT && !rc; t++) {
+    if ((t == CMX_GROUP_RCCL && !g->have_rccl) || (t == CMX_GROUP_DIRECT && !g->have_direct)) continue;
+    select_transport(g, t);
+    for (int pass = 0; pass < 2; pass++) {
+      const int reps = pass == 0 ? kCalibWarm : kCalibReps;
+      const double t0 = now_us();
+      const int prc = group_all(leader, [&](cmx_ctx *m, int r) {
+        int rc2 = bind_device(m);
+        for (int k = 0; k < reps && !rc2; k++) rc2 = comm_probe_exchange(m, buf[r][k & 1], buf[r][2], kCalibFloats);
+        if (!rc2 && hipStreamSynchronize(m->stream) != hipSuccess) rc2 = fail(m, CMX_ERR_HIP, "calibration exchange");
+        return rc2;
+      });
+      if (prc) { g->calib_us[t] = -1.0; if (t == CMX_GROUP_RCCL) g->have_rccl = false; else g->have_direct = false; break; }
+      if (pass == 1) g->calib_us[t] = (now_us() - t0) / reps;
+    }
+  }
+  (void)group_all(leader, [&](cmx_ctx *m, int r) {
+    (void)bind_device(m);
+    for (int k = 0; k < 3; k++) if (buf[r][k]) (void)hipFree(buf[r][k]);
+    return CMX_OK;
+  });
+  if (rc) return rc;
+  if (!g->have_rccl && !g->have_direct) return fail(leader, CMX_ERR_HIP, "no transport passed its calibration exchange");
+  int best = g->have_direct ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL;
+  if (g->have_rccl && g->have_direct && g->calib_us[CMX_GROUP_RCCL] < g->calib_us[CMX_GROUP_DIRECT]) best = CMX_GROUP_RCCL;
+  select_transport(g, best);
+  g->calibrated = true;
+  for (int r = 0; r < g->n; r++) { g->m[r]->comm_bytes_eval = 0; g->m[r]->comm_calls_eval = 0; }
+  return CMX_OK;
+}
+
+// transport set-up + worker threads of a group whose members exist; on failure the group stays "not ready" (group_all refuses)
+static int group_connect(cmx_group *g, cmx_ctx *leader, const int *devices, int n_devices, int transport, bool same_device) {
+  const bool automatic = transport == CMX_GROUP_AUTO;
+  int rc = CMX_OK;
+  if (transport == CMX_GROUP_RCCL) {
+    if (same_device) return fail(leader, CMX_ERR_INVALID_ARG, "RCCL cannot place two ranks on one device: use CMX_GROUP_DIRECT");
+    rc = setup_rccl(g, leader, devices, n_devices);
+  } else if (transport == CMX_GROUP_DIRECT) {
+    rc = setup_direct(g, leader, devices, n_devices);
+  } else {  // AUTO: whatever the devices allow (members sharing a device: the direct transport only); a transport that cannot be
+            // set up (no peer access, no librccl) is simply not a candidate
+    const int rd = setup_direct(g, leader, devices, n_devices);
+    const int rr = same_device ? CMX_ERR_INVALID_ARG : setup_rccl(g, leader, devices, n_devices);
+    if (rd && rr) rc = rd;  // (the text of the direct transport's failure; RCCL's is in the handle's error string only if it came last)
+    else leader->err.clear();
+  }
+  if (rc) return rc;
+  select_transport(g, g->have_direct && (transport == CMX_GROUP_DIRECT || automatic) ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL);
   for (int r = 1; r < n_devices; r++) g->workers.emplace_back(worker_loop, g, r);
   g->ready = true;
+  if (automatic) {
+    rc = group_calibrate(g, leader);
+    if (rc) { g->ready = false; return rc; }
+  }
   HIP_TRY(leader, hipSetDevice(devices[0]));
   return CMX_OK;
 }
@@ -486,10 +571,9 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
   bool same_device = false;
   for (int a = 0; a < n_devices; a++)
     for (int b = a + 1; b < n_devices; b++) same_device = same_device || devices[a] == devices[b];
-  if (transport == CMX_GROUP_AUTO) transport = same_device ? CMX_GROUP_DIRECT : CMX_GROUP_RCCL;
   cmx_group *g = new cmx_group();
   g->n = n_devices;
-  g->transport = transport;
+  g->transport = transport == CMX_GROUP_AUTO ? CMX_GROUP_DIRECT : transport;  // (AUTO: replaced by the measured choice in group_connect)
   for (int a = 1; a < n_devices; a++) g->cross_device = g->cross_device || devices[a] != devices[0];
   if (g_diag_force_cross_device.load(std::memory_order_relaxed)) g->cross_device = true;  // (cmax_hip_diag.h: a one-GPU box runs the xdev paths)
   int rc = CMX_OK;
@@ -594,6 +678,15 @@ int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *g
   return CMX_OK;
 }
 
+int cmx_group_transport_info(cmx_ctx *c, int *chosen, int *measured, double *us_direct, double *us_rccl) {
+  if (!c) return CMX_ERR_INVALID_ARG;
+  const cmx_group *g = c->group;
+  if (chosen) *chosen = g ? g->transport : CMX_GROUP_AUTO;
+  if (measured) *measured = (g && g->calibrated) ? 1 : 0;
+  if (us_direct) *us_direct = g ? g->calib_us[CMX_GROUP_DIRECT] : -1.0;
+  if (us_rccl) *us_rccl = g ? g->calib_us[CMX_GROUP_RCCL] : -1.0;
+  return CMX_OK;
+}
 int cmx_group_info(cmx_ctx *c, int *n_members, int *devices, int max_devices, int *transport, int64_t *events_per_member,
                    double *last_fanout_us) {
   if (!c) return CMX_ERR_INVALID_ARG;

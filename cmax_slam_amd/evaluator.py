@@ -405,6 +405,12 @@ class BackendEvaluator(_Evaluator):
         return {"members": n.value, "devices": list(dev[:n.value]), "transport": tr.value,
                 "events_per_member": [int(v) for v in ev[:n.value]], "last_fanout_us": us.value}
 
+    def group_transport_info(self):
+        """{'chosen', 'measured', 'us_direct', 'us_rccl'}: cmx_group_transport_info (CMX_GROUP_AUTO times the candidates at creation)."""
+        ch, me, ud, ur = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        self._ck(self._L.cmx_group_transport_info(self._ctx, C.byref(ch), C.byref(me), C.byref(ud), C.byref(ur)))
+        return {"chosen": ch.value, "measured": bool(me.value), "us_direct": ud.value, "us_rccl": ur.value}
+
     def get_pose_table(self):
         """cmx_backend_get_pose_table: (R[nb,3,3] fp64, Jcp[nb,3,3*order] fp32, idx[nb], t_batch_ns[nb]) at the last evaluation's
         parameters -- what Trajectory::evaluate returns per batch (value, ddrot_ddrot_cp, idx_cp_beg)."""

@@ -343,7 +343,9 @@ int cmx_comm_info(cmx_ctx *ctx, int *rank, int *nranks, int *transport);
  *              CMX_GROUP_DIRECT -- peer-to-peer reduce-scatter + all-gather kernels over the members' own buffers, ordered by
  *                                  HIP events (needs peer access between the devices; the only form for members that share
  *                                  ONE device, which is how a single-GPU box exercises all of this);
- *              CMX_GROUP_AUTO   -- DIRECT if two members share a device, RCCL otherwise.
+ *              CMX_GROUP_AUTO   -- MEASURED: every transport the devices allow is set up (members sharing a device: DIRECT only;
+ *                                  no peer access: RCCL only), a production-sized exchange is timed through each at creation and
+ *                                  the faster one kept (cmx_group_transport_info reports the choice and both timings).
  * n_devices == 1 returns a plain context (no group, no overhead).  Results equal the single-context evaluation of the whole
  * window to summation order (the planes are sums of the members' partial planes). */
 enum { CMX_GROUP_AUTO = 0, CMX_GROUP_RCCL = 1, CMX_GROUP_DIRECT = 2 };
@@ -353,6 +355,12 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
  * host microseconds of the last fan-out (command published -> all members returned).  Any pointer may be NULL. */
 int cmx_group_info(cmx_ctx *ctx, int *n_members, int *devices, int max_devices, int *transport, int64_t *events_per_member,
                    double *last_fanout_us);
+/* how the transport in use was picked: *chosen = CMX_GROUP_RCCL / _DIRECT; *measured = 1 when CMX_GROUP_AUTO timed the candidates at
+ * creation (20 staged exchanges of a 1 MB message -- a production tile set -- through every transport the devices allow, each member
+ * on its own thread as an evaluation issues them) and kept the faster; *us_direct / *us_rccl = microseconds per exchange (-1: that
+ * transport could not be set up on these devices -- e.g. RCCL for members sharing one device -- or was not timed).  Any pointer may
+ * be NULL; a plain context reports CMX_GROUP_AUTO, 0, -1, -1. */
+int cmx_group_transport_info(cmx_ctx *ctx, int *chosen, int *measured, double *us_direct, double *us_rccl);
 
 /* ------------------------------------------------------------------ optimiser driver (host C++) ----------
  * The reference runs GSL's Fletcher-Reeves conjugate gradient around the cost functors

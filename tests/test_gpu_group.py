@@ -487,3 +487,24 @@ def test_cross_device_code_paths_small_planes_whole_plane_exchange(hip, oracle, 
         cr, gr = ref.eval(d)
         assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL
     grp.close()
+
+
+def test_auto_transport_is_measured(hip):
+    """CMX_GROUP_AUTO keeps the transport that moved a production-sized message fastest at creation.  On one device
+    the only candidate is the direct transport (RCCL cannot place two ranks on a device): the calibration still runs -- 20 staged
+    exchanges of 1 MB through the members' own threads -- and reports its time; an explicit transport is not timed; evaluations
+    behind a calibrated group equal the single context's (and the members' contrasts agree bit for bit, or eval would have failed)."""
+    w = synth.config4_slab(0, 8, 800_000)
+    grp, one = _pair(hip, w, [0, 0], transport=_lib.GROUP_AUTO)
+    ti = grp.group_transport_info()
+    assert ti["chosen"] == _lib.GROUP_DIRECT and ti["measured"] and 1.0 < ti["us_direct"] < 5e4 and ti["us_rccl"] == -1.0, ti
+    assert grp.group_info()["transport"] == _lib.GROUP_DIRECT
+    rng = np.random.default_rng(31)
+    _same(grp, one, [(np.zeros(w.P), True), (rng.normal(0, 0.004, w.P), True), (rng.normal(0, 0.004, w.P), False)])
+    assert grp.stats()["comm_bytes"] < 2 * (1 << 20)   # (the calibration's traffic is not the evaluations')
+    explicit = hip.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, devices=[0, 0], transport=_lib.GROUP_DIRECT)
+    te = explicit.group_transport_info()
+    assert te["chosen"] == _lib.GROUP_DIRECT and not te["measured"] and te["us_direct"] == -1.0, te
+    assert one.group_transport_info() == {"chosen": _lib.GROUP_AUTO, "measured": False, "us_direct": -1.0, "us_rccl": -1.0}
+    for ev in (grp, one, explicit):
+        ev.close()
