@@ -677,6 +677,59 @@ def cmax_solves(n_solves, ev, kind, _lib):
             "host_takeovers": s1["chain_takeovers"] - s0["chain_takeovers"]}
 
 
+def aos_ingest(device, p, reps=5):
+    """SURVEY 8(f)-3: events from the host's own records (std::vector<dvs_msgs::Event>, 16-byte AoS) to resident-on-device.
+    (a) the *_aos entry points: ONE packing pass straight from the records; (b) what a host had to do before them: the conversion
+    loop into three SoA vectors (here numpy's strided field copies, the speed of a plain C loop) + the SoA entry point.  The
+    reference's own ingest is pushEvent's per-event push_back of the same 16-byte record (ang_vel_estimator.cpp:68-78) and a copy
+    of the packet into event_subset_ (:137-147) -- two passes over the records on the CPU and nothing uploaded."""
+    from cmax_slam_amd import _lib, evaluator
+    n = len(p.x)
+    ev = _lib.dvs_events(p.x, p.y, p.t_ns)
+    store = evaluator.EventStore(p.W, p.H, 2 * n, device=device)
+    fe = evaluator.FrontendEvaluator(p.W, p.H, p.lut, device=device)
+
+    def best(fn):
+        b = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            b = min(b, time.perf_counter() - t0)
+        return b * 1e3
+
+    def push_aos():
+        store.drop_before(store.end)
+        store.push_aos(ev)
+
+    def push_soa():
+        store.drop_before(store.end)
+        store.push(p.x, p.y, p.t_ns)
+
+    conv = {}
+
+    def convert():
+        conv["x"], conv["y"] = np.ascontiguousarray(ev["x"]), np.ascontiguousarray(ev["y"])
+        conv["t"] = ev["sec"].astype(np.int64) * 1000000000 + ev["nsec"]
+
+    def packet_aos():
+        fe.set_packet_aos(ev, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+
+    def packet_soa():
+        fe.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+
+    push_aos()
+    out = {"events": n, "record": "dvs_msgs::Event (16 bytes: uint16 x, y; uint32 sec, nsec; bool polarity)",
+           "store_push_aos_ms": best(push_aos), "store_push_soa_ms": best(push_soa), "aos_to_soa_conversion_ms": best(convert),
+           "set_packet_aos_ms": best(packet_aos), "set_packet_soa_ms": best(packet_soa)}
+    out["store_push_aos_events_per_s"] = n / (out["store_push_aos_ms"] * 1e-3)
+    out["via_conversion_events_per_s"] = n / ((out["aos_to_soa_conversion_ms"] + out["store_push_soa_ms"]) * 1e-3)
+    out["note"] = ("push = packing pass on the host pool into pinned staging + upload, complete on return; set_packet = packing pass + "
+                   "per-batch times, uploads queued behind it on the context's stream (the call returns; the first evaluation waits for them)")
+    store.close()
+    fe.close()
+    return out
+
+
 def per_packet_pipeline(device, which, n_packets=8):
     """The per-packet pipeline of the front end (reference: AngVelEstimator's loop, src/frontend/ang_vel_estimator.cpp:68-147:
     a NEW packet every ~10 ms): hand-over, first evaluation (upload + destination-tile sort + streams), FR-CG solve.
@@ -1237,6 +1290,10 @@ def summary_of(out):
                                           "host_seq": g(out, "per_window", "host_arrays", "sequential", "ratio_to_solve"),
                                           "store_set_window_ms": g(out, "per_window", "device_store", "set_window_ms"),
                                           "host_set_window_ms": g(out, "per_window", "host_arrays", "set_window_ms")}
+    if isinstance(out.get("aos_ingest"), dict) and "store_push_aos_ms" in out["aos_ingest"]:
+        ai = out["aos_ingest"]
+        s["aos_ingest_1M"] = {"push_aos_ms": round(ai["store_push_aos_ms"], 3), "convert_plus_push_soa_ms": round(ai["aos_to_soa_conversion_ms"] + ai["store_push_soa_ms"], 3),
+                              "events_per_s": ai["store_push_aos_events_per_s"]}
     if isinstance(out.get("comm"), dict):
         s["comm"] = {k: out["comm"].get(k) for k in ("nranks_seen", "transport", "ms_per_step", "share_of_step", "collectives_per_step",
                                                      "bytes_last_evaluation")}
@@ -1522,6 +1579,11 @@ def main():
                                          "store60k": per_packet_pipeline(local_rank, "store60k", 16)}
                 except Exception as e:  # must not cost the headline line
                     out["per_packet"] = {"error": repr(e)}
+            if world == 1 and not args.no_per_packet:
+                try:
+                    out["aos_ingest"] = aos_ingest(local_rank, p)
+                except Exception as e:
+                    out["aos_ingest"] = {"error": repr(e)}
             if world == 1 and not args.no_per_packet:
                 try:
                     out["concurrent_contexts"] = concurrent_contexts(local_rank, p, pts, out["whole_evaluation"]["hbm_mandatory_bytes"])

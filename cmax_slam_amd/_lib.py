@@ -32,6 +32,33 @@ c_i64p = C.POINTER(C.c_int64)
 ctx_p = C.c_void_p
 
 # every symbol include/cmax_hip.h declares: (restype, argtypes)
+class AosLayout(C.Structure):  # cmx_aos_layout: record size + byte offsets of (uint16 x, uint16 y, uint32 sec, uint32 nsec)
+    _fields_ = [("stride", C.c_size_t), ("off_x", C.c_size_t), ("off_y", C.c_size_t), ("off_sec", C.c_size_t), ("off_nsec", C.c_size_t)]
+
+
+import numpy as _np  # noqa: E402
+# dvs_msgs::Event as the reference's std::vector holds it: {uint16 x, y; ros::Time ts {uint32 sec, nsec}; bool polarity} = 16 bytes
+DVS_EVENT_DTYPE = _np.dtype({"names": ["x", "y", "sec", "nsec", "polarity"], "formats": ["<u2", "<u2", "<u4", "<u4", "u1"],
+                             "offsets": [0, 2, 4, 8, 12], "itemsize": 16})
+
+
+def aos_layout_of(arr):
+    """cmx_aos_layout of a numpy structured array with fields x, y, sec, nsec."""
+    f = arr.dtype.fields
+    return AosLayout(arr.dtype.itemsize, f["x"][1], f["y"][1], f["sec"][1], f["nsec"][1])
+
+
+def dvs_events(x, y, t_ns, polarity=None):
+    """SoA -> the reference's AoS records (test / bench helper: what a ROS host already has in msg->events)."""
+    ev = _np.zeros(len(x), DVS_EVENT_DTYPE)
+    ev["x"], ev["y"] = x, y
+    t = _np.asarray(t_ns, _np.int64)
+    ev["sec"], ev["nsec"] = t // 1000000000, t % 1000000000
+    if polarity is not None:
+        ev["polarity"] = polarity
+    return ev
+
+
 SYMBOLS = {
     "cmx_version": (C.c_char_p, []),
     "cmx_device_count": (C.c_int, []),
@@ -78,6 +105,11 @@ SYMBOLS = {
     "cmx_events_destroy": (None, [C.c_void_p]),
     "cmx_events_last_error": (C.c_char_p, [C.c_void_p]),
     "cmx_events_push": (C.c_int, [C.c_void_p, C.c_int64, c_u16p, c_u16p, c_i64p]),
+    "cmx_events_push_aos": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(AosLayout)]),
+    "cmx_frontend_set_packet_aos": (C.c_int, [ctx_p, C.c_int64, C.c_void_p, C.POINTER(AosLayout), C.c_int64, C.c_double, C.c_double,
+                                            C.c_double, C.c_double, C.c_int, C.c_double, C.c_int]),
+    "cmx_backend_set_window_aos": (C.c_int, [ctx_p, C.c_int64, C.c_void_p, C.POINTER(AosLayout), C.c_int, C.c_int, c_dp, C.c_int64,
+                                           C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, c_fp]),
     "cmx_events_drop_before": (C.c_int, [C.c_void_p, C.c_int64]),
     "cmx_events_begin": (C.c_int64, [C.c_void_p]),
     "cmx_events_end": (C.c_int64, [C.c_void_p]),

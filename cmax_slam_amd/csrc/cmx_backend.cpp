@@ -34,7 +34,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
                               const uint32_t *d_raw, const int64_t *d_t, int order, int K, const double *knots_xyzw,
                               int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
                               int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure,
-                              const float *IG) {
+                              const float *IG, const EvAos *aos) {
   if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
   int rc = bind_device(c);
   if (rc) return rc;
@@ -48,7 +48,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   if (event_batch_size <= 0 || event_sample_rate <= 0) return fail(c, CMX_ERR_INVALID_ARG, "batch size / sample rate must be > 0");
   // the back end's switch (global_focus_funcs.cpp:61-69) knows mean square only; everything else is variance
   if (contrast_measure != CMX_MEAN_SQUARE) contrast_measure = CMX_VARIANCE;
-  if (!d_raw) {
+  if (!d_raw && !aos) {
     rc = check_event_args(c, n, x, y, t_ns);
     if (rc) return rc;
   } else if (n < 0 || n > kMaxEvents) {
@@ -88,8 +88,9 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     for (int64_t b = b0; b < b1; b++) {
       const int64_t beg = b * B;
       const int64_t end = (n - beg > B) ? beg + B : n;
-      if (t_ns[end - 1] < t_ns[beg]) { err_kind = CMX_ERR_TIME_ORDER; err_at = beg; return; }
-      const long long tb = time_batch_ns(t_ns[beg], t_ns[end - 1]);
+      const int64_t t_first = aos ? aos->T(beg) : t_ns[beg], t_last = aos ? aos->T(end - 1) : t_ns[end - 1];
+      if (t_last < t_first) { err_kind = CMX_ERR_TIME_ORDER; err_at = beg; return; }
+      const long long tb = time_batch_ns(t_first, t_last);
       const long long st = tb - start_ns;
       if (st < 0 || st / dt_ns + order > K) { err_kind = CMX_ERR_SPLINE_RANGE; err_at = tb; return; }
       bt[(size_t)b] = tb;
@@ -97,13 +98,25 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
       uint32_t *dst = xy + b * per_batch;
       unsigned acc = 0;
       for (int64_t e = beg; e < end; e += rate) {
-        acc |= (unsigned)(x[e] >= sensor_w) | (unsigned)(y[e] >= sensor_h);
-        *dst++ = (uint32_t)x[e] | ((uint32_t)y[e] << 16) | ((t_ns[e] < t_next_win_beg_ns) ? 0x80000000u : 0u);
+        const unsigned ex = aos ? aos->X(e) : (unsigned)x[e], ey = aos ? aos->Y(e) : (unsigned)y[e];
+        const int64_t et = aos ? aos->T(e) : t_ns[e];
+        acc |= (unsigned)(ex >= sensor_w) | (unsigned)(ey >= sensor_h);
+        *dst++ = ex | (ey << 16) | ((et < t_next_win_beg_ns) ? 0x80000000u : 0u);
       }
       if (acc) out_of_range = 1;
     }
   });
-  if (rate == 1 && !d_raw)
+  if (rate == 1 && !d_raw && aos)  // straight from the host's records (dvs_msgs::Event): no x[] / y[] / t_ns[] vectors in between
+    parallel_ranges(n_packed_total, [&](int64_t a0, int64_t a1) {
+      unsigned acc = 0;
+      for (int64_t e = a0; e < a1; e++) {
+        const unsigned ex = aos->X(e), ey = aos->Y(e);
+        acc |= (unsigned)(ex >= sensor_w) | (unsigned)(ey >= sensor_h);
+        xy[e] = ex | (ey << 16) | ((uint32_t)(aos->T(e) < t_next_win_beg_ns) << 31);
+      }
+      if (acc) out_of_range = 1;
+    });
+  else if (rate == 1 && !d_raw)
     parallel_ranges(n_packed_total, [&](int64_t a0, int64_t a1) {
       const uint16_t *__restrict xs = x, *__restrict ys = y;
       const int64_t *__restrict ts = t_ns;
@@ -118,7 +131,7 @@ int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   // (with sub-sampling only the sampled events were looked at: the reference reads nothing else either, but the ABI
   // promises that every event handed over is inside the sensor)
   if (!d_raw && (out_of_range.load() || rate != 1)) {
-    rc = check_events(c, n, x, y, t_ns);
+    rc = check_events(c, n, x, y, t_ns, aos);
     if (rc) return rc;
   }
   if (err_kind.load() == CMX_ERR_TIME_ORDER)
@@ -207,10 +220,24 @@ int cmx_backend_set_window(cmx_ctx *c, int64_t n, const uint16_t *x, const uint1
                            int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
                            double blur_sigma, int contrast_measure, const float *IG) {
   if (is_group(c))
-    return group_set_window(c, n, x, y, t_ns, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
+    return group_set_window(c, nullptr, n, x, y, t_ns, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
                             event_sample_rate, blur_sigma, contrast_measure, IG);
   return be_set_window_impl(c, n, x, y, t_ns, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed,
                             t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
+}
+
+int cmx_backend_set_window_aos(cmx_ctx *c, int64_t n, const void *events, const cmx_aos_layout *layout, int order, int K,
+                               const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                               int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG) {
+  if (!c || c->kind != KIND_BE) return fail(c, CMX_ERR_STATE, "not a back-end context");
+  EvAos aos;
+  const int rc = make_aos(c, n, events, layout, &aos);
+  if (rc) return rc;
+  if (is_group(c))
+    return group_set_window(c, &aos, n, nullptr, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns,
+                            event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG);
+  return be_set_window_impl(c, n, nullptr, nullptr, nullptr, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed,
+                            t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG, &aos);
 }
 
 // knot_i <- exp(drot_i) * knot_i for the non-fixed knots (CopyAndIncrementalUpdate, trajectory.cpp:240-263)

@@ -213,17 +213,31 @@ int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y
   if (n > 0 && (!x || !y || !t)) return fail(c, CMX_ERR_INVALID_ARG, "null event arrays");
   return CMX_OK;
 }
-int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t) {
-  int rc0 = check_event_args(c, n, x, y, t);
-  if (rc0) return rc0;
+int make_aos(cmx_ctx *c, int64_t n, const void *events, const cmx_aos_layout *layout, EvAos *out) {
+  if (n < 0 || n > kMaxEvents) return fail(c, CMX_ERR_INVALID_ARG, "bad event count %lld (limit %lld)", (long long)n, (long long)kMaxEvents);
+  if (!layout || (n > 0 && !events)) return fail(c, CMX_ERR_INVALID_ARG, "null event array / layout");
+  const size_t st = layout->stride;
+  if (st < 12 || layout->off_x + 2 > st || layout->off_y + 2 > st || layout->off_sec + 4 > st || layout->off_nsec + 4 > st)
+    return fail(c, CMX_ERR_INVALID_ARG, "record layout: fields outside the %zu-byte record", st);
+  out->base = static_cast<const unsigned char *>(events);
+  out->stride = st; out->ox = layout->off_x; out->oy = layout->off_y; out->os = layout->off_sec; out->on = layout->off_nsec;
+  return CMX_OK;
+}
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t, const EvAos *aos) {
+  if (!aos) {
+    int rc0 = check_event_args(c, n, x, y, t);
+    if (rc0) return rc0;
+  }
   const int W = c->W, H = c->H;
   std::atomic<int64_t> bad(-1);
+  auto X = [&](int64_t i) { return aos ? aos->X(i) : (unsigned)x[i]; };
+  auto Y = [&](int64_t i) { return aos ? aos->Y(i) : (unsigned)y[i]; };
   parallel_ranges(n, [&](int64_t a, int64_t b) {
     unsigned acc = 0;
-    for (int64_t i = a; i < b; i++) acc |= (unsigned)(x[i] >= W) | (unsigned)(y[i] >= H);
+    for (int64_t i = a; i < b; i++) acc |= (unsigned)(X(i) >= (unsigned)W) | (unsigned)(Y(i) >= (unsigned)H);
     if (acc)
       for (int64_t i = a; i < b; i++)
-        if (x[i] >= W || y[i] >= H) {
+        if (X(i) >= (unsigned)W || Y(i) >= (unsigned)H) {
           int64_t cur = bad.load();
           while ((cur < 0 || i < cur) && !bad.compare_exchange_weak(cur, i)) {}
           break;
@@ -231,7 +245,7 @@ int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, co
   });
   const int64_t i = bad.load();
   if (i >= 0)
-    return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, x[i], y[i], W, H);
+    return fail(c, CMX_ERR_EVENT_RANGE, "event %lld at (%u,%u) outside the %dx%d sensor", (long long)i, X(i), Y(i), W, H);
   return CMX_OK;
 }
 

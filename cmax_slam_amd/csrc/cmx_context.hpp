@@ -367,8 +367,23 @@ int setup_blur(cmx_ctx *c, double sigma);
 hipEvent_t get_event(cmx_ctx *c);
 void collect_spans(cmx_ctx *c);  // call after the stream has been synchronised
 int create_common(cmx_ctx **out, int kind, int device, int W, int H, const double *lut);
+// events as an array of records (cmx_aos_layout): the accessors the packing passes use when a hand-over comes from the *_aos entry points
+struct EvAos {
+  const unsigned char *base = nullptr;
+  size_t stride = 0, ox = 0, oy = 0, os = 0, on = 0;
+  inline unsigned X(int64_t i) const { uint16_t v; memcpy(&v, base + (size_t)i * stride + ox, 2); return v; }
+  inline unsigned Y(int64_t i) const { uint16_t v; memcpy(&v, base + (size_t)i * stride + oy, 2); return v; }
+  inline int64_t T(int64_t i) const {
+    uint32_t sec, nsec;
+    memcpy(&sec, base + (size_t)i * stride + os, 4);
+    memcpy(&nsec, base + (size_t)i * stride + on, 4);
+    return (int64_t)sec * 1000000000LL + (int64_t)nsec;
+  }
+  EvAos from(int64_t first) const { EvAos r = *this; r.base = base + (size_t)first * stride; return r; }
+};
+int make_aos(cmx_ctx *c, int64_t n, const void *events, const cmx_aos_layout *layout, EvAos *out);  // argument checks
 int check_event_args(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
-int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t);
+int check_events(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t, const EvAos *aos = nullptr);
 int ensure_pinned_xy(cmx_ctx *c, size_t n);
 int ensure_pinned_dts(cmx_ctx *c, size_t n);
 
@@ -450,7 +465,7 @@ int group_size(const cmx_ctx *c);
 int group_members(const cmx_ctx *c, cmx_ctx **out, int max);  // the member contexts in rank order (a plain context: itself); returns their number
 int group_all(cmx_ctx *leader, const std::function<int(cmx_ctx *, int)> &fn);  // fn(member, rank) on every member; first failure
 void group_destroy(cmx_ctx *leader);
-int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
+int group_set_window(cmx_ctx *leader, const EvAos *aos, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
                      const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
                      int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
 int group_eval(cmx_ctx *leader, const double *drotv, double *contrast, double *grad);
@@ -470,8 +485,8 @@ void comm_release(cmx_ctx *c);  // destroys an attached communicator (cmx_destro
 // (d_raw != nullptr: the events are already on the device -- event store)
 int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
                        const uint32_t *d_raw, int64_t t_ref_ns, double fx, double fy, double cx, double cy,
-                       int event_batch_size, double blur_sigma, int contrast_measure);
+                       int event_batch_size, double blur_sigma, int contrast_measure, const EvAos *aos = nullptr);
 int be_set_window_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
                        const uint32_t *d_raw, const int64_t *d_t, int order, int K, const double *knots_xyzw,
                        int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size,
-                       int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
+                       int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG, const EvAos *aos = nullptr);

@@ -64,8 +64,24 @@ int cmx_events_devices(const cmx_events *e, int *devices, int max_devices) {
 
 // append a chunk of the (time-ordered) stream: AngVelEstimator::pushEvent's events_.push_back (ang_vel_estimator.cpp:68-78).
 // One packing pass on the host into pinned staging, then one asynchronous upload per replica (the devices copy side by side).
+static int events_push_impl(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, const EvAos *aos);
 int cmx_events_push(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns) {
   if (!e || n < 0 || (n > 0 && (!x || !y || !t_ns))) return efail(e, CMX_ERR_INVALID_ARG, "bad arguments");
+  return events_push_impl(e, n, x, y, t_ns, nullptr);
+}
+// the same from the host's own records (dvs_msgs::Event, cmx_aos_layout): pushEvent's loop over msg->events
+// (ang_vel_estimator.cpp:68-78) as ONE call -- x | y << 16 and sec * 1e9 + nsec are formed in the packing pass
+int cmx_events_push_aos(cmx_events *e, int64_t n, const void *events, const cmx_aos_layout *layout) {
+  if (!e || n < 0 || !layout || (n > 0 && !events)) return efail(e, CMX_ERR_INVALID_ARG, "bad arguments");
+  const size_t st = layout->stride;
+  if (st < 12 || layout->off_x + 2 > st || layout->off_y + 2 > st || layout->off_sec + 4 > st || layout->off_nsec + 4 > st)
+    return efail(e, CMX_ERR_INVALID_ARG, "record layout: fields outside the record");
+  EvAos aos;
+  aos.base = static_cast<const unsigned char *>(events);
+  aos.stride = st; aos.ox = layout->off_x; aos.oy = layout->off_y; aos.os = layout->off_sec; aos.on = layout->off_nsec;
+  return events_push_impl(e, n, nullptr, nullptr, nullptr, &aos);
+}
+static int events_push_impl(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, const EvAos *aos) {
   if (e->size + (size_t)n > e->capacity) return efail(e, CMX_ERR_INVALID_ARG, "event store full: drop old events first");
   if (n == 0) return CMX_OK;
   if ((size_t)n > e->stage_cap) {
@@ -82,6 +98,18 @@ int cmx_events_push(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t 
   const unsigned W = (unsigned)e->W, H = (unsigned)e->H;
   uint32_t *xy = e->h_xy;
   int64_t *tp = e->h_tp;
+  if (aos)
+    parallel_ranges(n, [&](int64_t a0, int64_t a1) {
+      unsigned acc = 0;
+      for (int64_t i = a0; i < a1; i++) {
+        const unsigned ex = aos->X(i), ey = aos->Y(i);
+        acc |= (unsigned)(ex >= W) | (unsigned)(ey >= H);
+        xy[i] = ex | (ey << 16);
+        tp[i] = aos->T(i);
+      }
+      if (acc) bad = 1;
+    });
+  else
   parallel_ranges(n, [&](int64_t a0, int64_t a1) {
     unsigned acc = 0;
     for (int64_t i = a0; i < a1; i++) {
@@ -102,7 +130,7 @@ int cmx_events_push(cmx_events *e, int64_t n, const uint16_t *x, const uint16_t 
     if (hipSetDevice(r.device) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) return efail(e, CMX_ERR_HIP, "upload failed");
   }
   (void)hipSetDevice(e->device);
-  e->h_t.insert(e->h_t.end(), t_ns, t_ns + n);
+  e->h_t.insert(e->h_t.end(), tp, tp + n);  // (the packed timestamps: the AoS form has no t_ns[] of its own)
   e->size += (size_t)n;
   return CMX_OK;
 }

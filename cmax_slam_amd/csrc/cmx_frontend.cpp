@@ -17,7 +17,7 @@ int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *l
 // host mirror of the timestamps
 int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
                               const uint32_t *d_raw, int64_t t_ref_ns, double fx, double fy, double cx, double cy,
-                              int event_batch_size, double blur_sigma, int contrast_measure) {
+                              int event_batch_size, double blur_sigma, int contrast_measure, const EvAos *aos) {
   if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
   int rc = bind_device(c);
   if (rc) return rc;
@@ -27,7 +27,7 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
   if (event_batch_size <= 0) return fail(c, CMX_ERR_INVALID_ARG, "event_batch_size must be > 0");
   // computeContrast's switch (local_focus_funcs.cpp:98-109): 1 = mean square, 2 = gradient magnitude, default = variance
   if (contrast_measure != CMX_MEAN_SQUARE && contrast_measure != CMX_GRADIENT_MAGNITUDE) contrast_measure = CMX_VARIANCE;
-  if (!d_raw) {
+  if (!d_raw && !aos) {
     rc = check_event_args(c, n, x, y, t_ns);
     if (rc) return rc;
   } else if (n < 0 || n > kMaxEvents) {
@@ -49,6 +49,17 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     xy = c->h_xy;
     std::atomic<unsigned> out_of_range(0);
     const unsigned W = (unsigned)c->W, H = (unsigned)c->H;
+    if (aos)  // straight from the host's records (dvs_msgs::Event): the same words, no x[] / y[] vectors in between
+      parallel_ranges(n, [&](int64_t a, int64_t b) {
+        unsigned acc = 0;
+        for (int64_t i = a; i < b; i++) {
+          const unsigned ex = aos->X(i), ey = aos->Y(i);
+          acc |= (unsigned)(ex >= W) | (unsigned)(ey >= H);
+          xy[i] = ex | (ey << 16);
+        }
+        if (acc) out_of_range = 1;
+      });
+    else
     parallel_ranges(n, [&](int64_t a, int64_t b) {
       unsigned acc = 0;
       for (int64_t i = a; i < b; i++) {
@@ -57,7 +68,7 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
       }
       if (acc) out_of_range = 1;
     });
-    if (out_of_range.load()) return check_events(c, n, x, y, t_ns);  // locate and report the offender
+    if (out_of_range.load()) return check_events(c, n, x, y, t_ns, aos);  // locate and report the offender
   }
   rc = ensure_pinned_dts(c, (size_t)nb);
   if (rc) return rc;
@@ -68,8 +79,9 @@ int fe_set_packet_impl(cmx_ctx *c, int64_t n, const uint16_t *x, const uint16_t 
     for (int64_t b = b0; b < b1; b++) {
       const int64_t beg = b * event_batch_size;
       const int64_t end = (beg + event_batch_size < n) ? beg + event_batch_size : n;
-      if (t_ns[end - 1] < t_ns[beg]) { bad_batch = (int)b; return; }
-      dts[(size_t)b] = time_to_sec(time_batch_ns(t_ns[beg], t_ns[end - 1])) - tref;
+      const int64_t t_first = aos ? aos->T(beg) : t_ns[beg], t_last = aos ? aos->T(end - 1) : t_ns[end - 1];
+      if (t_last < t_first) { bad_batch = (int)b; return; }
+      dts[(size_t)b] = time_to_sec(time_batch_ns(t_first, t_last)) - tref;
     }
   }, /*serial_below=*/4096);
   if (bad_batch.load() >= 0) return fail(c, CMX_ERR_TIME_ORDER, "batch %d spans a negative time interval", bad_batch.load());
@@ -97,6 +109,16 @@ int cmx_frontend_set_packet(cmx_ctx *c, int64_t n, const uint16_t *x, const uint
                             int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
                             double blur_sigma, int contrast_measure) {
   return fe_set_packet_impl(c, n, x, y, t_ns, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma, contrast_measure);
+}
+
+int cmx_frontend_set_packet_aos(cmx_ctx *c, int64_t n, const void *events, const cmx_aos_layout *layout, int64_t t_ref_ns, double fx,
+                                double fy, double cx, double cy, int event_batch_size, double blur_sigma, int contrast_measure) {
+  if (!c || c->kind != KIND_FE) return fail(c, CMX_ERR_STATE, "not a front-end context");
+  EvAos aos;
+  const int rc = make_aos(c, n, events, layout, &aos);
+  if (rc) return rc;
+  return fe_set_packet_impl(c, n, nullptr, nullptr, nullptr, nullptr, t_ref_ns, fx, fy, cx, cy, event_batch_size, blur_sigma,
+                            contrast_measure, &aos);
 }
 
 // The adjoint image pass can ride inside the splat launch (FusedArgs, cmx_internal.hpp): gradient evaluations of the production

@@ -596,12 +596,12 @@ int cmx_backend_create_group(cmx_ctx **out, const int *devices, int n_devices, i
 }
 
 // ---- the group forms of the entry points (called from the C ABI functions when the handle is a group's)
-int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
+int group_set_window(cmx_ctx *leader, const EvAos *aos, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns, int order, int K,
                      const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
                      int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG) {
   cmx_group *g = leader->group;
   const int N = g->n;
-  const bool shardable = n > 0 && event_batch_size > 0 && x && y && t_ns;
+  const bool shardable = n > 0 && event_batch_size > 0 && ((x && y && t_ns) || aos);
   const int rc = group_all(leader, [&](cmx_ctx *m, int r) {
     int64_t beg = 0, end = (r == 0) ? n : 0;  // bad arguments: member 0 gets them as they are and reports the error
     if (shardable) {
@@ -613,6 +613,11 @@ int group_set_window(cmx_ctx *leader, int64_t n, const uint16_t *x, const uint16
       if (end > beg && end < n) end += 1;
     }
     const bool none = !shardable && r != 0;
+    if (aos) {  // the member's range of the host's records (cmx_backend_set_window_aos)
+      const EvAos mine = aos->from(none ? 0 : beg);
+      return be_set_window_impl(m, none ? 0 : end - beg, nullptr, nullptr, nullptr, nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns,
+                                num_fixed, t_next_win_beg_ns, event_batch_size, event_sample_rate, blur_sigma, contrast_measure, IG, &mine);
+    }
     return be_set_window_impl(m, none ? 0 : end - beg, none ? nullptr : x + beg, none ? nullptr : y + beg, none ? nullptr : t_ns + beg,
                               nullptr, nullptr, order, K, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size,
                               event_sample_rate, blur_sigma, contrast_measure, IG);

@@ -272,6 +272,12 @@ class EventStore:
         self._ck(self._L.cmx_events_push(self._h, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p),
                                          t.ctypes.data_as(c_i64p)))
 
+    def push_aos(self, events):
+        """cmx_events_push_aos: records with fields x, y, sec, nsec (msg->events as it lies in the host's memory)."""
+        ev = np.ascontiguousarray(events)
+        lay = _lib.aos_layout_of(ev)
+        self._ck(self._L.cmx_events_push_aos(self._h, len(ev), ev.ctypes.data_as(C.c_void_p), C.byref(lay)))
+
     def drop_before(self, global_index):
         self._ck(self._L.cmx_events_drop_before(self._h, int(global_index)))
 
@@ -315,6 +321,15 @@ class FrontendEvaluator(_Evaluator):
             int(t_ref_ns), float(fx), float(fy), float(cx), float(cy), int(event_batch_size), float(blur_sigma),
             int(contrast_measure)))
         self.n_events = len(x)
+
+    def set_packet_aos(self, events, t_ref_ns, fx, fy, cx, cy, event_batch_size=100, blur_sigma=1.0, contrast_measure=VARIANCE):
+        """cmx_frontend_set_packet_aos: `events` = structured array of records with fields x, y, sec, nsec (e.g. _lib.DVS_EVENT_DTYPE)."""
+        ev = np.ascontiguousarray(events)
+        lay = _lib.aos_layout_of(ev)
+        self._ck(self._L.cmx_frontend_set_packet_aos(self._ctx, len(ev), ev.ctypes.data_as(C.c_void_p), C.byref(lay), int(t_ref_ns),
+                                                     float(fx), float(fy), float(cx), float(cy), int(event_batch_size),
+                                                     float(blur_sigma), int(contrast_measure)))
+        self.n_events = len(ev)
 
     def set_packet_from(self, store, first, count, t_ref_ns, fx, fy, cx, cy, event_batch_size=100, blur_sigma=1.0,
                         contrast_measure=VARIANCE):
@@ -446,6 +461,20 @@ class BackendEvaluator(_Evaluator):
             self._ctx, len(x), x.ctypes.data_as(c_u16p), y.ctypes.data_as(c_u16p), t.ctypes.data_as(c_i64p),
             int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns), int(num_fixed), int(t_next_win_beg_ns),
             int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
+            C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
+        self.K, self.num_fixed, self._order = k.shape[0], int(num_fixed), int(order)
+
+    def set_window_aos(self, events, order, knots_xyzw, start_ns, dt_ns, num_fixed, t_next_win_beg_ns, event_batch_size=100,
+                       event_sample_rate=1, blur_sigma=1.0, contrast_measure=VARIANCE, IG=None):
+        """cmx_backend_set_window_aos: `events` = structured array of records with fields x, y, sec, nsec."""
+        ev = np.ascontiguousarray(events)
+        lay = _lib.aos_layout_of(ev)
+        k = _c(knots_xyzw, np.float64).reshape(-1, 4)
+        keep = isinstance(IG, str) and IG == "resident"
+        ig = _c(IG, np.float32) if (IG is not None and not keep) else None
+        self._ck(self._L.cmx_backend_set_window_aos(
+            self._ctx, len(ev), ev.ctypes.data_as(C.c_void_p), C.byref(lay), int(order), k.shape[0], _dp(k), int(start_ns), int(dt_ns),
+            int(num_fixed), int(t_next_win_beg_ns), int(event_batch_size), int(event_sample_rate), float(blur_sigma), int(contrast_measure),
             C.cast(C.c_void_p(1), c_fp) if keep else (ig.ctypes.data_as(c_fp) if ig is not None else None)))
         self.K, self.num_fixed, self._order = k.shape[0], int(num_fixed), int(order)
 

@@ -119,6 +119,18 @@ int cmx_set_sched_class(cmx_ctx *ctx, int sched_class);
  * (src/cmax_slam.cpp:106-120); copied to the device once. */
 int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *lut);
 
+/* ------------------------------------------------------------------ events as the host holds them (AoS) ------
+ * The reference keeps its events as std::vector<dvs_msgs::Event> (src/frontend/ang_vel_estimator.cpp:68-147: pushEvent / the
+ * per-packet copy into event_subset_; src/backend/pose_graph_optimizer.cpp:131-165: getEventSubset) -- an array of
+ *   struct { uint16_t x, y; struct { uint32_t sec, nsec; } ts; uint8_t polarity; }        (16 bytes)
+ * The *_aos entry points take that memory as it is: ONE packing pass on the host pool straight from the array into the pinned
+ * upload buffer (x | y << 16 [| old << 31]; t_ns = sec * 1e9 + nsec formed on the fly for the batch times / the store's
+ * timestamps), no intermediate x[] / y[] / t_ns[] vectors.  `layout` describes any array of records: record size and the byte
+ * offsets of the four fields (uint16 x, uint16 y, uint32 sec, uint32 nsec); CMX_AOS_DVS_EVENT is dvs_msgs::Event's.  Same
+ * checks, same errors, bit-identical device contents as the SoA entry points given the same events. */
+typedef struct { size_t stride, off_x, off_y, off_sec, off_nsec; } cmx_aos_layout;
+#define CMX_AOS_DVS_EVENT {16, 0, 2, 4, 8}
+
 /* State AngVelEstimator hands over before a solve (src/frontend/ang_vel_estimator.cpp:137-147):
  * event_subset_ (SoA here; polarity is never read), time_packet_, camera_matrix_ (fx,fy,cx,cy),
  * warp_opt.{event_batch_size, blur_sigma}, process_opt.contrast_measure.  Uploads once; every
@@ -126,6 +138,9 @@ int cmx_frontend_create(cmx_ctx **out, int device, int W, int H, const double *l
 int cmx_frontend_set_packet(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns,
                             int64_t t_ref_ns, double fx, double fy, double cx, double cy, int event_batch_size,
                             double blur_sigma, int contrast_measure);
+int cmx_frontend_set_packet_aos(cmx_ctx *ctx, int64_t n, const void *events, const cmx_aos_layout *layout, int64_t t_ref_ns,
+                                double fx, double fy, double cx, double cy, int event_batch_size, double blur_sigma,
+                                int contrast_measure);
 
 /* Packet pipeline (no reference counterpart: the CPU path has no set-up to hide).  Queues everything the packet's first
  * evaluation would otherwise do before its first vote -- destination-tile sort at omega_hint, tile-ordered bearing / dt
@@ -185,6 +200,9 @@ int cmx_backend_set_window(cmx_ctx *ctx, int64_t n, const uint16_t *x, const uin
                            int order, int K, const double *knots_xyzw, int64_t start_ns, int64_t dt_ns,
                            int num_fixed, int64_t t_next_win_beg_ns, int event_batch_size, int event_sample_rate,
                            double blur_sigma, int contrast_measure, const float *IG);
+int cmx_backend_set_window_aos(cmx_ctx *ctx, int64_t n, const void *events, const cmx_aos_layout *layout, int order, int K,
+                               const double *knots_xyzw, int64_t start_ns, int64_t dt_ns, int num_fixed, int64_t t_next_win_beg_ns,
+                               int event_batch_size, int event_sample_rate, double blur_sigma, int contrast_measure, const float *IG);
 
 /* Window pipeline: the back end's counterpart of cmx_frontend_prepare -- pose table at drotv_hint (NULL = zero increments),
  * destination-tile sort, chunk table and bearing streams of the window handed over last, queued without waiting. */
@@ -251,6 +269,7 @@ int cmx_events_devices(const cmx_events *ev, int *devices, int max_devices);
 void cmx_events_destroy(cmx_events *ev);
 const char *cmx_events_last_error(const cmx_events *ev);
 int cmx_events_push(cmx_events *ev, int64_t n, const uint16_t *x, const uint16_t *y, const int64_t *t_ns);
+int cmx_events_push_aos(cmx_events *ev, int64_t n, const void *events, const cmx_aos_layout *layout); /* e.g. msg->events.data() */
 int cmx_events_drop_before(cmx_events *ev, int64_t global_index);
 int64_t cmx_events_begin(const cmx_events *ev); /* global index of the oldest event held */
 int64_t cmx_events_end(const cmx_events *ev);   /* one past the newest */
@@ -470,7 +489,8 @@ int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_sta
  *  5: cmx_comm_info; the event store behind a group (cmx_events_create_group, cmx_backend_set_window_from on a group);
  *     CMX_OPT_SPIN_WAIT values >= 2 are a spin budget in microseconds for all three waiters (before: "spin"), negative values are
  *     rejected (before: accepted as non-zero);
- *  6: named cmx_get_stats indices, two more of them) */
+ *  6: named cmx_get_stats indices, three more of them; cmx_group_transport_info; the *_aos entry points; cmx_set_stream_priority /
+ *     cmx_set_cu_mask moved to cmax_hip_diag.h) */
 #define CMX_ABI_VERSION 6
 int cmx_abi_version(void);
 int cmx_timing_enable(cmx_ctx *ctx, int on);
