@@ -472,6 +472,59 @@ def _slabs(make, n, per_gpu):
         return list(ex.map(lambda r: make(r, n, per_gpu), range(n)))
 
 
+def scaling_series(devices, per_gpu, pts, steps, mode, headline=None):
+    """ONE invocation, the whole weak-scaling series: config 4's window of k x per_gpu events through a group over
+    devices[:k] for k = 1, 2, 4, ... < N (k = 1: a plain context), timed like the headline (K dependent fdf evaluations by one native
+    call), with the exchange's share (HIP events around the collectives of a short sampled pass) and parity against the same window on
+    ONE context.  The k = N row is the headline's own measurement.  On a one-GPU box `--group-devices 0,0,0,0` runs it dry (members
+    share the device: the numbers say nothing about scaling, the code path is the multi-GPU one)."""
+    from cmax_slam_amd import _lib, evaluator, synth
+    N = len(devices)
+    rows = []
+    for k in [q for q in (1, 2, 4, 8, 16) if q < N]:
+        row = {"n": k, "devices": devices[:k]}
+        try:
+            w = synth.concat_slabs(_slabs(synth.config4_slab, k, per_gpu))
+            args_w = (w.x, w.y, w.t_ns, w.order, w.knots_init, w.start_ns, w.dt_ns, w.num_fixed, w.t_next_win_beg_ns, w.batch,
+                      w.sample_rate, w.sigma, _lib.VARIANCE, getattr(w, "IG", None))
+            ev = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=devices[0], devices=devices[:k] if k > 1 else None)
+            ev.set_window(*args_w)
+            (ev.set_fast_path if mode == "fast" else ev.set_reference_path)()
+            ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
+            xs = np.vstack([pts[i % len(pts)] for i in range(max(steps, 8))])
+            t_end = time.perf_counter() + SETTLE_S
+            while time.perf_counter() < t_end:
+                ev.eval_each(xs[:8], True)
+            t0 = time.perf_counter()
+            cs, gs = ev.eval_each(xs, True)
+            el = time.perf_counter() - t0
+            row["fdf_ms"] = el / len(xs) * 1e3
+            row["events_per_s_per_gpu"] = len(w.x) * len(xs) / el / k
+            if k > 1:
+                ev.timing_enable(["comm"])
+                ev.timing_get()
+                ev.eval_each(xs[:16], True)
+                tim = ev.timing_get()
+                ev.timing_enable(False)
+                row["comm_ms"] = (tim["comm"][0] / 16) if tim.get("comm", (0, 0))[1] else None
+                one = evaluator.BackendEvaluator(w.W, w.H, w.lut, w.Wp, w.Hp, device=devices[0])
+                one.set_window(*args_w)
+                (one.set_fast_path if mode == "fast" else one.set_reference_path)()
+                c1, g1 = one.eval(xs[-1], True)
+                one.close()
+                row["parity_vs_1gpu"] = {"contrast_rel": abs(float(cs[-1]) - c1) / abs(c1),
+                                         "grad_rel_inf": float(np.abs(gs[-1] - g1).max() / np.abs(g1).max())}
+            else:
+                row["comm_ms"] = 0.0
+            ev.close()
+        except Exception as e:
+            row["error"] = repr(e)
+        rows.append(row)
+    if headline is not None:
+        rows.append(headline)
+    return rows
+
+
 def one_gpu_same_workload(device, which, n_slabs, per_gpu, pts, steps, mode):
     """Weak-scaling reference for the N > 1 lines: slab 0 of the SAME window (per_gpu events, the same spline, map and options) on ONE plain
     context -- the per-GPU work of the sharded run without a partner.  value(N) / (N x this) is the efficiency a reader wants;
@@ -1294,6 +1347,12 @@ def summary_of(out):
         ai = out["aos_ingest"]
         s["aos_ingest_1M"] = {"push_aos_ms": round(ai["store_push_aos_ms"], 3), "convert_plus_push_soa_ms": round(ai["aos_to_soa_conversion_ms"] + ai["store_push_soa_ms"], 3),
                               "events_per_s": ai["store_push_aos_events_per_s"]}
+    if isinstance(out.get("scaling_series"), list):  # the whole series of ONE invocation: n, events/s/GPU, exchange ms, parity
+        def _par(r):
+            pv = r.get("parity_vs_1gpu") or {}
+            return None if not pv else max(pv.get("contrast_rel") or 0.0, pv.get("grad_rel_inf") or 0.0)
+        s["scaling_series"] = [{"n": r.get("n"), "events_per_s_per_gpu": r.get("events_per_s_per_gpu"), "comm_ms": r.get("comm_ms"),
+                                "parity_vs_1gpu": _par(r), **({"error": r["error"][:60]} if "error" in r else {})} for r in out["scaling_series"]]
     if isinstance(out.get("comm"), dict):
         s["comm"] = {k: out["comm"].get(k) for k in ("nranks_seen", "transport", "ms_per_step", "share_of_step", "collectives_per_step",
                                                      "bytes_last_evaluation")}
@@ -1691,6 +1750,14 @@ def main():
                     out["config5"] = {"error": str(e)}
     if sharded and group_devices is None:
         dist.destroy_process_group()  # (every rank arrives here together; what follows is rank 0's own work)
+    if family != "frontend" and group_devices and len(group_devices) > 1 and rank == 0 and not args.no_extras and which == "config4":
+        try:
+            head = {"n": len(group_devices), "devices": list(group_devices), "fdf_ms": out.get("ms_per_step"),
+                    "events_per_s_per_gpu": (out.get("value") or 0.0) / len(group_devices),
+                    "comm_ms": (out.get("comm") or {}).get("ms_per_step"), "parity_vs_1gpu": out.get("parity_vs_1gpu")}
+            out["scaling_series"] = scaling_series(list(group_devices), per_gpu, pts, args.steps, args.mode, head)
+        except Exception as e:
+            out["scaling_series"] = {"error": repr(e)}
     if family != "frontend" and sharded and rank == 0 and not args.no_extras:
         n_slabs = len(group_devices) if group_devices else world
         try:

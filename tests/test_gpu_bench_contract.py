@@ -90,6 +90,24 @@ def test_single_process_group_line(tmp_path):
     assert s["one_gpu_same_workload_events_per_s"] > 0
 
 
+def test_scaling_series_in_one_invocation_dry_run(tmp_path):
+    """ONE invocation prints the whole weak-scaling series.  Dry run on this box's one GPU: four members sharing
+    device 0 -> rows for groups of 1, 2 and 4 members on windows of 1x, 2x, 4x the per-GPU events, each with events/s per GPU, the
+    exchange's share and parity against the same window on one context -- inside the < 4 KB line."""
+    line, d = _run(tmp_path, "--gpus", "4", "--group-devices", "0,0,0,0", "--steps", "12", "--warmup", "2", "--events", "200000",
+                   "--no-cpu-baseline", "--solves", "0")
+    _check_line(line, 1, 12, 2)
+    ser = line["summary"]["scaling_series"]
+    assert [r["n"] for r in ser] == [1, 2, 4], ser
+    for r in ser:
+        assert "error" not in r and r["events_per_s_per_gpu"] > 0, r
+        if r["n"] > 1:
+            assert r["comm_ms"] is not None and r["comm_ms"] > 0 and r["parity_vs_1gpu"] < 1e-5, r
+    assert ser[0]["comm_ms"] == 0.0 and ser[0]["parity_vs_1gpu"] is None
+    full = d["scaling_series"]
+    assert full[1]["devices"] == [0, 0] and full[2]["devices"] == [0, 0, 0, 0] and full[2]["parity_vs_1gpu"]["grad_rel_inf"] < 1e-5
+
+
 def test_gpus_2_as_typed_on_a_one_gpu_box(tmp_path):
     """`python3 bench.py --gpus 2` with no launcher and ONE visible device: config 4's slab runs on what is there, n_gpus = 1, an
     error field says why, exit status 0 (the driver's scaling leg must never be an rc-1 record with no line)."""
