@@ -369,16 +369,32 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     # pipe at the fp64 issue rate; the HBM figure stays beside it (hbm_frac, hbm_achieved).
     valu = pmc.get("%s_%s_valu_insts" % (pmc_prefix, dom))
     if kind == "backend" and valu:
-        t_lane = valu * 64 / (dms * 1e-3) / 1e12
+        # Round 6: priced per instruction CLASS.  tools/microbench/valu_rates.hip (profiles/r06_valu_rates.txt): every class issues one
+        # wave-instruction per 4 clocks per SIMD on gfx950 -- fp64 FMA / ADD / MUL, fp32, integer, conversions alike -- except the
+        # transcendental classes: TRANS_F32 8 clocks, TRANS_F64 16.  So the launch's issue-slot count is SQ_INSTS_VALU plus one extra
+        # slot per TRANS_F32 and three per TRANS_F64 (the rocprofv3 --pmc SQ_INSTS_VALU_* passes of this build).
+        mix = pmc.get("%s_%s_valu_mix" % (pmc_prefix, dom)) or {}
+        slots = valu + 1.0 * mix.get("trans_f32", 0.0) + 3.0 * mix.get("trans_f64", 0.0)
+        t_lane = slots * 64 / (dms * 1e-3) / 1e12
         act = pmc.get("%s_%s_valu_active_x4clk" % (pmc_prefix, dom))
+        per_ev = 64.0 / max(n_local, 1)
+        f64 = sum(mix.get(k, 0.0) for k in ("add_f64", "mul_f64", "fma_f64", "trans_f64"))
+        f32 = sum(mix.get(k, 0.0) for k in ("add_f32", "mul_f32", "fma_f32", "trans_f32"))
+        if mix:
+            roofline["valu_mix_per_event"] = {"fp64": f64 * per_ev, "fp32": f32 * per_ev, "int32": mix.get("int32", 0.0) * per_ev,
+                                              "int64": mix.get("int64", 0.0) * per_ev, "cvt": mix.get("cvt", 0.0) * per_ev,
+                                              "trans_f64": mix.get("trans_f64", 0.0) * per_ev, "trans_f32": mix.get("trans_f32", 0.0) * per_ev,
+                                              "other (moves, selects, compares)": max(0.0, valu - f64 - f32 - mix.get("int32", 0.0) - mix.get("int64", 0.0)
+                                                                                      - mix.get("cvt", 0.0)) * per_ev,
+                                              "issue_slots": slots * per_ev}
         roofline.update({"bound": "valu_fp64", "achieved": t_lane, "peak": VALU_FP64_PEAK_TLANE, "unit": "Tinstr/s",
                          "frac": t_lane / VALU_FP64_PEAK_TLANE, "hbm_frac": achieved / HBM_PEAK_GBS, "hbm_achieved_gbs": achieved,
                          "valu_insts_per_launch": valu, "valu_insts_per_event": valu * 64 / max(n_local, 1),
                          # the pipe's own busy counter: clocks with a VALU instruction issuing, per SIMD, over the launch's clocks
                          "valu_busy_frac": (act * 4 / 1024 / (dms * 1e-3 * 2.4e9)) if act else None,
-                         "model": "wave-level VALU instructions per launch (SQ_INSTS_VALU) x 64 lanes / live kernel duration, against the fp64 "
-                                  "vector issue rate (one wave instruction per 4 clocks per SIMD: 39.3 T lane-instructions/s); hbm_frac = the "
-                                  "HBM-mandatory bytes of the same launch / duration / 8 TB/s"})
+                         "model": "VALU issue slots per launch (SQ_INSTS_VALU + 1 x TRANS_F32 + 3 x TRANS_F64: every class issues in 4 clocks per SIMD on "
+                                  "gfx950 except the transcendentals, profiles/r06_valu_rates.txt) x 64 lanes / live kernel duration, against one slot per "
+                                  "4 clocks per SIMD (39.3 T lane-slots/s); hbm_frac = the HBM-mandatory bytes of the same launch / duration / 8 TB/s"})
     out = {
         "ms_per_step": ms_step,
         "value": n_total * steps / elapsed,

@@ -62,7 +62,7 @@ NAMES = {
 def main(path):
     vals = {}
     for line in open(path):
-        m = re.match(r"(.{58})\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|SQ_ACTIVE_INST_LDS|SQ_BUSY_CYCLES|SQ_WAVES|SQ_WAVE_CYCLES)\s+([\d.]+)", line)
+        m = re.match(r"(.{58})\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU_[A-Z0-9_]+|SQ_INSTS_VALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|SQ_ACTIVE_INST_LDS|SQ_BUSY_CYCLES|SQ_WAVES|SQ_WAVE_CYCLES)\s+([\d.]+)", line)
         if not m:
             continue
         vals.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
@@ -101,6 +101,10 @@ def main(path):
                                      ("SQ_WAVE_CYCLES", "wave_cycles_x4clk")):
                     if cname in d:
                         row[oname] = d[cname]
+                mix = {c[len("SQ_INSTS_VALU_"):].lower(): v for c, v in d.items() if c.startswith("SQ_INSTS_VALU_")}
+                if mix:  # wave-level instructions per class (separate PMC passes of the same command)
+                    row["valu_mix"] = mix
+                    out[key + "_valu_mix"] = mix
                 out["kernels"][key] = row
                 out[key] = cor
                 if "valu_insts" in row:
