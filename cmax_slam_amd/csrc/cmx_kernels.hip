@@ -1952,10 +1952,29 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
   const BeSplatArgs &a = g.ev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
+#ifdef CMX_BE_GATHER_LDS_POSE
+  // EXPERIMENT (measured, rejected: profiles/r06_be_lds_pose.txt): the rotations of the batches a wave pass meets
+  // (<= kPoseRuns) fetched ONE PASS AHEAD into a per-wave LDS slot by 9 x kPoseRuns lanes -- one 72-byte load per batch run instead of
+  // one per lane, off the pass's critical path, no registers held across the warp -- and read back from LDS by every lane.
+  constexpr int kPoseRuns = 4;  // 256 events of a pass span at most 256 / per_batch + 2 batches; the launcher's per_batch >= 100
+  __shared__ double shR[2][4][kPoseRuns * 9];
+  auto load_pose = [&](int base_next) -> double {  // (the value stays in ONE register pair across the pass: the LDS write comes at its end)
+    if (lane < kPoseRuns * 9 && base_next < a.n) {
+      const int b = min(base_next / a.per_batch + lane / 9, (a.n - 1) / a.per_batch);
+      return a.poseR[b].R[lane % 9];
+    }
+    return 0.0;
+  };
+  int pslot = 0;
+  if (lane < kPoseRuns * 9) shR[0][wave][lane] = load_pose((blockIdx.x * 4 + wave) * 256);
+#endif
   for (int base = (blockIdx.x * 4 + wave) * 256; base < a.n; base += nwaves * 256) {
     const int i0 = base + lane * 4;
     double V0 = 0, V1 = 0, V2 = 0, U0 = 0, U1 = 0, U2 = 0;
     int batch = -1;
+#ifdef CMX_BE_GATHER_LDS_POSE
+    const double rnext = load_pose(base + nwaves * 256);  // the NEXT pass's rotations: in flight while this pass warps
+#endif
     if (i0 < a.n) {
       batch = i0 / a.per_batch;
       uint32_t e[4];
@@ -1967,8 +1986,16 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
         for (int u = 0; u < 4; u++) e[u] = (i0 + u < a.n) ? a.xy[i0 + u] : 0u;
       }
       double R[9];
+#ifdef CMX_BE_GATHER_LDS_POSE
+      {
+        const double *Rl = shR[pslot][wave] + (batch - base / a.per_batch) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = Rl[k];
+      }
+#else
 #pragma unroll
       for (int k = 0; k < 9; k++) R[k] = a.poseR[batch].R[k];
+#endif
       double rx[4], ry[4], rz[4];  // e_ray_w = R * bearing of the lane's four events
       if (g.tb && i0 + 3 < a.n) {  // 64 contiguous bytes per lane from the time-ordered bearing stream: (x, y), z = 1
 #pragma unroll
@@ -2006,6 +2033,10 @@ __global__ __launch_bounds__(256) void be_gather4_kernel(BeGatherArgs g) {
         }
       }
     }
+#ifdef CMX_BE_GATHER_LDS_POSE
+    pslot ^= 1;
+    if (lane < kPoseRuns * 9) shR[pslot][wave][lane] = rnext;
+#endif
     const bool any_u = __any(U0 != 0.0 || U1 != 0.0 || U2 != 0.0);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
