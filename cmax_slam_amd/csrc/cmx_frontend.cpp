@@ -121,6 +121,14 @@ int cmx_frontend_set_packet_aos(cmx_ctx *c, int64_t n, const void *events, const
                             contrast_measure, &aos);
 }
 
+// CMX_FUSE_TRACE (diagnostics): looked up during the first few hundred evaluations of the process only (tools/fuse_trace.py sets it after its warm-up)
+static const char *fuse_trace_path() {
+  static const char *path = nullptr;
+  static int looks = 0;
+  if (!path && looks < 1024) { looks++; path = getenv("CMX_FUSE_TRACE"); }
+  return path;
+}
+
 // The adjoint image pass can ride inside the splat launch (FusedArgs, cmx_internal.hpp): gradient evaluations of the production
 // path at the reference's blur (sigma 1 -> radius 4, register-resident operator rows), context-owned ping-pong planes, nothing
 // between splat and blur (no communicator), no bitwise-reproducibility promise to keep.
@@ -221,8 +229,11 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
           c->fused_full_done = true;
           c->fused_full_evals++;
         }
-        if (const char *dbg = getenv("CMX_FUSE_DEBUG")) f.debug = atoi(dbg);
-        if (getenv("CMX_FUSE_TRACE")) {  // diagnostics: per-workgroup wall-clock stamps of this launch (tools/fuse_trace.py)
+        // (diagnostics, read once per process -- a getenv per evaluation is ~0.1 us of the host's turn-around; tools/fuse_trace.py sets
+        //  its variables before the library is loaded or re-reads through CMX_FUSE_TRACE's presence at first use)
+        static const char *const env_dbg = getenv("CMX_FUSE_DEBUG");
+        if (env_dbg) f.debug = atoi(env_dbg);
+        if (fuse_trace_path()) {  // diagnostics: per-workgroup wall-clock stamps of this launch (tools/fuse_trace.py)
           const size_t nwg = (size_t)b.nchunks + (size_t)f.tiles_x * f.tiles_y * kFuseStrips + (size_t)f.gather_blocks;
           rc = ensure(c, c->d_fuse_trace, c->fuse_trace_cap, 8 * nwg);
           if (rc) return rc;
@@ -311,7 +322,7 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
       for (int attempt = 0;; attempt++) {
         rc = sync_and_collect(c, true);
         if (rc) return rc;
-        if (const char *path = getenv("CMX_FUSE_TRACE")) {
+        if (const char *path = fuse_trace_path()) {
           if (c->d_fuse_trace && c->fuse_trace_n) {
             std::vector<unsigned long long> h(8 * c->fuse_trace_n);
             HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -30,7 +30,7 @@ def main():
         x0 = float(sys.argv[2]) * np.array(p.omega_true, dtype=float)
     for _ in range(30):
         ev.eval(x0 + 1e-4 * np.random.randn(3), True)
-    os.environ["CMX_FUSE_TRACE"] = path
+    os.environ["CMX_FUSE_TRACE"] = path  # (the library looks the variable up during its first few hundred evaluations only)
     for rep in range(2):
         ev.eval(x0 + 1e-4 * np.random.randn(3), True)
         t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
