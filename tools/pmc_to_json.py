@@ -51,7 +51,8 @@ def so_hash():
 STREAM_BYTES = {"frontend_fast_splat": 24e6, "frontend_fast_gather": 24e6, "backend_fast_splat": 120e6, "backend_fast_gather": 100e6}
 
 NAMES = {
-    "fe_splat_lds_kernel": "frontend_fast_splat",
+    "fe_splat_lds_kernel<false, true, 1>": "frontend_fast_splat",  # round 6: the splat launch that carries the image pass (the timed fdf evaluations);
+                                                                     # <.., 0> is the plain splat of cost-only evaluations
     "fe_gather_kernel<0>": "frontend_fast_gather",  # the evaluations bench.py times (<1>, <2>: the device-driven solves, incl. gated-off launches)
     "image_adjoint_kernel<4, 64, 16, 1024, false>": None,  # shared by both ends in one run: split by call order is not possible
     "be_splat_lds_kernel": "backend_fast_splat", "be_gather4_kernel": "backend_fast_gather",
