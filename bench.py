@@ -268,8 +268,11 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     nsample = max(2 * npts, 24)
     ev.timing_enable([dom])
     ev.timing_get()
-    for i in range(nsample):
-        run.step(points[i % npts], True)
+    if native_loop:  # the same native loop as the region: a Python loop leaves gaps between the evaluations in which the device clocks
+        ev.eval_each(np.vstack([points[i % npts] for i in range(nsample)]), True)  # down (sampled durations read 15-20 % long)
+    else:
+        for i in range(nsample):
+            run.step(points[i % npts], True)
     run.fence()
     tim = ev.timing_get()
     ev.timing_enable(False)
@@ -1353,7 +1356,7 @@ def summary_of(out):
                                                "set_window_ms_store": g(out["group"], "per_window", "device_store", "set_window_ms"),
                                                "set_window_ms_host": g(out["group"], "per_window", "host_arrays", "set_window_ms")}
         else:
-            s["group"] = {k: out["group"].get(k) for k in ("members", "devices", "transport", "last_fanout_us")}
+            s["group"] = {k: out["group"].get(k) for k in ("members", "devices", "transport", "last_fanout_us", "transport_info")}
     if isinstance(out.get("per_window"), dict):
         s["per_window_ratio_to_solve"] = {"store_seq": g(out, "per_window", "device_store", "sequential", "ratio_to_solve"),
                                           "host_seq": g(out, "per_window", "host_arrays", "sequential", "ratio_to_solve"),
@@ -1732,6 +1735,10 @@ def main():
                     out["comm"]["error"] = repr(e)
             if group_devices:
                 out["group"] = ev.group_info()
+                try:  # how the transport was picked (CMX_GROUP_AUTO: measured at creation) and both candidates' timings
+                    out["group"]["transport_info"] = ev.group_transport_info()
+                except Exception as e:
+                    out["group"]["transport_info"] = {"error": repr(e)}
                 out["config"]["form"] = "one process, group handle over devices %s" % group_devices
                 if len(group_devices) > 1 and not args.no_extras:
                     try:

@@ -399,7 +399,8 @@ static int set_option_one(cmx_ctx *c, int key, int value) {
       c->spin_idle_us = value == 1 ? 50 : value;  // threads with nothing on the device give their core back after 50 us by default
       return CMX_OK;
     case CMX_OPT_TAIL_FINALIZE:
-      c->tail_finalize = value < 0 ? 0 : (value > 2 ? 2 : value);
+      c->tail_poll = value == 3;  // 3: the tail as 1, with the polling form on the front-end gather (A/B: measured, no gain)
+      c->tail_finalize = value == 3 ? 1 : (value < 0 ? 0 : (value > 2 ? 2 : value));
       return CMX_OK;
     case CMX_OPT_GATED_DF:
       c->gated_df = value != 0;

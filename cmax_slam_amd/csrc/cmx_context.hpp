@@ -259,6 +259,7 @@ struct cmx_ctx {
   double *chain_block_a = nullptr, *chain_block_g = nullptr;  // device pointers of the blocks of the slot being queued
   int64_t chain_solves = 0, chain_slots = 0, chain_takeovers = 0, chain_warm_starts = 0;
   int tail_finalize = 1;              // CMX_OPT_TAIL_FINALIZE: 0 off, 1 on (back end: cost-only evaluations), 2 on everywhere
+  bool tail_poll = false;             // ... 3: as 1 with the POLLING tail on the front-end gather (measured: no gain, profiles/r06_tail_poll.txt)
   unsigned *d_tail_counters = nullptr;  // kTailCounterWords words, all-zero between launches
   double *d_gacc = nullptr;             // kTailShards x kGaccStride gradient accumulators of the tail finalize, all-zero between launches
 

@@ -160,6 +160,9 @@ constexpr int kGaccStride = 2 * 3 * kMaxKnots + 2;  // doubles per accumulator r
 struct TailArgs {
   unsigned *counters;  // all-zero between launches (the last arrivers reset what they completed); null = no tail finalize
   FinalizeArgs fin;
+  int poll;            // 1 (front-end plain gather, round 6): workgroup 0 finalizes once every other workgroup has ARRIVED -- fire-and-forget
+                       // arrival atomics on counters[0], one polling lane -- instead of the last arriver found through two levels of
+                       // returning ticket atomics (two dependent memory trips less at the end of every gradient evaluation)
 };
 
 struct ImgArgs {

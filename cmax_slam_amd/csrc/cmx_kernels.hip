@@ -1864,6 +1864,43 @@ __global__ __launch_bounds__(kFeGatherNT) void fe_gather_kernel(FeGatherArgs g) 
     } else if (tail) st_sc1(g.gpartials + (size_t)k * gridDim.x + blockIdx.x, v);  // write-through: read by the last arriver
     else g.gpartials[(size_t)k * gridDim.x + blockIdx.x] = v;
   }
+  if (CHAIN == 0 && tail && g.tail.poll) {
+    // Polling tail: the sums above are on their way as agent-scope atomics; drain them, then everybody but workgroup 0 ARRIVES
+    // (one fire-and-forget atomic) and leaves.  Workgroup 0 -- dispatched first, long done with its own slice -- polls the count with
+    // one lane and finalizes.  It waits for workgroups that wait for nobody; the wait is bounded all the same (1 s: only a dead device
+    // gets there; the result then carries kFuseIncomplete in its fallback word).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (the arrivals are sharded over the kTailShards + 1 counter lines: ~1000 atomics on ONE memory-side address serialise at ~12 ns
+    //  each -- the single-counter form of this tail took the launch from 13.9 to 21.6 us)
+    constexpr int kLines = kTailShards + 1;
+    if (blockIdx.x != 0) {
+      if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(g.tail.counters + (blockIdx.x % kLines) * kTailStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (threadIdx.x < 64) {  // wave 0: lane q < kLines polls line q
+      const unsigned want = gridDim.x - 1u;
+      const unsigned long long t0 = wall_clock64();
+      const int q = threadIdx.x;
+      for (;;) {
+        unsigned v = q < kLines ? __hip_atomic_load(g.tail.counters + q * kTailStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);  // (lanes 0..15 hold the sum of the lines)
+        const unsigned total = __shfl(v, 0, 64);
+        if (total >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 100000000ull) {
+          if (q == 0 && g.tail.fin.fallback) atomicOr(g.tail.fin.fallback, kFuseIncomplete);
+          break;
+        }
+      }
+      if (q < kLines) __hip_atomic_store(g.tail.counters + q * kTailStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    finalize_body<kFeGatherNT, false>(g.tail.fin, fin_sm);
+    return;
+  }
   if (tail && tail_arrive(g.tail, (int)gridDim.x, (int)blockIdx.x, fin_sm)) finalize_body<kFeGatherNT, CHAIN != 0>(g.tail.fin, fin_sm);
 }
 

@@ -308,6 +308,9 @@ bool arm_tail(cmx_ctx *c, FinalizeArgs &f, TailArgs &tail, bool gated) {
   }
   tail.counters = c->d_tail_counters;
   tail.fin = f;
+  // CMX_OPT_TAIL_FINALIZE 3 (A/B, measured without gain): front-end gradient evaluations through accumulator rows let workgroup 0 poll
+  // sharded arrival counts instead of finding the last arriver through two levels of returning tickets
+  tail.poll = (c->kind == KIND_FE && f.gP > 0 && f.gacc && c->tail_poll && !f.chain.sm) ? 1 : 0;
   return true;
 }
 

@@ -24,6 +24,9 @@ enum {
                              CMX_OPT_DETERMINISTIC the front end uses a [column][workgroup] table instead and back-end
                              gradient evaluations keep the separate launch (the 42-column table made the tail slower).
                              2: tail with the table form everywhere (back-end gradient included).
+                             3: as 1, with a POLLING tail on the front-end gather (workgroup 0 polls sharded fire-and-forget
+                                arrival counts and finalizes; round 6 A/B: 14.2 vs 14.1 us, no gain -- and 21.6 us with ONE
+                                counter: ~1000 atomics on one memory-side address serialise at ~12 ns each).
                              0: separate finalize launch (the round-1 flow) */
   /* 7: retired (round 2's opt-in fused gradient pass: measured slower, removed; profiles/r02_pmc_fe_fused_gather.txt) */
   CMX_OPT_COMPOSITE_IMAGE = 8, /* 1 (default): the image pass of the adjoint gradient applies G^T G as one banded operator per

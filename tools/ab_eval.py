@@ -88,6 +88,8 @@ def main():
     if "composite" in kv:
         variants = [("composite=0", {_lib.OPT_COMPOSITE_IMAGE: 0}), ("composite=1", {_lib.OPT_COMPOSITE_IMAGE: 1}),
                     ("composite=0", {_lib.OPT_COMPOSITE_IMAGE: 0}), ("composite=1", {_lib.OPT_COMPOSITE_IMAGE: 1})]
+    if "tailpoll" in kv:
+        variants = [("tail tickets", {_lib.OPT_TAIL_FINALIZE: 1}), ("tail polling", {_lib.OPT_TAIL_FINALIZE: 3})] * 3
     if "fused" in kv:
         variants = [("fused=0", {_lib.OPT_FUSED_IMAGE: 0}), ("fused=1", {_lib.OPT_FUSED_IMAGE: 1})] * 2
     if "fold" in kv:
