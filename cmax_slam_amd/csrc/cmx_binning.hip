@@ -496,7 +496,7 @@ constexpr unsigned long long kFuseTimeoutTicks = 200000ull;  // 2 ms of the 100 
 template <bool FIXED, bool STREAM, int FUSE>
 __device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f) {
   __shared__ __attribute__((aligned(16))) fix_t win[kBinWindow * kBinStride];
-  if (a.skip && *a.skip) return;  // device-driven solve: finished
+  if (wg_stop_requested(a.skip)) return;  // device-driven solve: finished
   if (FUSE == 2 && (int)blockIdx.x >= b.nchunks + f.tiles_x * f.tiles_y * kFuseStrips) {  // GATHER ROLE
     __shared__ FgSmem fg_sm;
     fused_gather_role<kFeSplatNT>(a, b, f, (int)blockIdx.x - b.nchunks - f.tiles_x * f.tiles_y * kFuseStrips, fg_sm);

@@ -249,6 +249,7 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
       c->force_rebin = true;
       c->fused_redos++;
       fuse_incomplete = (flags & kFuseIncomplete) != 0;
+      if (fuse_incomplete) c->fused_timeouts++;
       diverged = true;
       break;
     }
@@ -302,7 +303,12 @@ int chain_run_frontend(cmx_ctx *c, FrcgSM &hs, bool *completed) {
     (void)hipStreamSynchronize(c->stream);
     if (c->d_tail_counters) (void)hipMemsetAsync(c->d_tail_counters, 0, kTailCounterWords * sizeof(unsigned), c->stream);
     if (c->d_gacc) (void)hipMemsetAsync(c->d_gacc, 0, (size_t)kTailShards * kGaccStride * sizeof(double), c->stream);
-    if (fuse_incomplete && c->d_fnbr_cnt) (void)hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream);
+    // The stop word lands in the middle of whatever slot is running: of a fused slot, some chunk workgroups may have arrived on tile
+    // counters whose tile workgroups then left at once (counts never taken back), or tile workgroups may be waiting for chunks that left
+    // (they give up after kFuseTimeoutTicks and flag the fallback word nobody reads any more).  Counters and word start from zero again.
+    (void)fuse_incomplete;
+    if (c->d_fnbr_cnt) (void)hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream);
+    if (c->d_fallback) (void)hipMemsetAsync(c->d_fallback, 0, sizeof(unsigned), c->stream);
     if (diverged) c->chain_takeovers++;
   }
   c->x_valid = false;

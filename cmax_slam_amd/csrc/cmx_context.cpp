@@ -582,6 +582,7 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[CMX_STAT_FUSED_EVALS] = (double)c->fused_evals;
   stats[CMX_STAT_FUSED_REDOS] = (double)c->fused_redos;
   stats[CMX_STAT_ONE_LAUNCH_EVALS] = (double)c->fused_full_evals;
+  stats[CMX_STAT_FUSED_TIMEOUTS] = (double)c->fused_timeouts;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

@@ -205,7 +205,7 @@ struct cmx_ctx {
   unsigned votes_bin_id = 0;          // binning under which d_accum's votes were made by an LDS splat (0: some other way)
   unsigned last_fallback_flags = 0;   // kFuseUnsafe / kFuseIncomplete of the last collected evaluation
   bool force_rebin = false;           // a fused evaluation reported votes outside their windows: sort again before the next splat
-  int64_t fused_evals = 0, fused_redos = 0;
+  int64_t fused_evals = 0, fused_redos = 0, fused_timeouts = 0;
   unsigned long long *d_fuse_trace = nullptr;  // diagnostics (env CMX_FUSE_TRACE = output file): see FusedArgs::trace
   size_t fuse_trace_cap = 0, fuse_trace_n = 0;
   int64_t rebin_count = 0;

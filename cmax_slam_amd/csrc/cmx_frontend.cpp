@@ -334,8 +334,10 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
         if (!flags || !c->fused_done) break;
         c->fused_redos++;
         c->force_rebin = true;
-        if (flags & kFuseIncomplete)  // a tile gave up waiting: late arrivals are still on its counter
+        if (flags & kFuseIncomplete) {  // a tile gave up waiting: late arrivals are still on its counter
+          c->fused_timeouts++;
           HIP_TRY(c, hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream));
+        }
         double om[3] = {c->last_x[0], c->last_x[1], c->last_x[2]};
         const bool again_fused = attempt == 0 && !(flags & kFuseIncomplete);
         rc = fe_accumulate(c, om, 1, /*allow_fuse=*/again_fused, /*allow_full=*/again_fused);

@@ -1188,7 +1188,7 @@ __device__ __forceinline__ double block_sum_n(double v, double *red, int nwaves)
 template <int R, int TX, int TY, int NT, bool LIST>  // LIST: see image_moments_kernel
 __global__ __launch_bounds__(NT) void image_adjoint_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (g.img.skip && *g.img.skip) return;  // device-driven solve: finished
+  if (wg_stop_requested(g.img.skip)) return;  // device-driven solve: finished
   const ImgArgs &a = g.img;
   const int r = (R >= 0) ? R : a.r;
   const int W = a.W, H = a.H;
@@ -1336,7 +1336,7 @@ template <int R, bool LIST, int TAIL>  // TAIL: 0 none, 1 finalize in the last-a
 __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void image_adjoint2_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ FinSmem fin_sm;
-  if (TAIL >= 2 && g.img.skip && *g.img.skip) return;  // device-driven solve: finished
+  if (TAIL >= 2 && wg_stop_requested(g.img.skip)) return;  // device-driven solve: finished
   constexpr bool tail = TAIL == 1 || TAIL == 2;
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads, NTAP = 4 * R + 1;
   constexpr int AW = TX + 4 * R, AH = TY + 4 * R, GH = TY + 2 * R;
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(kAdjThreads) __attribute__((amdgpu_waves_per_eu(8, 
 template <bool LIST>
 __global__ __launch_bounds__(kAdjThreads) void image_adjoint2g_kernel(ImgAdjArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (g.img.skip && *g.img.skip) return;  // device-driven solve: finished
+  if (wg_stop_requested(g.img.skip)) return;  // device-driven solve: finished
   constexpr int TX = kAdjTX, TY = kAdjTY, NT = kAdjThreads;
   const ImgArgs &a = g.img;
   const int W = a.W, H = a.H, r = a.r, ntap = 4 * r + 1;
@@ -1741,7 +1741,7 @@ __device__ __forceinline__ void fe_gather_streams(const FeGatherArgs &g, const F
 template <int CHAIN>
 __global__ __launch_bounds__(kFeGatherNT) void fe_gather_kernel(FeGatherArgs g) {
   if (CHAIN != 2 && g.gate && *g.gate == 0) return;  // gated gradient pass: the cost-only evaluation in front decided against it
-  if (CHAIN && g.ev.skip && *g.ev.skip) return; // device-driven solve: finished
+  if (CHAIN && wg_stop_requested(g.ev.skip)) return;  // device-driven solve: finished
   __shared__ double red[(kFeGatherNT / 64) * 6];
   __shared__ FinSmem fin_sm;
   if (CHAIN == 2) {

@@ -33,6 +33,19 @@ __device__ __forceinline__ void fe_resolve_omega(FeSplatArgs &a) {
   if (a.w_dev) { a.wx = a.w_dev[0]; a.wy = a.w_dev[1]; a.wz = a.w_dev[2]; }
 }
 
+// device-driven solve: "finished" (FeSplatArgs::skip / ImgArgs::skip).  The word is set by the finalize step of an earlier launch --
+// or by the HOST, on the null stream, in the middle of whatever launch is running when it takes a solve over (cmx_chain.cpp).  The
+// decision must therefore be ONE read per workgroup: with one read per wave, some waves of a workgroup leave and the others stay, and
+// the ones that stay find LDS the leavers were to clear (a splat window full of a previous workgroup's data, flushed as votes -- also
+// to rows below the image's last one, i.e. into whatever allocation follows the plane).
+__device__ __forceinline__ bool wg_stop_requested(const int *skip) {
+  if (!skip) return false;  // (kernel argument: uniform)
+  __shared__ int stop_sh;
+  if (threadIdx.x == 0) stop_sh = __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  return stop_sh != 0;
+}
+
 struct FeWarp {
   int xx, yy;
   float dx, dy;
