@@ -177,3 +177,19 @@ def test_one_launch_form_matches_too(hip, oracle, small, measure):
         s = a.stats()
         assert s["one_launch_evals"] >= 5, s
         assert rel_scalar(-a.contrast_f((0.1, 0.2, 0.3)), ref.eval((0.1, 0.2, 0.3))[0]) < RTOL  # the other paths still work behind it
+
+
+def test_take_overs_in_mid_launch_short_soak():
+    """tools/soak_fused.py for a few seconds: six host threads, each checking a fused context against a three-launch one evaluation by
+    evaluation, with device-driven solves the host takes over in mid-launch (the stop word lands while a slot's workgroups are running),
+    jumps beyond the tiles' reach and a back-end context beside them.  Round 6's long runs of this found the stop word being read per
+    wave (profiles/r06_soak_fused.txt); here: no mismatch, no tile that gave up waiting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_fused.py"), "10", "6"], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "soak ok" in out, out[-3000:]
+    assert "TIMEOUTS 0;" in out, out[-3000:]
+    assert "chain take-overs 0," not in out, out[-3000:]   # the case under test did occur
