@@ -19,6 +19,7 @@
 #include "cmx_warp.hpp"
 #include "cmx_tilepass.hpp"
 #include "cmx_fusedgather.hpp"
+#include "cmx_selfserve.hpp"
 
 namespace cmx {
 
@@ -493,6 +494,7 @@ static_assert(sizeof(fix_t) * kBinWindow * kBinStride >= kTpLdsBytes, "the fused
 constexpr unsigned long long kFuseTimeoutTicks = 200000ull;  // 2 ms of the 100 MHz wall clock: ~200 x the launch's own duration
 // FUSE 1: the adjoint image pass runs inside this launch, tile by tile, as the tiles' inputs complete (FusedArgs, cmx_tilepass.hpp)
 // FUSE 2: ... and so do the gradient gather and the finalize step (cmx_fusedgather.hpp): one launch per evaluation
+// FUSE 3: one launch of the chunk workgroups alone: each runs the passes of the tiles it owns and gathers its own events (cmx_selfserve.hpp)
 template <bool FIXED, bool STREAM, int FUSE>
 __device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f) {
   __shared__ __attribute__((aligned(16))) fix_t win[kBinWindow * kBinStride];
@@ -502,7 +504,7 @@ __device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEv
     fused_gather_role<kFeSplatNT>(a, b, f, (int)blockIdx.x - b.nchunks - f.tiles_x * f.tiles_y * kFuseStrips, fg_sm);
     return;
   }
-  if (FUSE && (int)blockIdx.x >= b.nchunks) {
+  if ((FUSE == 1 || FUSE == 2) && (int)blockIdx.x >= b.nchunks) {
     // TILE ROLE: the workgroups behind the chunk table's launch bound each own one 32 x 32 image tile.  They are dispatched after
     // every chunk workgroup (lower indices), wait -- one polling lane, the other waves parked at the barrier -- until the chunks
     // that can vote into the tile's neighbourhood have all arrived, and run the tile's image pass.  A wait only ever points at
@@ -544,9 +546,13 @@ __device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEv
   fe_resolve_omega(a);
   // the launch is sized by an upper bound of the table's length, and so is the table's allocation: the entry is read
   // BEFORE the length is checked, so that the two loads share one memory round trip instead of taking two (~1 us each)
-  const Chunk c = b.chunks[blockIdx.x];
+  Chunk c = b.chunks[blockIdx.x];
   if (FUSE && f.trace && threadIdx.x == 0) { f.trace[8 * (size_t)blockIdx.x] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = 0; }
-  if ((int)blockIdx.x >= *b.nchunks_dev) return;
+  const bool has_chunk = (int)blockIdx.x < *b.nchunks_dev;
+  if (!has_chunk) {
+    if (FUSE != 3) return;
+    c = Chunk{-200000000, -200000000, 0, 0, 0, -1};  // (self-service: a workgroup beyond the table still owns tiles and arrives)
+  }
   const bool has_win = c.wx0 > -100000000;
   const int tid = threadIdx.x;
   // votes on the global path are counted per workgroup (LDS) and reported with ONE device atomic: a counter every thread
@@ -649,6 +655,11 @@ __device__ __forceinline__ void fe_splat_lds_body(FeSplatArgs &a, const BinnedEv
     }
     if (f.trace && tid == 0) { f.trace[8 * (size_t)blockIdx.x + 1] = wall_clock64(); f.trace[8 * (size_t)blockIdx.x + 3] = 1; }
   }
+  if constexpr (FUSE == 3 && STREAM) {
+    __shared__ SsSmem ss_sm;
+    // (behind the barrier above: the window's cells are in registers or flushed, sfall is final)
+    self_serve_tail<kFeSplatNT>(a, b, f, c, has_chunk, (sfall & kFuseCountMask) != 0u, reinterpret_cast<unsigned char *>(win), ss_sm);
+  }
 }
 template <bool FIXED, bool STREAM, int FUSE>
 __global__ __launch_bounds__(kFeSplatNT) void fe_splat_lds_kernel(FeSplatArgs a, BinnedEvents b, FusedArgs f) {
@@ -661,6 +672,27 @@ template <bool STREAM>
 __global__ __launch_bounds__(kFeSplatNT) __attribute__((amdgpu_waves_per_eu(6, 8))) void fe_splat_lds_one_kernel(FeSplatArgs a, BinnedEvents b,
                                                                                                                 FusedArgs f) {
   fe_splat_lds_body<false, STREAM, 2>(a, b, f);
+}
+// the self-service one-launch form (FUSE = 3): every workgroup of the launch must be resident at once -- at least four waves per SIMD
+// = two 512-thread workgroups per CU (<= 128 VGPRs): 512 chunk workgroups on 256 CUs (a 1M-event packet has ~413)
+__global__ __launch_bounds__(kFeSplatNT) __attribute__((amdgpu_waves_per_eu(4, 8))) void fe_splat_lds_self_kernel(FeSplatArgs a, BinnedEvents b,
+                                                                                                                 FusedArgs f) {
+  fe_splat_lds_body<false, true, 3>(a, b, f);
+}
+int fe_selfserve_capacity() {
+  static std::mutex mu;
+  static int cap[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cap[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fe_splat_lds_self_kernel, kFeSplatNT, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cap[dev] = -1;
+    else cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+  }
+  return cap[dev] > 0 ? cap[dev] : 0;
 }
 template <bool FIXED, bool STREAM, int FUSE>
 static void launch_fe_splat_lds_t(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
@@ -678,7 +710,11 @@ void launch_fe_splat_lds(const FeSplatArgs &a, const BinnedEvents &b, hipStream_
   if (b.nchunks <= 0) return;
   const bool stream = b.sb && b.sdt;
   const FusedArgs none{};
-  if (fused && !b.fixed && fused->gather_blocks > 0 && stream) {  // one launch per evaluation (needs the tile-ordered streams)
+  if (fused && !b.fixed && fused->self_serve && stream) {  // one launch of the chunk workgroups alone (cmx_selfserve.hpp)
+    const dim3 grid(b.nchunks);
+    if (t0 || t1) hipExtLaunchKernelGGL(fe_splat_lds_self_kernel, grid, dim3(kFeSplatNT), 0, s, t0, t1, 0, a, b, *fused);
+    else hipLaunchKernelGGL(fe_splat_lds_self_kernel, grid, dim3(kFeSplatNT), 0, s, a, b, *fused);
+  } else if (fused && !b.fixed && fused->gather_blocks > 0 && stream) {  // one launch per evaluation (needs the tile-ordered streams)
     launch_fe_splat_lds_t<false, true, 2>(a, b, *fused, s, t0, t1);
   } else if (fused && !b.fixed) {  // (never with the deterministic mode's fixed-point planes)
     if (stream) launch_fe_splat_lds_t<false, true, 1>(a, b, *fused, s, t0, t1);

@@ -417,6 +417,8 @@ static int set_option_one(cmx_ctx *c, int key, int value) {
     case CMX_OPT_FUSED_IMAGE:
       c->fused_image = value != 0;
       c->fused_full = value == 2;  // 2: gather + finalize inside the same launch as well (A/B: measured slower, see cmax_hip_diag.h)
+      c->fused_self = value == 3;  // 3: one launch of the chunk workgroups alone (cmx_selfserve.hpp; A/B: measured a tie with 1)
+      c->fused_self_strikes = 0;
       c->bin_valid = false;  // the fused pass's tables are built with the chunk table
       c->x_valid = false;
       return CMX_OK;
@@ -583,6 +585,7 @@ int cmx_get_stats(cmx_ctx *c, double *out, int n_stats) {
   stats[CMX_STAT_FUSED_REDOS] = (double)c->fused_redos;
   stats[CMX_STAT_ONE_LAUNCH_EVALS] = (double)c->fused_full_evals;
   stats[CMX_STAT_FUSED_TIMEOUTS] = (double)c->fused_timeouts;
+  stats[CMX_STAT_SELF_SERVE_EVALS] = (double)c->fused_self_evals;
   for (int i = 0; i < n_stats && i < CMX_N_STATS; i++) out[i] = stats[i];
   return CMX_OK;
 }

@@ -194,6 +194,9 @@ struct cmx_ctx {
   unsigned fuse_seq = 0;
   bool fused_full = false;            // CMX_OPT_FUSED_IMAGE 2 (opt-in, measured slower: profiles/r06_fused_ab.txt): gather + finalize ride
                                       // in the splat launch as well
+  bool fused_self = false;            // CMX_OPT_FUSED_IMAGE 3: ONE launch of the chunk workgroups alone (cmx_selfserve.hpp)
+  int fused_self_strikes = 0;         // evaluations of that form that ran into a bounded wait (three: the context stops using it)
+  int64_t fused_self_evals = 0;
   bool fused_full_done = false;       // the pending evaluation is ONE launch: its finalize carries the ticket, nothing is left to queue
   int64_t fused_full_evals = 0;
   unsigned fused_bin_id = 0;          // binning the three tables above were built for (0: none)

@@ -145,6 +145,14 @@ static bool fe_full_ok(const cmx_ctx *c) {
          c->ticket_wait && c->measure != CMX_GRADIENT_MAGNITUDE && !c->chain_active && c->d_ftile_done && c->n_packed > 0;
 }
 
+// ... or as ONE launch of the chunk workgroups alone (FUSE = 3, cmx_selfserve.hpp): the same evaluations, once the chunk table's exact
+// length is known and all of its workgroups are resident at once on this device
+static bool fe_self_ok(const cmx_ctx *c) {
+  return c->fused_self && c->streams_valid && c->d_cx && c->d_cy && c->d_gacc && c->d_tail_counters && c->tail_finalize == 1 &&
+         c->ticket_wait && c->measure != CMX_GRADIENT_MAGNITUDE && !c->chain_active && c->d_ftile_done && c->n_packed > 0 &&
+         c->nchunks_exact && c->nchunks > 0 && c->nchunks <= fe_selfserve_capacity();
+}
+
 int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fuse, bool allow_full) {
   yield_to_urgent(c);
   c->timing_tick++;  // every span of this evaluation (accumulate and finish) samples, or none does
@@ -205,12 +213,18 @@ int fe_accumulate(cmx_ctx *c, const double omega[3], int nplanes, bool allow_fus
           c->alt_clean = true;  // stream-ordered: clean by the time the next accumulate's splat runs
           c->alt_flagged = false;
         }
-        if (allow_full && fe_full_ok(c)) {  // ONE launch: gather workgroups and the finalize step behind the strips
+        const bool self = allow_full && fe_self_ok(c);
+        if (self || (allow_full && fe_full_ok(c))) {  // ONE launch: gather workgroups and the finalize step behind the strips
           const int NT = 512, n = c->n_packed;
           int per = ((n + 399) / 400 + NT - 1) / NT * NT;
           per = per < NT ? NT : (per > 4 * NT ? 4 * NT : per);
-          f.gather_per_block = per;
-          f.gather_blocks = (n + per - 1) / per;
+          if (self) {  // ... or the chunk workgroups themselves run the passes and gather their own events
+            f.self_serve = 1;
+            c->fused_self_evals++;
+          } else {
+            f.gather_per_block = per;
+            f.gather_blocks = (n + per - 1) / per;
+          }
           if (++c->fuse_seq == 0u) c->fuse_seq = 1u;
           f.seq = c->fuse_seq;
           f.tile_done = c->d_ftile_done;
@@ -336,6 +350,9 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
         c->force_rebin = true;
         if (flags & kFuseIncomplete) {  // a tile gave up waiting: late arrivals are still on its counter
           c->fused_timeouts++;
+          // the self-service form needs every workgroup resident at once: a context that shares the device with other work and keeps
+          // running into the bounded waits goes back to the two-launch form for good
+          if (c->fused_full_done && c->fused_self && ++c->fused_self_strikes >= 3) c->fused_self = false;
           HIP_TRY(c, hipMemsetAsync(c->d_fnbr_cnt, 0, c->fcnt_cap * sizeof(unsigned), c->stream));
         }
         double om[3] = {c->last_x[0], c->last_x[1], c->last_x[2]};

@@ -315,6 +315,7 @@ struct FusedArgs {
   // checksum + ticket to the mapped result block.  Every wait points at workgroups with LOWER indices that wait for nobody
   // further up, and is bounded (kFuseIncomplete).
   int gather_blocks;            // 0: two-launch form (FUSE = 1)
+  int self_serve;               // 1: the self-service one-launch form (FUSE = 3, cmx_selfserve.hpp): no strip / gather workgroups at all
   int gather_per_block;         // events per gather workgroup (a multiple of the workgroup size; at most 4 per thread)
   unsigned seq;                 // this launch's stamp in tile_done[]
   unsigned *tile_done;          // [tiles * kFuseStrips * kFuseCntStride]: == seq once the strip's Jt and moment row have been stored
@@ -394,6 +395,7 @@ int launch_be_gather(const BeGatherArgs &a, int nb, hipStream_t s, hipEvent_t t0
 int be_batch_blocks(int nb);
 int gather_blocks(int n);
 int fe_gather_blocks(int n);
+int fe_selfserve_capacity();  // workgroups of the self-service one-launch form that are resident at once on the current device
 // contrast_ImageGradientMagnitude (front end, contrast_measure = 2): Sobel moments of the blurred planes
 struct SobelArgs {
   int W, H, P;

@@ -77,12 +77,12 @@ class _Evaluator:
         self.set_option(_lib.OPT_SPLAT_MODE, mode)
 
     def stats(self):
-        s = np.zeros(21)
-        self._ck(self._L.cmx_get_stats(self._ctx, _dp(s), 21))
+        s = np.zeros(22)
+        self._ck(self._L.cmx_get_stats(self._ctx, _dp(s), 22))
         return {"rebins": int(s[0]), "fallback_frac": float(s[1]), "chunks": int(s[2]), "events": int(s[3]),
                 "reuse_hits": int(s[4]), "sharded_host_syncs": int(s[5]), "exchange_misses": int(s[6]), "exchange_tiles": int(s[7]), "comm_bytes": int(s[8]), "spec_images": int(s[9]), "spec_hits": int(s[10]),
                 "gated_launches": int(s[11]), "gated_hits": int(s[12]), "chain_solves": int(s[13]), "chain_slots": int(s[14]),
-                "chain_takeovers": int(s[15]), "chain_warm_starts": int(s[16]), "fused_evals": int(s[17]), "fused_redos": int(s[18]), "one_launch_evals": int(s[19]), "fused_timeouts": int(s[20])}
+                "chain_takeovers": int(s[15]), "chain_warm_starts": int(s[16]), "fused_evals": int(s[17]), "fused_redos": int(s[18]), "one_launch_evals": int(s[19]), "fused_timeouts": int(s[20]), "self_serve_evals": int(s[21])}
 
     def hint_next_df(self, threshold, mode):
         """cmx_hint_next_df: the next cost-only evaluation's value f = -contrast decides (mode 1: f < threshold, 2: f <= threshold,

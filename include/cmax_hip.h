@@ -481,7 +481,8 @@ enum {
   CMX_STAT_FUSED_REDOS = 18,        /* ... of which were repeated (votes beyond the reach of their tiles' arrival counts) */
   CMX_STAT_ONE_LAUNCH_EVALS = 19,   /* ... of which ran splat, image pass, gather and finalize as ONE launch */
   CMX_STAT_FUSED_TIMEOUTS = 20,     /* repeats caused by a tile workgroup that gave up waiting (stays 0: a wait is bounded at 2 ms) */
-  CMX_N_STATS = 21
+  CMX_STAT_SELF_SERVE_EVALS = 21,   /* ... of the one-launch evaluations, those of the self-service form (chunk workgroups alone) */
+  CMX_N_STATS = 22
 };
 int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_stats, CMX_N_STATS) entries (ABI 3: the length is explicit) */
 /* ABI revision of this header: bumped whenever a signature or the layout of a caller-provided buffer changes

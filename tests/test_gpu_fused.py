@@ -179,6 +179,53 @@ def test_one_launch_form_matches_too(hip, oracle, small, measure):
         assert rel_scalar(-a.contrast_f((0.1, 0.2, 0.3)), ref.eval((0.1, 0.2, 0.3))[0]) < RTOL  # the other paths still work behind it
 
 
+@pytest.mark.parametrize("measure", [0, 1])
+def test_self_service_one_launch_form(hip, oracle, small, measure):
+    """CMX_OPT_FUSED_IMAGE = 3: ONE launch of the chunk workgroups alone -- each runs the image pass of the tiles it owns and gathers
+    the gradient sums of its own events (cmx_selfserve.hpp).  Same numbers as the three-launch form and the oracle's, on a dense
+    packet, a partial-tile image and a SPARSE packet (fewer chunks than tiles: workgroups own several tiles), incl. a jump beyond the
+    tiles' reach (repeated after a fresh sort) and motion onto the global path (waits for every pass of the launch)."""
+    sparse = synth.frontend_packet(3_001, 346, 260, 300.0, 300.0, 172.5, 129.5, seed=33)
+    for p in (small, synth.frontend_packet(20_011, 100, 70, 90.0, 90.0, 49.5, 34.5, seed=170), sparse):
+        a, b = _fe(hip, p, 3, measure), _fe(hip, p, 0, measure)
+        ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, measure)
+        ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+        pts = [(0.5, -0.8, 0.3), (0.52, -0.83, 0.31), (0.53, -0.80, 0.33), (1.6, -2.4, 1.1), (1.62, -2.4, 1.1), (6.0, -5.0, 9.0), (6.0, -5.01, 9.0),
+               (6.01, -5.01, 9.0), (0.0, 0.0, 0.0), (0.01, 0.0, 0.0)]
+        for om in pts:
+            ca, ga = a.eval(om)
+            cb, gb = b.eval(om)
+            cr, gr = ref.eval(om)
+            assert rel_scalar(ca, cb) < 1e-7 and rel_vec(ga, gb) < 1e-6, (om, ca, cb, ga, gb)
+            assert rel_scalar(ca, cr) < RTOL and rel_vec(ga, gr) < RTOL, (om, ca, cr, ga, gr)
+        s = a.stats()
+        assert s["self_serve_evals"] >= 4 and s["fused_timeouts"] == 0, s  # (a sort's first evaluation does not know the table's length yet)
+        assert rel_scalar(-a.contrast_f((0.1, 0.2, 0.3)), ref.eval((0.1, 0.2, 0.3))[0]) < RTOL  # the other paths still work behind it
+
+
+def test_self_service_config2_full_size_and_many_evaluations(hip, oracle):
+    """BASELINE config 2 (1M events, 640x480) through the self-service launch at a sequence of points, then 300 evaluations back to
+    back against the three-launch form: counters, stamps and accumulator rows reset themselves."""
+    p = synth.frontend_packet(1_000_000, 640, 480, 588.10, 593.99, 339.83, 242.43, seed=20240316)
+    fe, plain = _fe(hip, p, 3), _fe(hip, p, 0)
+    ref = oracle.Frontend(p.W, p.H, p.lut, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, 0)
+    ref.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns)
+    for om in [(0.6, -0.9, 0.4), (0.55, -0.95, 0.42), (0.62, -0.88, 0.37)]:
+        c, g = fe.eval(om)
+        cr, gr = ref.eval(om)
+        assert rel_scalar(c, cr) < RTOL and rel_vec(g, gr) < RTOL, (om, c, cr, g, gr)
+    rng = np.random.default_rng(19)
+    om = np.array([0.6, -0.9, 0.4])
+    for it in range(300):
+        c, g = fe.eval(om)
+        if it % 30 == 0:
+            cb, gb = plain.eval(om)
+            assert rel_scalar(c, cb) < 1e-7 and rel_vec(g, gb) < 1e-6, (it, c, cb, g, gb)
+        om = om + rng.normal(0, 0.01, 3)
+    s = fe.stats()
+    assert s["self_serve_evals"] >= 300 and s["fused_redos"] == 0 and s["fused_timeouts"] == 0, s
+
+
 def test_take_overs_in_mid_launch_short_soak():
     """tools/soak_fused.py for a few seconds: six host threads, each checking a fused context against a three-launch one evaluation by
     evaluation, with device-driven solves the host takes over in mid-launch (the stop word lands while a slot's workgroups are running),

@@ -13,7 +13,7 @@ from cmax_slam_amd import _lib, evaluator, synth  # noqa: E402
 
 npts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 p = synth.config2(1_000_000)
-for fused in (0, 1, 2, 0, 1, 2):
+for fused in [int(v) for v in os.environ.get('AB_FUSED', '0,1,2,3,0,1,2,3').split(',')]:
     ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
     ev.set_option(_lib.OPT_FUSED_IMAGE, fused)
     ev.set_option(_lib.OPT_REUSE_IMAGE, 0)
@@ -36,5 +36,5 @@ for fused in (0, 1, 2, 0, 1, 2):
     st = ev.stats()
     print("fused=%d: %.4f ms per fdf cycling %d points; kernels(us): %s; rebins %d fallback %.5f fused %d redos %d"
           % (fused, best * 1e3, npts, " ".join("%s=%.1f" % (k, 1e3 * v[0] / v[1]) for k, v in tim.items() if v[1]), st["rebins"],
-             st["fallback_frac"], st["fused_evals"], st["fused_redos"]) + " one-launch %d" % st["one_launch_evals"], flush=True)
+             st["fallback_frac"], st["fused_evals"], st["fused_redos"]) + " one-launch %d self-service %d timeouts %d" % (st["one_launch_evals"], st["self_serve_evals"], st["fused_timeouts"]), flush=True)
     ev.close()

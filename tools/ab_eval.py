@@ -91,7 +91,7 @@ def main():
     if "tailpoll" in kv:
         variants = [("tail tickets", {_lib.OPT_TAIL_FINALIZE: 1}), ("tail polling", {_lib.OPT_TAIL_FINALIZE: 3})] * 3
     if "fused" in kv:
-        variants = [("fused=0", {_lib.OPT_FUSED_IMAGE: 0}), ("fused=1", {_lib.OPT_FUSED_IMAGE: 1})] * 2
+        variants = [("fused=0", {_lib.OPT_FUSED_IMAGE: 0}), ("fused=1", {_lib.OPT_FUSED_IMAGE: 1}), ("fused=3", {_lib.OPT_FUSED_IMAGE: 3})] * 2
     if "fold" in kv:
         variants = [("fold=0", {_lib.OPT_FOLD_BATCH: 0}), ("fold=1", {_lib.OPT_FOLD_BATCH: 1})] * 2
     if "det" in kv:

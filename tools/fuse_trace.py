@@ -23,6 +23,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     p = synth.config2(n)
     ev = evaluator.FrontendEvaluator(p.W, p.H, p.lut)
+    if os.environ.get("TRACE_FUSED"):
+        ev.set_option(_lib.OPT_FUSED_IMAGE, int(os.environ["TRACE_FUSED"]))
     ev.set_packet(p.x, p.y, p.t_ns, p.t_ref_ns, p.fx, p.fy, p.cx, p.cy, p.batch, p.sigma, _lib.VARIANCE)
     x0 = np.array([0.3, -0.5, 0.2])
     if len(sys.argv) > 2:  # sort at omega = 0, evaluate at argv[2] x the packet's true rate (a cold-start solve's range)
@@ -57,6 +59,33 @@ def main():
             if (t[tl, 7] > 0).all():
                 pct(us(7, tl) - us(2, tl), "  the whole pass AGAIN (warm code)")
             pct(us(1, tl) - us(1, ch).max(), "poll ok - last chunk arrival")
+        if ev.stats()["self_serve_evals"]:  # self-service form: every workgroup is a chunk workgroup (cmx_selfserve.hpp's stamps)
+            dbg64 = bool(int(os.environ.get("CMX_FUSE_DEBUG", "0")) & 64)
+            own = ch & (t[:, 2] > 0) & (not dbg64)
+            if dbg64:
+                own = ch & False
+                pct(us(5, ch), "events re-read + warped")
+                pct(us(6, ch), "its tiles' passes are done")
+                pct(us(7, ch), "Jt cells read, sums added")
+                pct(us(2, ch) - us(6, ch), "  wait ended -> first cells loaded")
+                pct(us(4, ch) - us(2, ch), "  -> per-thread sums formed")
+                pct(us(7, ch) - us(4, ch), "  -> wave sums, LDS, atomics issued")
+                continue
+            pct(us(2, own), "owner: tile inputs complete")
+            pct(us(2, own) - us(1, own), "  (since the owner's own arrival)")
+            pct(us(2, own) - us(1, ch).max(), "  (since the LAST chunk arrival)")
+            pct(us(4, own), "owner: pass stored + published")
+            pct(us(4, own) - us(2, own), "owner: pass duration")
+            pct(us(5, ch), "events re-read + warped")
+            pct(us(5, ch & ~own) - us(1, ch & ~own), "  (non-owners: since arrival)")
+            pct(us(5, own) - us(4, own), "  (owners: since their pass)")
+            pct(us(6, ch), "its tiles' passes are done")
+            pct(us(7, ch), "Jt cells read, sums added")
+            pct(us(7, ch) - us(6, ch), "  (since the wait ended)")
+            if int(os.environ.get("CMX_FUSE_DEBUG", "0")) & 64:  # (stamps 2 and 4 re-used: cells loaded, sums formed)
+                pct(us(2, ch) - us(6, ch), "  wait ended -> first cells loaded")
+                pct(us(4, ch) - us(2, ch), "  -> per-thread sums formed")
+                pct(us(7, ch) - us(4, ch), "  -> wave sums, LDS, atomics issued")
         if ga.sum():
             pct(us(0, ga), "gather start")
             pct(us(1, ga), "gather: events warped")
