@@ -74,21 +74,15 @@ __device__ __forceinline__ void fg_finalize(const FusedArgs &f, unsigned *fallba
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int nstrips = f.tiles_x * f.tiles_y * kFuseStrips;
   // every strip of this launch must have stored its moments: usually long true (the gather workgroups waited for the strips their
-  // votes touch; strips that only see a neighbour's blur may still be running)
+  // votes touch; strips that only see a neighbour's blur may still be running).  The independent reads -- moment rows (agent-scope
+  // loads: stored write-through by the strips), accumulator rows, fallback word -- are requested TOGETHER with the first read of the
+  // strip count (one round trip instead of two); only if that count was short are the moment rows read again behind the wait.
+  const unsigned want = (unsigned)*f.n_active;
+  unsigned done0 = 0u;
   if (t == 0) {
-    const unsigned want = (unsigned)*f.n_active;
-    const unsigned long long t0 = wall_clock64();
-    int ok = 1;
-    while (__hip_atomic_load(f.tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > 200000ull) { ok = 0; break; }
-    }
-    __hip_atomic_store(f.tiles_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!ok) atomicOr(fallback, kFuseIncomplete);
+    done0 = __hip_atomic_load(f.tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sm.chk = 0ull;
   }
-  __syncthreads();
-  // the independent reads first: moment rows (agent-scope loads: stored write-through by the strips), accumulator rows, fallback word
   double p0 = 0, p1 = 0;
   for (int b = t; b < nstrips; b += NT) {
     p0 += fg_ld_sc1(f.partials + b);
@@ -98,6 +92,28 @@ __device__ __forceinline__ void fg_finalize(const FusedArgs &f, unsigned *fallba
   if (t < 6) {
 #pragma unroll
     for (int q = 0; q < kTailShards; q++) gv[q] = fg_ld_sc1(f.gacc + (size_t)q * f.gacc_stride + t);
+  }
+  if (t == 0) {
+    int ok = 1, late = 0;
+    if (done0 < want) {
+      late = 1;
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(f.tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 200000ull) { ok = 0; break; }
+      }
+    }
+    __hip_atomic_store(f.tiles_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) atomicOr(fallback, kFuseIncomplete);
+    sm.pending = late;
+  }
+  __syncthreads();
+  if (sm.pending) {  // (workgroup-uniform) strips were still running when the rows were read: once more, behind the wait
+    p0 = p1 = 0;
+    for (int b = t; b < nstrips; b += NT) {
+      p0 += fg_ld_sc1(f.partials + b);
+      p1 += fg_ld_sc1(f.partials + nstrips + b);
+    }
   }
   unsigned fb = 0u;
   if (t == 0) fb = __hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

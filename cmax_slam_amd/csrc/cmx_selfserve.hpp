@@ -83,14 +83,18 @@ struct SsSmem {
 
 // the wait of a tile's pass for its inputs: one polling lane, the other waves parked at the barrier (the tile role's wait of the
 // two-launch form)
+// `early`: thread 0's read of the counter from BEFORE the pass's preamble (operator rows, addresses): an owner is usually late for its
+// tile -- the count is complete by then and the poll's round trip to the memory side is not paid a second time behind the preamble
 template <int NT>
-__device__ __forceinline__ bool ss_wait_tile_inputs(const FusedArgs &f, unsigned *fallback, int t, unsigned expected, int &ok_sh) {
+__device__ __forceinline__ bool ss_wait_tile_inputs(const FusedArgs &f, unsigned *fallback, int t, unsigned expected, unsigned early, int &ok_sh) {
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(f.nbr_cnt + (size_t)t * kFuseCntStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+    unsigned v = early;
+    while (v < expected) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > 200000ull) { ok = 0; break; }
+      v = __hip_atomic_load(f.nbr_cnt + (size_t)t * kFuseCntStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (ok) __hip_atomic_store(f.nbr_cnt + (size_t)t * kFuseCntStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all-zero again for the next launch
     else atomicOr(fallback, kFuseIncomplete);
@@ -106,32 +110,37 @@ struct SsRound {
   float dx[4], dy[4], r0[4][3], r1[4][3];
 };
 
-// streams, fp64 warp with the Jacobian rows, border term of events i0, i0 + NT, i0 + 2 NT, i0 + 3 NT (< end): nothing of this depends
-// on the launch's votes.  An event that does not count keeps zero rows: its terms in ss_consume are exact zeros whatever cell 0 holds.
-template <int NT>
-__device__ __forceinline__ void ss_prewarp(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, int i0, int end, SsRound &s, double (&acc2)[3]) {
-  const int W = a.W, H = a.H, r = kTpR;
+// the tile-ordered streams of events i0, i0 + NT, i0 + 2 NT, i0 + 3 NT (< end): bearing (x, y) and dt, 24 bytes per event
+struct SsStreams {
   double2 bv[4];
   double dt[4];
   bool ok[4];
+};
+template <int NT>
+__device__ __forceinline__ void ss_load_streams(const BinnedEvents &b, int i0, int end, SsStreams &t) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int i = i0 + q * NT;
-    ok[q] = i < end;
-    const int ii = ok[q] ? i : 0;
-    bv[q] = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)ii);
-    dt[q] = b.sdt[ii];
+    t.ok[q] = i < end;
+    const int ii = t.ok[q] ? i : 0;
+    t.bv[q] = *reinterpret_cast<const double2 *>(b.sb + 2 * (size_t)ii);
+    t.dt[q] = b.sdt[ii];
   }
+}
+// fp64 warp with the Jacobian rows and the border term of four loaded events: nothing of this depends on the launch's votes.  An
+// event that does not count keeps zero rows: its terms in ss_consume are exact zeros whatever cell 0 holds.
+__device__ __forceinline__ void ss_warp(const FeSplatArgs &a, const FusedArgs &f, const SsStreams &t, SsRound &s, double (&acc2)[3]) {
+  const int W = a.W, H = a.H, r = kTpR;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const FeWarp w = fe_warp_math<true>(a, bv[q].x, bv[q].y, 1.0, dt[q]);
-    ok[q] = ok[q] && w.ok;
-    s.off[q] = ok[q] ? (unsigned)(((size_t)w.yy * W + w.xx) * sizeof(float)) : 0u;  // (cells 0 .. W+1 exist in every image the path accepts)
+    const FeWarp w = fe_warp_math<true>(a, t.bv[q].x, t.bv[q].y, 1.0, t.dt[q]);
+    const bool ok = t.ok[q] && w.ok;
+    s.off[q] = ok ? (unsigned)(((size_t)w.yy * W + w.xx) * sizeof(float)) : 0u;  // (cells 0 .. W+1 exist in every image the path accepts)
     s.dx[q] = w.dx;
     s.dy[q] = w.dy;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { s.r0[q][k] = ok[q] ? w.r0[k] : 0.f; s.r1[q][k] = ok[q] ? w.r1[k] : 0.f; }
-    if (ok[q] && (w.xx <= r || w.xx + 1 >= W - 1 - r || w.yy <= r || w.yy + 1 >= H - 1 - r)) {  // votes within r of the border: the mu term's c = G^T 1
+    for (int k = 0; k < 3; k++) { s.r0[q][k] = ok ? w.r0[k] : 0.f; s.r1[q][k] = ok ? w.r1[k] : 0.f; }
+    if (ok && (w.xx <= r || w.xx + 1 >= W - 1 - r || w.yy <= r || w.yy + 1 >= H - 1 - r)) {  // votes within r of the border: the mu term's c = G^T 1
       const float c00 = f.cx[w.xx] * f.cy[w.yy], c01 = f.cx[w.xx + 1] * f.cy[w.yy], c10 = f.cx[w.xx] * f.cy[w.yy + 1],
                   c11 = f.cx[w.xx + 1] * f.cy[w.yy + 1];
       const float Ac = (1.f - w.dy) * (c01 - c00) + w.dy * (c11 - c10), Bc = (1.f - w.dx) * (c10 - c00) + w.dx * (c11 - c01);
@@ -141,6 +150,12 @@ __device__ __forceinline__ void ss_prewarp(const FeSplatArgs &a, const BinnedEve
       }
     }
   }
+}
+template <int NT>
+__device__ __forceinline__ void ss_prewarp(const FeSplatArgs &a, const BinnedEvents &b, const FusedArgs &f, int i0, int end, SsRound &s, double (&acc2)[3]) {
+  SsStreams t;
+  ss_load_streams<NT>(b, i0, end, t);
+  ss_warp(a, f, t, s, acc2);
 }
 // the four Jt cells of a round's events and their terms of the three sums
 __device__ __forceinline__ void ss_consume(const float *row0, const float *row1, bool plain, const SsRound &s, double (&acc)[3]) {
@@ -175,8 +190,10 @@ __device__ __forceinline__ void self_serve_tail(const FeSplatArgs &a, const Binn
     const unsigned expected = (unsigned)f.nbr_expected[t];
     if (expected == 0u) continue;  // no vote can reach this tile: B = Jt = 0 there, zero moments (rows cleared at sort time)
     bool ran = false;
+    unsigned early = 0u;
+    if (tid == 0) early = __hip_atomic_load(f.nbr_cnt + (size_t)t * kFuseCntStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fused_tile_pass<NT, true>(fq, a.planes, W, a.H, t, lds, [&]() -> bool {
-      ran = ss_wait_tile_inputs<NT>(f, b.fallback, t, expected, sm.ok_sh);
+      ran = ss_wait_tile_inputs<NT>(f, b.fallback, t, expected, early, sm.ok_sh);
       if (tr && tid == 0) tr[2] = wall_clock64();
       return ran;
     });
@@ -195,6 +212,10 @@ __device__ __forceinline__ void self_serve_tail(const FeSplatArgs &a, const Binn
   // every neighbour waits for, and the state kept across the pass spills); eight events per thread here (spills: every scratch reload
   // behind the wait is a memory round trip).
   ss_prewarp<NT>(a, b, f, beg + tid, end, s0, acc2);
+  // chunks of more than 4 NT events (workgroup-uniform): the second round's streams are requested in front of the wait as well
+  const bool two = end - beg > 4 * NT;
+  SsStreams t1;
+  if (two) ss_load_streams<NT>(b, beg + 4 * NT + tid, end, t1);
   if (tr && tid == 0) tr[5] = wall_clock64();
   // ---- step 3b: wait for the passes this chunk's vote cells lie in: the 3 x 3 tiles around its own (window = tile + 16 px); with
   // votes on the global path (or no window at all) for every pass of the launch
@@ -233,7 +254,11 @@ __device__ __forceinline__ void self_serve_tail(const FeSplatArgs &a, const Binn
   const bool plain = W % kBinTile == 0 && (reinterpret_cast<unsigned long long>(f.jt) & 127ull) == 0ull;  // (see ss_ld_cells)
   ss_consume(row0, row1, plain, s0, acc);
   if (tr && tid == 0 && (f.debug & 64)) tr[2] = wall_clock64();
-  for (int i0 = beg + 4 * NT + tid; i0 < end; i0 += 4 * NT) {  // chunks of more than 4 NT events: further rounds of four
+  if (two) {
+    ss_warp(a, f, t1, s0, acc2);
+    ss_consume(row0, row1, plain, s0, acc);
+  }
+  for (int i0 = beg + 8 * NT + tid; i0 < end; i0 += 4 * NT) {  // chunks of more than 8 NT events (packets above ~1M events): further rounds
     ss_prewarp<NT>(a, b, f, i0, end, s0, acc2);
     ss_consume(row0, row1, plain, s0, acc);
   }

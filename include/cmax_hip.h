@@ -491,7 +491,7 @@ int cmx_get_stats(cmx_ctx *ctx, double *stats, int n_stats); /* writes min(n_sta
  *  5: cmx_comm_info; the event store behind a group (cmx_events_create_group, cmx_backend_set_window_from on a group);
  *     CMX_OPT_SPIN_WAIT values >= 2 are a spin budget in microseconds for all three waiters (before: "spin"), negative values are
  *     rejected (before: accepted as non-zero);
- *  6: named cmx_get_stats indices, three more of them; cmx_group_transport_info; the *_aos entry points; cmx_set_stream_priority /
+ *  6: named cmx_get_stats indices, five more of them (the buffer length is the caller's: old callers keep reading what they asked for); cmx_group_transport_info; the *_aos entry points; cmx_set_stream_priority /
  *     cmx_set_cu_mask moved to cmax_hip_diag.h) */
 #define CMX_ABI_VERSION 6
 int cmx_abi_version(void);

@@ -59,6 +59,13 @@ enum {
                                the same launch as well.  Built, parity-tested and measured SLOWER than 1 (0.048 vs 0.0365 ms per
                                1M-event evaluation: the three roles compete for the same CUs and the gather's workgroups do not
                                all fit beside the strips; profiles/r06_fused_ab.txt) -- kept as an A/B switch.
+                               3: ONE launch of the chunk workgroups ALONE (self-service, cmx_selfserve.hpp): each runs the image
+                               pass of the tile(s) it owns, then gathers the gradient sums of its own events, the last arriver
+                               finalizes.  Used only once the chunk table's exact length is known and fits the device (all workgroups
+                               resident at once; 512 on an MI355X), evaluations it does not cover take form 1; a context whose launches
+                               run into the bounded waits three times (it shares the GPU) stops using it.  Parity-tested; measured a
+                               TIE with 1 (0.0349-0.0352 vs 0.0353-0.0354 ms per 1M-event evaluation, -2.7 % at a fixed point;
+                               profiles/r06_selfserve.txt) -- kept as an A/B switch.
                                0: splat, image pass and gather as three launches */
 };
 
