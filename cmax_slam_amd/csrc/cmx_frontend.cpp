@@ -350,6 +350,9 @@ int cmx_frontend_finish(cmx_ctx *c, double *contrast, double *grad) {
         c->force_rebin = true;
         if (flags & kFuseIncomplete) {  // a tile gave up waiting: late arrivals are still on its counter
           c->fused_timeouts++;
+          // ... and passes that never ran have not cleared their tiles of the ping-pong partner: neither buffer is known to be clean
+          c->alt_clean = false;
+          c->accum_clean = false;
           // the self-service form needs every workgroup resident at once: a context that shares the device with other work and keeps
           // running into the bounded waits goes back to the two-launch form for good
           if (c->fused_full_done && c->fused_self && ++c->fused_self_strikes >= 3) c->fused_self = false;

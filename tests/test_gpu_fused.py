@@ -226,6 +226,43 @@ def test_self_service_config2_full_size_and_many_evaluations(hip, oracle):
     assert s["self_serve_evals"] >= 300 and s["fused_redos"] == 0 and s["fused_timeouts"] == 0, s
 
 
+def test_self_service_beside_other_contexts_stays_correct(hip):
+    """Three host threads, each with its own self-service context on the same GPU: a launch may now find CUs taken by another context's
+    workgroups, i.e. NOT all of its workgroups resident at once -- the case the form's bounded waits exist for.  Whatever happens
+    (no wait runs out; or some do, the evaluation is repeated through the separate launches and after three strikes the context
+    stops using the form), every evaluation returns the three-launch form's numbers and nothing hangs."""
+    import threading
+    p = synth.frontend_packet(300_007, 640, 480, 588.10, 593.99, 339.83, 242.43, seed=77)
+    plain = _fe(hip, p, 0)
+    rng = np.random.default_rng(3)
+    pts = [np.array([0.6, -0.9, 0.4]) + rng.normal(0, 0.02, 3) for _ in range(40)]
+    want = [plain.eval(om) for om in pts]
+    errs, stats = [], []
+
+    def work(k):
+        try:
+            fe = _fe(hip, p, 3)
+            for rep in range(5):
+                for om, (cw, gw) in zip(pts, want):
+                    c, g = fe.eval(om)
+                    if not (rel_scalar(c, cw) < 1e-7 and rel_vec(g, gw) < 1e-6):
+                        errs.append((k, rep, tuple(om), c, cw, fe.stats()))
+                        return
+            stats.append(fe.stats())
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a self-service context hangs beside other contexts"
+    assert not errs, errs[:3]
+    assert len(stats) == 3 and all(s["fused_evals"] >= 200 for s in stats), stats
+    print("self-service beside other contexts:", [(s["self_serve_evals"], s["fused_timeouts"], s["fused_redos"]) for s in stats])
+
+
 def test_take_overs_in_mid_launch_short_soak():
     """tools/soak_fused.py for a few seconds: six host threads, each checking a fused context against a three-launch one evaluation by
     evaluation, with device-driven solves the host takes over in mid-launch (the stop word lands while a slot's workgroups are running),
