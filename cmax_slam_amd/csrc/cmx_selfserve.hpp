@@ -6,10 +6,11 @@
 //   2. runs the adjoint image pass (cmx_tilepass.hpp) of the tiles it OWNS: tile t belongs to workgroup G - 1 - (t mod G), i.e. to the
 //      workgroups at the END of the chunk table first.  The table is ordered longest chunk first, so the owners are the workgroups
 //      that finish their votes earliest; with G >= tiles (every dense packet) the G - tiles largest chunks own nothing;
-//   3. gathers the gradient sums of ITS OWN events: the chunk's slice of the tile-ordered streams (read a second time, from L2) is
-//      warped again with the Jacobian rows BEFORE Jt exists, the workgroup then waits for the passes of the 3 x 3 tiles its window
-//      lies in (tile_done[t] == seq) -- or, if any of its votes took the global path, for every pass of the launch --, reads the
-//      four Jt cells of each event with agent-scope loads, and adds its six sums to the accumulator rows;
+//   3. gathers the gradient sums of ITS OWN events, four per thread and round: the chunk's slice of the tile-ordered streams (read a
+//      second time, from L2) is warped again with the Jacobian rows -- the first round BEFORE the wait --, the workgroup waits for the
+//      passes of the 3 x 3 tiles its window lies in (tile_done[t] == seq) -- or, if any of its votes took the global path, for every
+//      pass of the launch --, reads the four Jt cells of each event (two 8-byte loads; cached loads where a line of Jt belongs to one
+//      tile, agent-scope loads otherwise: ss_ld_cells), and adds its six sums to the accumulator rows;
 //   4. arrives; the last arriver runs fg_finalize (cmx_fusedgather.hpp).
 // What the form removes from the two-launch evaluation: the gather launch's dispatch, the kernel boundary in front of it, and the
 // residency pressure of the first one-launch form (FUSE = 2: 713 + 489 workgroups with three roles competing for the CUs).
@@ -29,24 +30,16 @@
 
 namespace cmx {
 
-
-
-// The four Jt cells of N events: two 8-byte loads per event -- cells (yy, xx), (yy, xx + 1) and the pair one image row below; global
+// The four Jt cells of four events: two 8-byte loads per event -- cells (yy, xx), (yy, xx + 1) and the pair one image row below; global
 // loads need dword alignment only --, all in flight at once, ONE wait, in ONE asm statement: a register that a pending load is going
 // to write must not be visible to the compiler before the wait.
-// SC1 = true: agent-scope loads, served by the memory side every time -- always correct, but a scattered gather of 2 x 8 bytes per
-// event then moves a whole line across the fabric per load (measured: 11-22 us for a chunk's cells).
-// SC1 = false: plain loads, cached by the XCD's L2 and the CU's L1.  Correct when a cache line of Jt never spans two tiles (row
-// stride a multiple of the 32-pixel tile, 128-byte aligned base): both caches are invalidated when the launch starts, a line enters
-// them only through a load, and a workgroup loads a line only after it has seen the stamp of the ONE tile the line belongs to --
-// whose owner stored it write-through and drained its stores before the stamp.
+// SC1 = false (production): plain loads, cached by the XCD's L2 and the CU's L1, behind the agent-scope acquire that follows the wait for
+// the tiles' stamps (self_serve_tail): a line fetched afterwards holds what its tile's owner released before the stamp.
+// SC1 = true (diagnostics): agent-scope loads, served by the memory side every time -- a scattered gather of 2 x 8 bytes per event then
+// moves a whole line across the fabric per load (measured: 11-22 us for a chunk's cells against ~1 us).
 #define CMX_SS_LD(n, o, r, fl) "global_load_dwordx2 %" #n ", %" #o ", %" #r fl "\n\t"
 #define CMX_SS_LD4(fl) CMX_SS_LD(0, 8, 12, fl) CMX_SS_LD(1, 8, 13, fl) CMX_SS_LD(2, 9, 12, fl) CMX_SS_LD(3, 9, 13, fl) CMX_SS_LD(4, 10, 12, fl) \
     CMX_SS_LD(5, 10, 13, fl) CMX_SS_LD(6, 11, 12, fl) CMX_SS_LD(7, 11, 13, fl) "s_waitcnt vmcnt(0)"
-#define CMX_SS_LD8(fl) CMX_SS_LD(0, 16, 24, fl) CMX_SS_LD(1, 16, 25, fl) CMX_SS_LD(2, 17, 24, fl) CMX_SS_LD(3, 17, 25, fl) CMX_SS_LD(4, 18, 24, fl) \
-    CMX_SS_LD(5, 18, 25, fl) CMX_SS_LD(6, 19, 24, fl) CMX_SS_LD(7, 19, 25, fl) CMX_SS_LD(8, 20, 24, fl) CMX_SS_LD(9, 20, 25, fl) \
-    CMX_SS_LD(10, 21, 24, fl) CMX_SS_LD(11, 21, 25, fl) CMX_SS_LD(12, 22, 24, fl) CMX_SS_LD(13, 22, 25, fl) CMX_SS_LD(14, 23, 24, fl) \
-    CMX_SS_LD(15, 23, 25, fl) "s_waitcnt vmcnt(0)"
 template <bool SC1>
 __device__ __forceinline__ void ss_ld_cells(const float *row0, const float *row1, const unsigned (&off)[4], unsigned long long (&c)[4][2]) {
 #define CMX_SS_OPS4                                                                                                                      \
@@ -57,17 +50,8 @@ __device__ __forceinline__ void ss_ld_cells(const float *row0, const float *row1
   else asm volatile(CMX_SS_LD4("") CMX_SS_OPS4);
 #undef CMX_SS_OPS4
 }
-template <bool SC1>
-__device__ __forceinline__ void ss_ld_cells(const float *row0, const float *row1, const unsigned (&off)[8], unsigned long long (&c)[8][2]) {
-#define CMX_SS_OPS8                                                                                                                      \
-  : "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[2][0]), "=&v"(c[2][1]), "=&v"(c[3][0]), "=&v"(c[3][1]), \
-    "=&v"(c[4][0]), "=&v"(c[4][1]), "=&v"(c[5][0]), "=&v"(c[5][1]), "=&v"(c[6][0]), "=&v"(c[6][1]), "=&v"(c[7][0]), "=&v"(c[7][1])  \
-  : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "s"(row0), "s"(row1)     \
-  : "memory"
-  if (SC1) asm volatile(CMX_SS_LD8(" sc1") CMX_SS_OPS8);
-  else asm volatile(CMX_SS_LD8("") CMX_SS_OPS8);
-#undef CMX_SS_OPS8
-}
+#undef CMX_SS_LD4
+#undef CMX_SS_LD
 // the two directional differences of Jt at an event's vote cell (bilinear_grad's expressions, cmx_kernels.hip)
 __device__ __forceinline__ void ss_cell_grad(const unsigned long long (&c)[2], float dx, float dy, float &A, float &B) {
   const float i00 = __uint_as_float((unsigned)c[0]), i01 = __uint_as_float((unsigned)(c[0] >> 32));
@@ -197,7 +181,8 @@ __device__ __forceinline__ void self_serve_tail(const FeSplatArgs &a, const Binn
       if (tr && tid == 0) tr[2] = wall_clock64();
       return ran;
     });
-    // publish: every wave's write-through stores have left, then the tile's stamp and the launch's count of passes
+    // publish: every wave's write-through stores have left (the producer side of the tail finalize's protocol, cmx_kernels.hip), then
+    // the tile's stamp and the launch's count of passes
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -247,11 +232,17 @@ __device__ __forceinline__ void self_serve_tail(const FeSplatArgs &a, const Binn
       if (give_up) atomicOr(b.fallback, kFuseIncomplete);
     }
     __syncthreads();
+    // agent-scope ACQUIRE behind the stamps (every wave; buffer_inv sc1: the CU's L1 and the XCD's L2 drop what they hold of memory other
+    // XCDs write): the cell loads below are plain, cached loads.  This is what the form costs: 30 -> 48 us per launch.  WITHOUT it the
+    // launch is right on a GPU the context has to itself (both caches are invalidated when a launch starts, and a line of Jt is loaded
+    // only behind its tile's stamp) and WRONG about once in 2000 evaluations -- a few stale cells from the previous evaluation, in
+    // the XCD's L2: an L1-only invalidate does not cure it -- when three contexts share the GPU (profiles/r06_selfserve.txt section 6).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   if (tr && tid == 0) tr[6] = wall_clock64();
   // ---- step 3c: the four Jt cells of every event, the sums
   const float *row0 = f.jt, *row1 = f.jt + W;
-  const bool plain = W % kBinTile == 0 && (reinterpret_cast<unsigned long long>(f.jt) & 127ull) == 0ull;  // (see ss_ld_cells)
+  const bool plain = !(f.debug & 256);  // (diagnostics: agent-scope loads instead, see ss_ld_cells)
   ss_consume(row0, row1, plain, s0, acc);
   if (tr && tid == 0 && (f.debug & 64)) tr[2] = wall_clock64();
   if (two) {

@@ -63,9 +63,11 @@ enum {
                                pass of the tile(s) it owns, then gathers the gradient sums of its own events, the last arriver
                                finalizes.  Used only once the chunk table's exact length is known and fits the device (all workgroups
                                resident at once; 512 on an MI355X), evaluations it does not cover take form 1; a context whose launches
-                               run into the bounded waits three times (it shares the GPU) stops using it.  Parity-tested; measured a
-                               TIE with 1 (0.0349-0.0352 vs 0.0353-0.0354 ms per 1M-event evaluation, -2.7 % at a fixed point;
-                               profiles/r06_selfserve.txt) -- kept as an A/B switch.
+                               run into the bounded waits three times (it shares the GPU) stops using it.  Parity-tested; SLOWER than 1
+                               (0.054 vs 0.0353 ms per 1M-event evaluation): reading the tiles' Jt inside the launch that wrote it needs
+                               an agent-scope acquire per workgroup (an L2 invalidate) -- with plain cached loads the launch takes 30 us,
+                               a tie with 1, and is wrong about once in 2000 evaluations when contexts share the GPU
+                               (profiles/r06_selfserve.txt) -- kept as an A/B switch.
                                0: splat, image pass and gather as three launches */
 };
 

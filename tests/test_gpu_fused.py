@@ -246,7 +246,8 @@ def test_self_service_beside_other_contexts_stays_correct(hip):
                 for om, (cw, gw) in zip(pts, want):
                     c, g = fe.eval(om)
                     if not (rel_scalar(c, cw) < 1e-7 and rel_vec(g, gw) < 1e-6):
-                        errs.append((k, rep, tuple(om), c, cw, fe.stats()))
+                        st = fe.stats()
+                        errs.append((k, rep, c, cw, list(g), list(gw), rel_vec(g, gw), st["self_serve_evals"], st["fused_timeouts"], st["fused_redos"]))
                         return
             stats.append(fe.stats())
         except Exception as e:  # noqa: BLE001
