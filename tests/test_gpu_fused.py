@@ -181,8 +181,9 @@ def test_one_launch_form_matches_too(hip, oracle, small, measure):
 
 @pytest.mark.parametrize("measure", [0, 1])
 def test_self_service_one_launch_form(hip, oracle, small, measure):
-    """CMX_OPT_FUSED_IMAGE = 3: ONE launch of the chunk workgroups alone -- each runs the image pass of the tiles it owns and gathers
-    the gradient sums of its own events (cmx_selfserve.hpp).  Same numbers as the three-launch form and the oracle's, on a dense
+    """CMX_OPT_FUSED_IMAGE = 3 (an A/B switch: in its correct form -- an agent-scope acquire behind the tiles' stamps -- slower than the
+    default, profiles/r06_selfserve.txt): ONE launch of the chunk workgroups alone -- each runs the image pass of the tiles it owns and
+    gathers the gradient sums of its own events (cmx_selfserve.hpp).  Same numbers as the three-launch form and the oracle's, on a dense
     packet, a partial-tile image and a SPARSE packet (fewer chunks than tiles: workgroups own several tiles), incl. a jump beyond the
     tiles' reach (repeated after a fresh sort) and motion onto the global path (waits for every pass of the launch)."""
     sparse = synth.frontend_packet(3_001, 346, 260, 300.0, 300.0, 172.5, 129.5, seed=33)
@@ -230,7 +231,9 @@ def test_self_service_beside_other_contexts_stays_correct(hip):
     """Three host threads, each with its own self-service context on the same GPU: a launch may now find CUs taken by another context's
     workgroups, i.e. NOT all of its workgroups resident at once -- the case the form's bounded waits exist for.  Whatever happens
     (no wait runs out; or some do, the evaluation is repeated through the separate launches and after three strikes the context
-    stops using the form), every evaluation returns the three-launch form's numbers and nothing hangs."""
+    stops using the form), every evaluation returns the three-launch form's numbers and nothing hangs.  This is the test that found
+    (i) the repeat path trusting a ping-pong partner that passes which gave up never cleared and (ii) the form's cached loads of Jt
+    returning stale lines of the previous evaluation about once in 2000 evaluations -- only under sharing."""
     import threading
     p = synth.frontend_packet(300_007, 640, 480, 588.10, 593.99, 339.83, 242.43, seed=77)
     plain = _fe(hip, p, 0)
